@@ -1,0 +1,156 @@
+/*
+ * pdae.h -- C ABI of the MI355X-native Point-DAE hot path (libpdae_hip.so).
+ *
+ * This is the drop-in boundary for the pretraining step's native operators.
+ * The reference (YBZh/Point-DAE) reaches its CUDA kernels through pybind11
+ * torch extensions; every entry below names the reference host function it
+ * replaces (file:line under the reference tree) and keeps that function's
+ * argument meaning.  Differences that hold for every entry:
+ *
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     to contiguous row-major buffers owned by the caller.  Nothing is
+ *     allocated, retained or freed by the library.
+ *   - every entry takes an explicit stream (a hipStream_t passed as void*);
+ *     the reference launches chamfer/emd on the legacy default stream
+ *     (chamfer.cu:159, emd_kernel.cu:188) and pointnet2 on torch's current
+ *     stream (sampling_gpu.cu:183).  Calls are asynchronous and re-entrant.
+ *   - return value: PDAE_OK (0) or a negative pdae_status; the reference
+ *     either printf()s (chamfer.cu:166-169) or exit(-1)s (cuda_utils.h:32-41).
+ *   - outputs are fully written by the call (the reference relies on
+ *     torch::zeros in its host wrappers; here the zero-fill, where the
+ *     semantics need one, is part of the call).
+ *
+ * Arithmetic contract (shared with oracle/pdae_oracle.c): fp32, squared
+ * distances evaluated as ((dx*dx + dy*dy) + dz*dz) with every operation
+ * rounded (no FMA contraction), indices by the reference's tie rules.
+ */
+#ifndef PDAE_H
+#define PDAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pdae_stream_t; /* hipStream_t */
+
+enum pdae_status {
+  PDAE_OK = 0,
+  PDAE_ERR_BAD_ARG = -1,     /* null pointer / negative size / unsupported size */
+  PDAE_ERR_LAUNCH = -2,      /* hipGetLastError() != hipSuccess after launch    */
+  PDAE_ERR_UNSUPPORTED = -3  /* shape outside what the kernels implement         */
+};
+
+/* Library identification: returns "pdae-hip gfx950 <abi version>". */
+const char* pdae_version(void);
+/* Text for the last failing status on this thread (hipGetErrorString or arg). */
+const char* pdae_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Farthest point sampling.
+ * Replaces furthest_point_sampling_kernel_wrapper(b, n, m, dataset, temp, idxs)
+ *   extensions/pointnet2/_ext_src/src/sampling_gpu.cu:178-229 (kernel :72-176),
+ *   host alloc sampling.cpp:67-88 (third-party pointnet2_ops twin called from
+ *   utils/misc.py:18).
+ * dataset (b,n,3) f32 -> idxs (b,m) i32.  idxs[:,0]=0; points with
+ * x*x+y*y+z*z <= 1e-3 are never selected; ties resolved as the reference's
+ * 512-thread strided scan + lower-tid tree reduce.  The reference's `temp`
+ * scratch (b,n) lives in registers here and is not part of the ABI.
+ * If `centres` is non-null it receives dataset[idxs] as (b,m,3) f32 (the
+ * gather_operation + 2 transposes of utils/misc.py:19 fused).
+ */
+int pdae_furthest_point_sampling(int b, int n, int m, const float* dataset,
+                                 int32_t* idxs, float* centres /*nullable*/,
+                                 pdae_stream_t stream);
+
+/* gather_points_kernel_wrapper(b, c, n, npoints, points, idx, out)
+ *   sampling_gpu.cu:25-33: out[b,c,j] = points[b,c,idx[b,j]].            */
+int pdae_gather_points(int b, int c, int n, int npoints, const float* points,
+                       const int32_t* idx, float* out, pdae_stream_t stream);
+/* gather_points_grad_kernel_wrapper, sampling_gpu.cu:52-60: scatter-add of
+ * grad_out (b,c,npoints) into grad_points (b,c,n); grad_points is zero-filled
+ * by this call (sampling.cpp:50-52 does it with torch::zeros).            */
+int pdae_gather_points_grad(int b, int c, int n, int npoints,
+                            const float* grad_out, const int32_t* idx,
+                            float* grad_points, pdae_stream_t stream);
+
+/* query_ball_point_kernel_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
+ *   ball_query_gpu.cu:49-57 (kernel :12-47), host ball_query.cpp:11-35.
+ * idx (b,m,nsample) i32: first nsample indices k (ascending) with d2 < r*r;
+ * short lists padded with the first hit; empty ball -> zeros.              */
+int pdae_ball_query(int b, int n, int m, float radius, int nsample,
+                    const float* new_xyz, const float* xyz, int32_t* idx,
+                    pdae_stream_t stream);
+
+/* group_points_kernel_wrapper(b, c, n, npoints, nsample, points, idx, out)
+ *   group_points_gpu.cu:33-43: out[b,c,j,k] = points[b,c,idx[b,j,k]].     */
+int pdae_group_points(int b, int c, int n, int npoints, int nsample,
+                      const float* points, const int32_t* idx, float* out,
+                      pdae_stream_t stream);
+/* group_points_grad_kernel_wrapper, group_points_gpu.cu:69-78; grad_points
+ * (b,c,n) is zero-filled by this call (group_points.cpp:49-51).           */
+int pdae_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                           const float* grad_out, const int32_t* idx,
+                           float* grad_points, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * k nearest neighbours.  Replaces KNN_CUDA 0.2 `knn(ref, query, k)` as used
+ * through KNN(k, transpose_mode=True)(ref, query) at
+ * models/PointCAE_transformer.py:59,76 (third-party wheel, not in the
+ * reference tree; semantics restated in oracle/pdae_oracle.c).
+ * ref (b,n,3), query (b,g,3) -> idx (b,g,k) int64 ascending by squared
+ * distance, earlier index first on ties; dist (b,g,k) f32 = sqrtf(d2),
+ * nullable.  Requires 1 <= k <= min(n, 64).
+ * If `nbr` is non-null it receives ref[idx] - query as (b,g,k,3) f32, i.e.
+ * the flat-index gather + centre subtraction of Group.forward
+ * (models/PointCAE_transformer.py:79-85) fused into the same launch.
+ */
+int pdae_knn(int b, int n, int g, int k, const float* ref, const float* query,
+             int64_t* idx, float* dist /*nullable*/, float* nbr /*nullable*/,
+             pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Chamfer distance.  Replaces chamfer_cuda_forward(xyz1, xyz2)
+ *   extensions/chamfer_dist/chamfer.cu:147-171 (kernel :15-145) and
+ * chamfer_cuda_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+ *   chamfer.cu:203-229 (kernel :173-201); pybind names chamfer.forward /
+ *   chamfer.backward (chamfer_cuda.cpp:36-39).
+ * xyz1 (b,n,3), xyz2 (b,m,3) -> dist1 (b,n), idx1 (b,n) i32 [nearest in xyz2],
+ * dist2 (b,m), idx2 (b,m) i32 [nearest in xyz1]; lowest index wins ties.
+ * backward: grad_xyz1 (b,n,3), grad_xyz2 (b,m,3) fully written.
+ */
+int pdae_chamfer_forward(int b, int n, const float* xyz1, int m,
+                         const float* xyz2, float* dist1, float* dist2,
+                         int32_t* idx1, int32_t* idx2, pdae_stream_t stream);
+int pdae_chamfer_backward(int b, int n, const float* xyz1, int m,
+                          const float* xyz2, const int32_t* idx1,
+                          const int32_t* idx2, const float* grad_dist1,
+                          const float* grad_dist2, float* grad_xyz1,
+                          float* grad_xyz2, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Approximate earth mover's distance.  Replaces ApproxMatchForward /
+ * MatchCostForward / MatchCostBackward, extensions/emd/cuda/emd_kernel.cu
+ * :168-194, :256-280, :369-398 (kernels :25-158, :200-243, :286-355); pybind
+ * names emd_cuda.approxmatch_forward / matchcost_forward / matchcost_backward
+ * (emd.cpp:23-27).
+ * xyz1 (b,n,3), xyz2 (b,m,3); match (b,m,n) f32; cost (b) f32;
+ * temp is scratch of b*2*(n+m) floats (the reference allocates it,
+ * emd_kernel.cu:183).
+ */
+int pdae_emd_approxmatch(int b, int n, int m, const float* xyz1,
+                         const float* xyz2, float* match, float* temp,
+                         pdae_stream_t stream);
+int pdae_emd_matchcost(int b, int n, int m, const float* xyz1,
+                       const float* xyz2, const float* match, float* cost,
+                       pdae_stream_t stream);
+int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
+                            const float* xyz1, const float* xyz2,
+                            const float* match, float* grad1, float* grad2,
+                            pdae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDAE_H */

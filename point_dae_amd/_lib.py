@@ -1,0 +1,104 @@
+"""ctypes binding of libpdae_hip.so -- the C ABI declared in include/pdae.h.
+
+This is the only place the product talks to native code.  There is no CPU
+fallback: if the library is missing, or a tensor is not a contiguous float32
+(int32 / int64 where the ABI says so) tensor on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdae_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes (restype is always int unless listed in _STR)
+_SIGNATURES = {
+    "pdae_furthest_point_sampling": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_gather_points": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_gather_points_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "pdae_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_knn": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+_STR = ("pdae_version", "pdae_last_error")
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Every symbol include/pdae.h declares (used by the CPU-side ABI test)."""
+    return list(_SIGNATURES) + list(_STR)
+
+
+def lib():
+    """Load libpdae_hip.so (built by __graft_entry__.build / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). point_dae_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        for name in _STR:
+            getattr(handle, name).restype = ctypes.c_char_p
+        _lib = handle
+    return _lib
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def require(t, name, dtype=torch.float32, dim=None):
+    """Input validation of the reference's CHECK_CUDA / CHECK_CONTIGUOUS /
+    CHECK_IS_FLOAT / CHECK_IS_INT macros (extensions/pointnet2/_ext_src/include/
+    utils.h:8-28), raised as RuntimeError like AT_ASSERT does."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on the GPU (CPU not supported)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be a {dtype} tensor, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if dim is not None and t.dim() != dim:
+        raise RuntimeError(f"{name} must have {dim} dimensions, got {t.dim()}")
+    return t
+
+
+def call(name, on, *args):
+    """Invoke one C entry on torch's current stream of `on`'s device; raise on a
+    non-zero status."""
+    handle = lib()
+    if on.device.index != torch.cuda.current_device():
+        with torch.cuda.device(on.device):
+            rc = getattr(handle, name)(*args, stream_ptr())
+    else:
+        rc = getattr(handle, name)(*args, stream_ptr())
+    if rc != 0:
+        msg = handle.pdae_last_error().decode()
+        raise RuntimeError(f"{name} failed with status {rc}: {msg}")

@@ -1,0 +1,282 @@
+// chamfer.hip -- Chamfer distance forward / backward for gfx950.
+//
+// Semantics: extensions/chamfer_dist/chamfer.cu:15-145 (forward) and :173-201
+// (backward) of the reference, restated in oracle/pdae_oracle.c.  For every
+// point of one cloud: squared distance to, and index of, the nearest point of
+// the other cloud, lowest index on ties.
+//
+// The reference launches <<<dim3(32,16),512>>> whatever the shape; with the
+// Transformer path's ~5000 clouds of 32 points only 32 lanes of each block do
+// work and the backward serialises the batch over 16 blocks.
+// Here the grid follows the data:
+//   * packed kernel (small clouds): queries of consecutive clouds are packed
+//     densely into 256-thread workgroups; the candidate clouds those queries
+//     need are staged once in LDS as float4 and read back as broadcasts.
+//   * tiled kernel (large clouds): Q query points per lane in registers,
+//     candidates streamed through a 1024-point LDS tile.
+// Backward has a deterministic gather form for small clouds (bit-identical to
+// the oracle's ordering) and an atomic scatter form for large ones (the
+// reference itself accumulates with atomicAdd in unspecified order).
+#include "common.h"
+
+namespace pdae {
+
+constexpr int kPackT = 256;
+
+// ---- forward, packed small clouds ------------------------------------------
+// thread -> query row r = blockIdx.x*256 + tid of the flattened (b*n) queries.
+__global__ __launch_bounds__(kPackT) void chamfer_fwd_packed(
+    int b, int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+    float* __restrict__ dist, int32_t* __restrict__ idx) {
+  extern __shared__ float4 cand[];  // [(c1-c0+1) * m]
+  const long long total = (long long)b * n;
+  const long long r0 = (long long)blockIdx.x * kPackT;
+  const long long r1 = min(total, r0 + kPackT) - 1;
+  const int c0 = (int)(r0 / n), c1 = (int)(r1 / n);
+  const int ncand = (c1 - c0 + 1) * m;
+  const float* src = xyz2 + (size_t)c0 * m * 3;
+  for (int i = threadIdx.x; i < ncand; i += kPackT)
+    cand[i] = make_float4(src[i * 3 + 0], src[i * 3 + 1], src[i * 3 + 2], 0.f);
+  __syncthreads();
+  const long long r = r0 + threadIdx.x;
+  if (r >= total) return;
+  const int c = (int)(r / n);
+  const float x1 = xyz1[r * 3 + 0], y1 = xyz1[r * 3 + 1], z1 = xyz1[r * 3 + 2];
+  const float4* my = cand + (c - c0) * m;
+  float best = __builtin_huge_valf();
+  int besti = 0;
+#pragma unroll 4
+  for (int k = 0; k < m; ++k) {
+    const float4 q = my[k];
+    const float d = sqdist(q.x, q.y, q.z, x1, y1, z1);
+    if (d < best) {
+      best = d;
+      besti = k;
+    }
+  }
+  dist[r] = best;
+  idx[r] = besti;
+}
+
+// ---- forward, tiled large clouds -------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(256) void chamfer_fwd_tiled(int n, int m,
+                                                         const float* __restrict__ xyz1,
+                                                         const float* __restrict__ xyz2,
+                                                         float* __restrict__ dist,
+                                                         int32_t* __restrict__ idx) {
+  constexpr int TILE = 1024;
+  __shared__ float4 cand[TILE];
+  const int bi = blockIdx.y;
+  const float* p1 = xyz1 + (size_t)bi * n * 3;
+  const float* p2 = xyz2 + (size_t)bi * m * 3;
+  float x1[Q], y1[Q], z1[Q], best[Q];
+  int besti[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const int j = (blockIdx.x * Q + i) * 256 + threadIdx.x;
+    const bool in = j < n;
+    x1[i] = in ? p1[j * 3 + 0] : 0.f;
+    y1[i] = in ? p1[j * 3 + 1] : 0.f;
+    z1[i] = in ? p1[j * 3 + 2] : 0.f;
+    best[i] = __builtin_huge_valf();
+    besti[i] = 0;
+  }
+  for (int k0 = 0; k0 < m; k0 += TILE) {
+    const int cnt = min(TILE, m - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256)
+      cand[i] = make_float4(p2[(k0 + i) * 3 + 0], p2[(k0 + i) * 3 + 1], p2[(k0 + i) * 3 + 2], 0.f);
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < cnt; ++k) {
+      const float4 q = cand[k];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const float d = sqdist(q.x, q.y, q.z, x1[i], y1[i], z1[i]);
+        if (d < best[i]) {
+          best[i] = d;
+          besti[i] = k0 + k;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    const int j = (blockIdx.x * Q + i) * 256 + threadIdx.x;
+    if (j < n) {
+      dist[(size_t)bi * n + j] = best[i];
+      idx[(size_t)bi * n + j] = besti[i];
+    }
+  }
+}
+
+static bool use_packed(int n, int m) {
+  // LDS for the clouds a 256-query workgroup can touch
+  const long long clouds = (kPackT + n - 1) / n + 1;
+  return n <= 256 && clouds * m * (long long)sizeof(float4) <= 64 * 1024;
+}
+
+static void chamfer_fwd_dir(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist,
+                            int32_t* idx, hipStream_t s) {
+  if (n == 0) return;
+  if (use_packed(n, m)) {
+    const long long total = (long long)b * n;
+    const int blocks = (int)((total + kPackT - 1) / kPackT);
+    const size_t lds = (size_t)((kPackT + n - 1) / n + 1) * m * sizeof(float4);
+    hipLaunchKernelGGL(chamfer_fwd_packed, dim3(blocks), dim3(kPackT), lds, s, b, n, m, xyz1, xyz2,
+                       dist, idx);
+  } else if ((long long)b * ((n + 1023) / 1024) >= 1024 || n >= 4096) {
+    dim3 grid((n + 1023) / 1024, b);
+    hipLaunchKernelGGL((chamfer_fwd_tiled<4>), grid, dim3(256), 0, s, n, m, xyz1, xyz2, dist, idx);
+  } else {
+    dim3 grid((n + 255) / 256, b);
+    hipLaunchKernelGGL((chamfer_fwd_tiled<1>), grid, dim3(256), 0, s, n, m, xyz1, xyz2, dist, idx);
+  }
+}
+
+// ---- backward, gather form (small clouds) ----------------------------------
+// grad_a[j] = own(j) + sum over l with idx_b[l]==j of -(2 g_b[l] (b_l - a_j)),
+// scatter terms in ascending l.  own_first selects whether the own term is
+// added before (direction 1 of the oracle) or after (direction 2) them.
+__global__ __launch_bounds__(kPackT) void chamfer_bwd_packed(
+    int b, int n, int m, const float* __restrict__ xa, const float* __restrict__ xb,
+    const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_b,
+    const float* __restrict__ g_a, const float* __restrict__ g_b, float* __restrict__ grad_a,
+    int own_first) {
+  extern __shared__ float4 other[];  // per candidate: (x, y, z, 2*g) of cloud b
+  const long long total = (long long)b * n;
+  const long long r0 = (long long)blockIdx.x * kPackT;
+  const long long r1 = min(total, r0 + kPackT) - 1;
+  const int c0 = (int)(r0 / n), c1 = (int)(r1 / n);
+  const int ncand = (c1 - c0 + 1) * m;
+  int* other_idx = reinterpret_cast<int*>(other + ncand);
+  const size_t base = (size_t)c0 * m;
+  for (int i = threadIdx.x; i < ncand; i += kPackT) {
+    other[i] = make_float4(xb[(base + i) * 3 + 0], xb[(base + i) * 3 + 1],
+                           xb[(base + i) * 3 + 2], g_b[base + i] * 2);
+    other_idx[i] = idx_b[base + i];
+  }
+  __syncthreads();
+  const long long r = r0 + threadIdx.x;
+  if (r >= total) return;
+  const int c = (int)(r / n);
+  const int j = (int)(r - (long long)c * n);
+  const float x1 = xa[r * 3 + 0], y1 = xa[r * 3 + 1], z1 = xa[r * 3 + 2];
+  const float4* ob = other + (c - c0) * m;
+  const int* oi = other_idx + (c - c0) * m;
+  // own term: g (a_j - b_{idx_a[j]}), chamfer.cu:192-195
+  const int j2 = idx_a[r];
+  const float g = g_a[r] * 2;
+  const float ox = g * (x1 - ob[j2].x), oy = g * (y1 - ob[j2].y), oz = g * (z1 - ob[j2].z);
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (own_first) {
+    gx += ox;
+    gy += oy;
+    gz += oz;
+  }
+  for (int l = 0; l < m; ++l) {
+    if (oi[l] == j) {  // chamfer.cu:196-198 with the roles of the clouds swapped
+      const float4 q = ob[l];
+      gx += -(q.w * (q.x - x1));
+      gy += -(q.w * (q.y - y1));
+      gz += -(q.w * (q.z - z1));
+    }
+  }
+  if (!own_first) {
+    gx += ox;
+    gy += oy;
+    gz += oz;
+  }
+  grad_a[r * 3 + 0] = gx;
+  grad_a[r * 3 + 1] = gy;
+  grad_a[r * 3 + 2] = gz;
+}
+
+// ---- backward, scatter form (large clouds) ----------------------------------
+// pass 1 (plain stores): grad_a[j] = own(j).  pass 2: atomics for the scatter.
+__global__ void chamfer_bwd_own(long long total, int n, int m, const float* __restrict__ xa,
+                                const float* __restrict__ xb, const int32_t* __restrict__ idx_a,
+                                const float* __restrict__ g_a, float* __restrict__ grad_a) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= total) return;
+  const long long c = r / n;
+  const size_t o = ((size_t)c * m + idx_a[r]) * 3;
+  const float g = g_a[r] * 2;
+  grad_a[r * 3 + 0] = g * (xa[r * 3 + 0] - xb[o + 0]);
+  grad_a[r * 3 + 1] = g * (xa[r * 3 + 1] - xb[o + 1]);
+  grad_a[r * 3 + 2] = g * (xa[r * 3 + 2] - xb[o + 2]);
+}
+
+__global__ void chamfer_bwd_scatter(long long total, int n, int m, const float* __restrict__ xa,
+                                    const float* __restrict__ xb,
+                                    const int32_t* __restrict__ idx_a,
+                                    const float* __restrict__ g_a, float* __restrict__ grad_b) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= total) return;
+  const long long c = r / n;
+  const size_t o = ((size_t)c * m + idx_a[r]) * 3;
+  const float g = g_a[r] * 2;
+  atomicAdd(grad_b + o + 0, -(g * (xa[r * 3 + 0] - xb[o + 0])));
+  atomicAdd(grad_b + o + 1, -(g * (xa[r * 3 + 1] - xb[o + 1])));
+  atomicAdd(grad_b + o + 2, -(g * (xa[r * 3 + 2] - xb[o + 2])));
+}
+
+static bool use_packed_bwd(int n, int m) {
+  const long long clouds = (kPackT + n - 1) / n + 1;
+  return n <= 256 && m <= 256 && clouds * m * 20ll <= 64 * 1024;
+}
+
+}  // namespace pdae
+
+extern "C" int pdae_chamfer_forward(int b, int n, const float* xyz1, int m, const float* xyz2,
+                                    float* dist1, float* dist2, int32_t* idx1, int32_t* idx2,
+                                    pdae_stream_t stream) {
+  using namespace pdae;
+  if (b < 0 || n < 0 || m < 0) return bad_arg("chamfer_forward: negative size");
+  if (b == 0 || (n == 0 && m == 0)) return PDAE_OK;
+  if (n == 0 || m == 0) return bad_arg("chamfer_forward: one cloud is empty");
+  if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2)
+    return bad_arg("chamfer_forward: null pointer");
+  if (b > 65535 && !(use_packed(n, m) && use_packed(m, n)))
+    return unsupported("chamfer_forward: b > 65535 with large clouds");
+  hipStream_t s = as_stream(stream);
+  chamfer_fwd_dir(b, n, m, xyz1, xyz2, dist1, idx1, s);
+  chamfer_fwd_dir(b, m, n, xyz2, xyz1, dist2, idx2, s);
+  return check_launch("chamfer_forward");
+}
+
+extern "C" int pdae_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz2,
+                                     const int32_t* idx1, const int32_t* idx2,
+                                     const float* grad_dist1, const float* grad_dist2,
+                                     float* grad_xyz1, float* grad_xyz2, pdae_stream_t stream) {
+  using namespace pdae;
+  if (b < 0 || n < 0 || m < 0) return bad_arg("chamfer_backward: negative size");
+  if (b == 0 || (n == 0 && m == 0)) return PDAE_OK;
+  if (n == 0 || m == 0) return bad_arg("chamfer_backward: one cloud is empty");
+  if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_dist1 || !grad_dist2 || !grad_xyz1 || !grad_xyz2)
+    return bad_arg("chamfer_backward: null pointer");
+  hipStream_t s = as_stream(stream);
+  const long long t1 = (long long)b * n, t2 = (long long)b * m;
+  if (use_packed_bwd(n, m) && use_packed_bwd(m, n)) {
+    const size_t lds1 = (size_t)((kPackT + n - 1) / n + 1) * m * 20;
+    const size_t lds2 = (size_t)((kPackT + m - 1) / m + 1) * n * 20;
+    hipLaunchKernelGGL(chamfer_bwd_packed, dim3((unsigned)((t1 + kPackT - 1) / kPackT)),
+                       dim3(kPackT), lds1, s, b, n, m, xyz1, xyz2, idx1, idx2, grad_dist1,
+                       grad_dist2, grad_xyz1, 1);
+    hipLaunchKernelGGL(chamfer_bwd_packed, dim3((unsigned)((t2 + kPackT - 1) / kPackT)),
+                       dim3(kPackT), lds2, s, b, m, n, xyz2, xyz1, idx2, idx1, grad_dist2,
+                       grad_dist1, grad_xyz2, 0);
+  } else {
+    const int T = 256;
+    hipLaunchKernelGGL(chamfer_bwd_own, dim3((unsigned)((t1 + T - 1) / T)), dim3(T), 0, s, t1, n, m,
+                       xyz1, xyz2, idx1, grad_dist1, grad_xyz1);
+    hipLaunchKernelGGL(chamfer_bwd_own, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2, m, n,
+                       xyz2, xyz1, idx2, grad_dist2, grad_xyz2);
+    hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t1 + T - 1) / T)), dim3(T), 0, s, t1,
+                       n, m, xyz1, xyz2, idx1, grad_dist1, grad_xyz2);
+    hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2,
+                       m, n, xyz2, xyz1, idx2, grad_dist2, grad_xyz1);
+  }
+  return check_launch("chamfer_backward");
+}

@@ -1,0 +1,104 @@
+// common.h -- shared helpers of the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pdae.h"
+
+namespace pdae {
+
+constexpr int kWave = 64;
+
+// Records the reason of the last failing status (thread local, host side).
+void set_error(const char* msg);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(hipGetErrorString(e));
+    (void)what;
+    return PDAE_ERR_LAUNCH;
+  }
+  return PDAE_OK;
+}
+
+inline int bad_arg(const char* msg) {
+  set_error(msg);
+  return PDAE_ERR_BAD_ARG;
+}
+
+inline int unsupported(const char* msg) {
+  set_error(msg);
+  return PDAE_ERR_UNSUPPORTED;
+}
+
+inline hipStream_t as_stream(pdae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// The squared distance every geometry kernel uses.  Written exactly like the
+// reference kernels write it and compiled with -ffp-contract=off:
+// ((dx*dx + dy*dy) + dz*dz), each operation rounded.
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by,
+                                        float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// ---- 64-lane shuffles on 64-bit keys (two ds_bpermute each) ----------------
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src_lane) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)(v & 0xffffffffull), src_lane, kWave);
+  const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src_lane, kWave);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---- DPP helpers ----------------------------------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm 0x00-0xff, row_shr:n 0x110+n,
+// row_mirror 0x140, row_half_mirror 0x141.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = dpp_u32<CTRL>((unsigned)(v & 0xffffffffull));
+  const unsigned hi = dpp_u32<CTRL>((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long max_u64(unsigned long long a,
+                                                      unsigned long long b) {
+  return a > b ? a : b;
+}
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long a,
+                                                      unsigned long long b) {
+  return a < b ? a : b;
+}
+
+// Max of a 64-bit key over the wave; result is wave-uniform (held in SGPRs).
+// In-row butterfly with DPP (xor1, xor2, half-mirror, mirror), then the four
+// row values are read with v_readlane and combined on the scalar unit.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  v = max_u64(v, dpp_u64<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = max_u64(v, dpp_u64<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = max_u64(v, dpp_u64<0x141>(v));  // row_half_mirror
+  v = max_u64(v, dpp_u64<0x140>(v));  // row_mirror
+  const unsigned lo = (unsigned)(v & 0xffffffffull), hi = (unsigned)(v >> 32);
+  unsigned long long r = 0;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)lo, row * 16);
+    const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hi, row * 16);
+    r = max_u64(r, ((unsigned long long)h << 32) | l);
+  }
+  return r;
+}
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+}  // namespace pdae

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_ops():
+    from oracle import ops
+    ops.build()
+    return ops
+
+
+def make_clouds(seed, B, N, kind="uniform"):
+    """Seeded synthetic clouds used on both sides of every parity test."""
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":          # what the reference's own tests use (torch.rand)
+        return rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    if kind == "shapes":
+        from point_dae_amd.synthetic import shapenet_like_clouds
+        return shapenet_like_clouds(B, N, seed=seed)
+    raise ValueError(kind)
