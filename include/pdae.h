@@ -111,6 +111,24 @@ int pdae_knn(int b, int n, int g, int k, const float* ref, const float* query,
              pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * In-forward patch corruption.  Fuses, for PointCAE_transformer.forward
+ * (models/PointCAE_transformer.py:680-684):
+ *     neighborhood += center; (t_nb, t_c) = corrupt_data(neighborhood, center);
+ *     neighborhood -= center;  t_nb -= t_c
+ * where corrupt_data (datasets/corrupt_util_tensor.py:706-727) applies 1-3
+ * per-sample linear maps ('translate' / 'scale_nonorm' multiply by a 3-vector,
+ * :59-116; 'rotate' / 'reflection' / 'shear' right-multiply by a 3x3 matrix,
+ * :139-342).  The maps are drawn on the host with the reference's RNG calls and
+ * passed as steps (nsteps, b, 10) f32: [kind (0 = multiply, 1 = matrix), then
+ * 3 factors or 9 row-major matrix entries].
+ * nbr (b,g,k,3) centre-subtracted, center (b,g,3) ->
+ * gt_nbr (b,g,k,3) = (nbr + c) - c, t_nbr (b,g,k,3), t_center (b,g,3).
+ */
+int pdae_patch_affine(int b, int g, int k, int nsteps, const float* nbr,
+                      const float* center, const float* steps, float* gt_nbr,
+                      float* t_nbr, float* t_center, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Chamfer distance.  Replaces chamfer_cuda_forward(xyz1, xyz2)
  *   extensions/chamfer_dist/chamfer.cu:147-171 (kernel :15-145) and
  * chamfer_cuda_backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)

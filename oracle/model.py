@@ -1,0 +1,360 @@
+"""Plain-PyTorch fp32 restatement of the reference's pretraining models, on CPU.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Geometry ops come from the
+C oracle (oracle/ops.py); everything else is ordinary torch.nn so that it can
+be checked directly against the reference's own Python classes imported in the
+dev container (tests/golden/make_fixtures.py) -- parameter names equal the
+reference's state_dict keys, so one state_dict drives both.  It is also the
+model half of bench.py's cpu_baseline.
+
+Restates: models/PointCAE_transformer.py (Encoder :20-51, Group :54-86,
+Mlp :94-110, Attention :113-137, Block :140-158, TransformerEncoder :161-177,
+TransformerDecoder :200-232, MaskTransformer :304-469, PointCAE_transformer
+:616-742), datasets/corrupt_util_tensor.py (:59-348, :706-727) and
+models/PointCAE_pointnetv2.py :61-173 + models/pointnetv2_util.py :319-346.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- native ops
+class _Chamfer(torch.autograd.Function):
+    """extensions/chamfer_dist/__init__.py:14-26"""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        d1, d2, i1, i2 = (torch.from_numpy(a) for a in O.chamfer_forward(_np(xyz1), _np(xyz2)))
+        ctx.save_for_backward(xyz1, xyz2, i1, i2)
+        ctx.mark_non_differentiable(i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, g1, g2, *_):
+        xyz1, xyz2, i1, i2 = ctx.saved_tensors
+        a, b = O.chamfer_backward(_np(xyz1), _np(xyz2), _np(i1), _np(i2), _np(g1), _np(g2))
+        return torch.from_numpy(a), torch.from_numpy(b)
+
+
+def chamfer_l2(a, b):
+    d1, d2, _, _ = _Chamfer.apply(a.contiguous(), b.contiguous())
+    return d1.mean() + d2.mean()
+
+
+def chamfer_l1(a, b):
+    d1, d2, _, _ = _Chamfer.apply(a.contiguous(), b.contiguous())
+    return (d1.sqrt().mean() + d2.sqrt().mean()) / 2
+
+
+class _Grouping(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.N = features.shape[2]
+        return torch.from_numpy(O.grouping_operation(_np(features), _np(idx)))
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return torch.from_numpy(O.grouping_operation_grad(_np(g.contiguous()), _np(idx), ctx.N)), None
+
+
+def group_divider(xyz, num_group, group_size):
+    """Group.forward (PointCAE_transformer.py:61-86): FPS centres, kNN, gather,
+    subtract centre."""
+    x = _np(xyz)
+    _, center = O.furthest_point_sample(x, num_group, return_centres=True)
+    _, _, nbr = O.knn(x, center, group_size, return_nbr=True)
+    return torch.from_numpy(nbr), torch.from_numpy(center)
+
+
+# ------------------------------------------------------ in-forward corruption
+AFFINE = ['translate', 'scale_nonorm', 'rotate', 'reflection', 'shear']
+
+
+def _eye(B):
+    return torch.eye(3).expand((B, 3, 3)).clone().float()
+
+
+def draw_affine_step(name, B):
+    """One level-4 affine corruption as ('mul', (B,3)) or ('mat', (B,3,3)); the
+    host RNG calls are the reference's, in its order
+    (corrupt_util_tensor.py:59-116, :139-191, :258-292, :307-342)."""
+    if name == 'scale_nonorm':
+        s = 2.0
+        return 'mul', torch.FloatTensor(B, 1, 1, 3).uniform_(1. / s, s).reshape(B, 3)
+    if name == 'translate':        # multiplies (sic), :88,113
+        s = 0.5
+        return 'mul', torch.FloatTensor(B, 1, 1, 3).uniform_(-s, s).reshape(B, 3)
+    if name == 'rotate':
+        clip = math.pi / 5 * (4 + 1)
+        ang = torch.FloatTensor(B, 3).uniform_(-clip, clip)
+        Rx, Ry, Rz = _eye(B), _eye(B), _eye(B)
+        Rx[:, 1, 1] = torch.cos(ang[:, 0]); Rx[:, 1, 2] = -torch.sin(ang[:, 0])
+        Rx[:, 2, 1] = torch.sin(ang[:, 0]); Rx[:, 2, 2] = torch.cos(ang[:, 0])
+        Ry[:, 0, 0] = torch.cos(ang[:, 1]); Ry[:, 0, 2] = torch.sin(ang[:, 1])
+        Ry[:, 2, 0] = -torch.sin(ang[:, 1]); Ry[:, 2, 2] = torch.cos(ang[:, 1])
+        Rz[:, 0, 0] = torch.cos(ang[:, 2]); Rz[:, 0, 1] = -torch.sin(ang[:, 2])
+        Rz[:, 1, 0] = torch.sin(ang[:, 2]); Rz[:, 1, 1] = torch.cos(ang[:, 2])
+        return 'mat', torch.matmul(Rz, torch.matmul(Ry, Rx))
+    if name == 'reflection':
+        r = torch.from_numpy(np.random.choice(np.array([1, -1]), size=(B, 3)))
+        Rx, Ry, Rz = _eye(B), _eye(B), _eye(B)
+        Rx[:, 0, 0] = r[:, 0]
+        Ry[:, 1, 1] = r[:, 1]
+        Rz[:, 0, 0] = r[:, 2]      # z-flip lands on x (sic), :280
+        return 'mat', torch.matmul(Rz, torch.matmul(Ry, Rx))
+    if name == 'shear':
+        sh = torch.from_numpy(np.random.uniform(-0.5, 0.5, size=(B, 6)))
+        R = _eye(B)
+        R[:, 0, 1] = sh[:, 0]; R[:, 0, 2] = sh[:, 1]; R[:, 1, 0] = sh[:, 2]
+        R[:, 1, 2] = sh[:, 3]; R[:, 2, 0] = sh[:, 4]; R[:, 2, 1] = sh[:, 5]
+        return 'mat', R
+    raise KeyError(name)
+
+
+def draw_corruption(corrupt_type, B):
+    """corrupt_data (corrupt_util_tensor.py:706-727) up to the RNG draws: the
+    list of affine steps for this batch."""
+    steps = []
+    for item in corrupt_type:
+        if item in ('clean', 'Drop-Patch'):
+            continue
+        if item == 'affine_r3':
+            number = random.choice([1, 2, 3])
+            for name in random.sample(AFFINE, number):
+                steps.append(draw_affine_step(name, B))
+        else:
+            raise NotImplementedError(item)
+    return steps
+
+
+def apply_corruption(neighborhood, center, steps):
+    for kind, p in steps:
+        if kind == 'mul':
+            neighborhood = neighborhood * p[:, None, None, :]
+            center = center * p[:, None, :]
+        else:
+            neighborhood = torch.matmul(neighborhood, p[:, None])
+            center = torch.matmul(center, p)
+    return neighborhood, center
+
+
+def draw_mask(B, G, mask_ratio, rand_ratio):
+    """MaskTransformer._mask_center_rand (PointCAE_transformer.py:395-422):
+    one ratio per batch, int(ratio*G) masked per sample, numpy shuffle."""
+    if rand_ratio == 'True':
+        mask_ratio = torch.FloatTensor(1).uniform_(0.5, 0.8).item()
+    num_mask = int(mask_ratio * G)
+    overall = np.zeros([B, G])
+    for i in range(B):
+        m = np.hstack([np.zeros(G - num_mask), np.ones(num_mask)])
+        np.random.shuffle(m)
+        overall[i, :] = m
+    return torch.from_numpy(overall).to(torch.bool)
+
+
+# ------------------------------------------------------------------- layers
+class DropPath(nn.Module):
+    """timm 0.4.5 drop_path (per-sample stochastic depth)."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if self.p == 0. or not self.training:
+            return x
+        keep = 1 - self.p
+        r = keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+        r.floor_()
+        return x.div(keep) * r
+
+
+class Encoder(nn.Module):
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, encoder_channel, 1))
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        f = self.first_conv(point_groups.reshape(bs * g, n, 3).transpose(2, 1))
+        fg = f.max(dim=2, keepdim=True)[0]
+        f = self.second_conv(torch.cat([fg.expand(-1, -1, n), f], dim=1))
+        return f.max(dim=2)[0].reshape(bs, g, self.encoder_channel)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        return self.proj((attn @ v).transpose(1, 2).reshape(B, N, C))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, drop_path):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * 4.))
+        self.attn = Attention(dim, num_heads)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
+        super().__init__()
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+
+    def forward(self, x, pos):
+        for blk in self.blocks:
+            x = blk(x + pos)
+        return x
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
+        super().__init__()
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim)
+        self.head = nn.Identity()
+        for m in self.modules():      # :216-223
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x, pos, return_token_num=-1):
+        for blk in self.blocks:
+            x = blk(x + pos)
+        if return_token_num == -1:
+            return self.norm(x)
+        return self.norm(x[:, -return_token_num:])
+
+
+def _pos_embed(dim):
+    return nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim))
+
+
+class MaskTransformer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.mask_ratio, self.rand_ratio = tc.mask_ratio, tc.rand_ratio
+        self.trans_dim, self.depth = tc.trans_dim, tc.depth
+        self.encoder = Encoder(tc.encoder_dims)
+        self.pos_embed = _pos_embed(self.trans_dim)
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.trans_dim, self.depth, tc.num_heads, dpr)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        for m in self.modules():      # :353-364
+            if isinstance(m, (nn.Linear, nn.Conv1d)):
+                nn.init.trunc_normal_(m.weight, std=.02, a=-2., b=2.)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, neighborhood, center, mask=None):
+        tokens = self.encoder(neighborhood)
+        B, G, C = tokens.shape
+        if mask is None:
+            mask = draw_mask(B, G, self.mask_ratio, self.rand_ratio)
+        x_vis = tokens[~mask].reshape(B, -1, C)
+        pos = self.pos_embed(center[~mask].reshape(B, -1, 3))
+        return self.norm(self.blocks(x_vis, pos)), mask
+
+
+class PointCAE_transformer(nn.Module):
+    """models/PointCAE_transformer.py:616-742, 'Drop-Patch' branch with
+    all_patch 'False' or 'True'."""
+
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.trans_dim = tc.trans_dim
+        assert 'Drop-Patch' in config.corrupt_type
+        self.MAE_encoder = MaskTransformer(config)
+        self.group_size, self.num_group = config.group_size, config.num_group
+        self.corrupt_type, self.all_patch = config.corrupt_type, config.all_patch
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.decoder_pos_embed = _pos_embed(self.trans_dim)
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
+        self.MAE_decoder = TransformerDecoder(self.trans_dim, tc.decoder_depth, tc.decoder_num_heads, dpr)
+        self.increase_dim = nn.Sequential(nn.Conv1d(self.trans_dim, 3 * self.group_size, 1))
+        nn.init.trunc_normal_(self.mask_token, std=.02, a=-2., b=2.)
+        self.loss_func = {'cdl1': chamfer_l1, 'cdl2': chamfer_l2}[config.loss]
+
+    def forward(self, corrupted_pts, pts, mask=None, steps=None, capture=None):
+        pts = pts[:, :, :3].contiguous()
+        neighborhood, center = group_divider(pts, self.num_group, self.group_size)
+        neighborhood = neighborhood + center.unsqueeze(2)
+        if steps is None:
+            steps = draw_corruption(self.corrupt_type, pts.shape[0])
+        t_nb, t_c = apply_corruption(neighborhood, center, steps)
+        neighborhood = neighborhood - center.unsqueeze(2)
+        t_nb = t_nb - t_c.unsqueeze(2)
+        x_vis, mask = self.MAE_encoder(t_nb, t_c, mask)
+        B, _, C = x_vis.shape
+        pos_vis = self.decoder_pos_embed(center[~mask]).reshape(B, -1, C)
+        pos_mask = self.decoder_pos_embed(center[mask]).reshape(B, -1, C)
+        N = pos_mask.shape[1]
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1)], dim=1)
+        pos_full = torch.cat([pos_vis, pos_mask], dim=1)
+        if self.all_patch == 'True':
+            x_rec = self.MAE_decoder(x_full, pos_full)
+            gt = torch.cat((neighborhood[~mask].reshape(B, -1, self.group_size, 3),
+                            neighborhood[mask].reshape(B, -1, self.group_size, 3)), dim=1)
+        else:
+            x_rec = self.MAE_decoder(x_full, pos_full, N)
+            gt = neighborhood[mask]
+        B, M, C = x_rec.shape
+        rebuild = self.increase_dim(x_rec.transpose(1, 2)).transpose(1, 2).reshape(B * M, -1, 3)
+        gt = gt.reshape(B * M, -1, 3)
+        loss1 = self.loss_func(rebuild, gt)
+        if capture is not None:
+            capture.update(center=center, neighborhood=neighborhood, t_nb=t_nb, t_c=t_c, mask=mask,
+                           x_vis=x_vis, x_rec=x_rec, rebuild=rebuild, gt=gt)
+        return loss1, torch.zeros(1)

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "pdae_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_knn": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_patch_affine": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,291 @@
+"""Transformer denoising auto-encoder of the pretraining step, MI355X host side.
+
+Keeps the reference's model API and state_dict layout
+(models/PointCAE_transformer.py: Encoder :20-51, Group :54-86, Block :140-158,
+MaskTransformer :304-469, PointCAE_transformer :616-742):
+
+    model = MODELS.build(cfg.model)
+    loss_xyz, loss_normal = model(corrupted_pts, pts)
+
+Parameter names equal the reference's, so its checkpoints load unchanged.  The
+data path is not the reference's: grouping is FPS+centre gather in one launch
+and kNN+neighbourhood gather in one launch, the in-forward corruption is one
+kernel, tokens are kept flat as (B*T, C) rows for the GEMMs, the visible /
+masked token shuffles are two index_selects on precomputed row ids (the
+reference boolean-indexes five times), and the loss runs on the packed Chamfer
+kernels.  There is no CPU path: the geometry operators raise off-GPU.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import nn_ops
+from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from .corrupt_util_tensor import corrupt_patches, draw_corruption
+from .knn_cuda import knn
+from .pointnet2_utils import furthest_point_sample_with_centres
+from .registry import MODELS
+
+
+def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
+    """timm.models.layers.trunc_normal_ (absolute cut-offs a, b)."""
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+class Group(nn.Module):
+    """FPS centres + kNN patches, centre-subtracted (Group.forward :61-86)."""
+
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group, self.group_size = num_group, group_size
+
+    @torch.no_grad()
+    def forward(self, xyz):
+        _, center = furthest_point_sample_with_centres(xyz, self.num_group)
+        _, _, neighborhood = knn(xyz, center, self.group_size, with_neighbourhood=True)
+        return neighborhood, center
+
+
+class Encoder(nn.Module):
+    """mini-PointNet patch embedder (:20-51); parameters live in the reference's
+    Sequential layout, the forward is nn_ops.patch_embed."""
+
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, encoder_channel, 1))
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        tok = nn_ops.patch_embed(point_groups.reshape(bs * g, n, 3), self.first_conv, self.second_conv,
+                                 self.training)
+        return tok.reshape(bs, g, self.encoder_channel)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    """pre-LN block (:140-158): x += dp(attn(ln1 x)); x += dp(mlp(ln2 x))."""
+
+    def __init__(self, dim, num_heads, drop_path=0.):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * 4.))
+        self.attn = Attention(dim, num_heads)
+        self.drop_prob = float(drop_path)
+
+    def forward(self, x, pos, B, T):
+        """x, pos: (B*T, C) rows; computes block(x + pos)."""
+        return nn_ops.transformer_block(x, pos, B, T, self, self.training)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
+        super().__init__()
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+
+    def forward(self, x, pos, B, T):
+        for blk in self.blocks:        # position re-added before EVERY block (:174-177)
+            x = blk(x, pos, B, T)
+        return x
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
+        super().__init__()
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim)
+        self.head = nn.Identity()
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):              # :216-223
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x, pos, B, T, return_token_num=-1):
+        for blk in self.blocks:
+            x = blk(x, pos, B, T)
+        C = x.shape[-1]
+        if return_token_num != -1:     # the masked tokens sit last in every sample (:229-231)
+            x = x.reshape(B, T, C)[:, -return_token_num:].reshape(-1, C)
+        return nn_ops.layer_norm(x, self.norm)
+
+
+def _pos_embed(dim):
+    return nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim))
+
+
+def draw_mask(B, G, mask_ratio, rand_ratio):
+    """MaskTransformer._mask_center_rand (:395-422) with the reference's host
+    RNG calls: one ratio ~ U(0.5, 0.8) per BATCH when rand_ratio == 'True',
+    int(ratio * G) masked groups per sample, numpy shuffle per sample.
+    -> (bool mask (B,G) on the host, ratio actually used)."""
+    if rand_ratio == 'True':
+        mask_ratio = torch.FloatTensor(1).uniform_(0.5, 0.8).item()
+    num_mask = int(mask_ratio * G)
+    overall = np.zeros([B, G])
+    for i in range(B):
+        m = np.hstack([np.zeros(G - num_mask), np.ones(num_mask)])
+        np.random.shuffle(m)
+        overall[i, :] = m
+    return torch.from_numpy(overall).to(torch.bool), mask_ratio
+
+
+def mask_row_ids(mask):
+    """Flat row ids (into B*G) of the visible and of the masked groups, each in
+    ascending group order per sample -- what tokens[~mask] / tokens[mask] select."""
+    B, G = mask.shape
+    rows = torch.arange(B * G).reshape(B, G)
+    return rows[~mask].reshape(-1), rows[mask].reshape(-1)
+
+
+class MaskTransformer(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        tc = config.transformer_config
+        self.mask_ratio, self.rand_ratio = tc.mask_ratio, tc.rand_ratio
+        self.trans_dim, self.depth = tc.trans_dim, tc.depth
+        self.drop_path_rate, self.num_heads = tc.drop_path_rate, tc.num_heads
+        self.encoder_dims = tc.encoder_dims
+        self.num_group, self.group_size = config.num_group, config.group_size
+        if tc.get('enc_arch', 'PointViT') != 'PointViT':
+            raise NotImplementedError("enc_arch '3detr' is outside the pretraining hot path")
+        self.mask_type = tc.mask_type
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.pos_embed = _pos_embed(self.trans_dim)
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.trans_dim, self.depth, self.num_heads, dpr)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):              # :353-364
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _mask_center_rand(self, center, noaug=False):
+        B, G, _ = center.shape
+        if noaug or self.mask_ratio == 0:
+            return torch.zeros(B, G, dtype=torch.bool)
+        if self.mask_type != 'rand':
+            raise NotImplementedError
+        mask, self.mask_ratio = draw_mask(B, G, self.mask_ratio, self.rand_ratio)   # stateful, :406-408
+        self.num_mask = int(self.mask_ratio * G)
+        return mask
+
+    def forward(self, neighborhood, center, noaug=False, mask=None):
+        """-> x_vis rows (B*Tvis, C), host bool mask (B,G), (vis_rows, mask_rows) on device."""
+        tokens = self.encoder(neighborhood)                    # every group is embedded (:437)
+        B, G, C = tokens.shape
+        if mask is None:
+            mask = self._mask_center_rand(center, noaug=noaug)
+        vis_rows, mask_rows = (r.to(tokens.device) for r in mask_row_ids(mask.cpu()))
+        Tvis = vis_rows.numel() // B
+        x_vis = tokens.reshape(B * G, C).index_select(0, vis_rows)
+        pos = nn_ops.pos_embed(center.reshape(B * G, 3).index_select(0, vis_rows), self.pos_embed)
+        x_vis = self.blocks(x_vis, pos, B, Tvis)
+        return nn_ops.layer_norm(x_vis, self.norm), mask, (vis_rows, mask_rows)
+
+
+@MODELS.register_module()
+class PointCAE_transformer(nn.Module):
+    """models/PointCAE_transformer.py:616-742 ('Drop-Patch' configurations)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        tc = config.transformer_config
+        self.trans_dim = tc.trans_dim
+        if 'Drop-Patch' not in config.corrupt_type:
+            raise NotImplementedError("only the 'Drop-Patch' (masked) variant is on the hot path")
+        self.MAE_encoder = MaskTransformer(config)
+        self.group_size, self.num_group = config.group_size, config.num_group
+        self.corrupt_type, self.all_patch = config.corrupt_type, config.all_patch
+        self.drop_path_rate = tc.drop_path_rate
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.decoder_pos_embed = _pos_embed(self.trans_dim)
+        self.decoder_depth, self.decoder_num_heads = tc.decoder_depth, tc.decoder_num_heads
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.decoder_depth)]
+        self.MAE_decoder = TransformerDecoder(self.trans_dim, self.decoder_depth, self.decoder_num_heads, dpr)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.increase_dim = nn.Sequential(nn.Conv1d(self.trans_dim, 3 * self.group_size, 1))
+        trunc_normal_(self.mask_token, std=.02)
+        self.loss = config.loss
+        self.build_loss_func(self.loss)
+
+    def build_loss_func(self, loss_type):
+        if loss_type == 'cdl1':
+            self.loss_func = ChamferDistanceL1()
+        elif loss_type == 'cdl2':
+            self.loss_func = ChamferDistanceL2()
+        else:
+            raise NotImplementedError(loss_type)
+
+    def forward(self, corrupted_pts, pts, vis=False, mask=None, steps=None, capture=None, **kwargs):
+        """`corrupted_pts` is ignored on this path, as in the reference (:676).
+        `mask` (B,G) bool and `steps` (nsteps,B,10) inject the random draws
+        (parity tests); by default they come from the host RNGs like the
+        reference's."""
+        pts = pts[:, :, :3].contiguous()
+        B = pts.shape[0]
+        neighborhood, center = self.group_divider(pts)
+        if steps is None:
+            steps = draw_corruption(self.corrupt_type, B)
+        gt_nb, t_nb, t_c = corrupt_patches(neighborhood, center, steps)
+
+        x_vis, mask, (vis_rows, mask_rows) = self.MAE_encoder(t_nb, t_c, mask=mask)
+        C = x_vis.shape[-1]
+        G = self.num_group
+        Tvis = vis_rows.numel() // B
+        M = G - Tvis
+        # decoder positions come from the UN-transformed centres (:695-696)
+        ctr = center.reshape(B * G, 3)
+        order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
+        pos_full = nn_ops.pos_embed(ctr.index_select(0, order), self.decoder_pos_embed)
+        x_full = torch.cat([x_vis.reshape(B, Tvis, C), self.mask_token.expand(B, M, -1)], dim=1)
+        x_full = x_full.reshape(B * G, C)
+        if self.all_patch == 'True':
+            x_rec = self.MAE_decoder(x_full, pos_full, B, G)
+            gt_rows, R = order, G
+        else:
+            x_rec = self.MAE_decoder(x_full, pos_full, B, G, M)
+            gt_rows, R = mask_rows, M
+        rebuild = nn_ops.conv1x1(x_rec, self.increase_dim[0]).reshape(B * R, self.group_size, 3)
+        gt_points = gt_nb.reshape(B * G, self.group_size, 3).index_select(0, gt_rows)
+        loss1 = self.loss_func(rebuild, gt_points)
+        if capture is not None:
+            capture.update(center=center, neighborhood=gt_nb, t_nb=t_nb, t_c=t_c, mask=mask,
+                           x_vis=x_vis.reshape(B, Tvis, C), x_rec=x_rec.reshape(B, R, C),
+                           rebuild=rebuild, gt=gt_points)
+        return loss1, torch.zeros(1, device=loss1.device)

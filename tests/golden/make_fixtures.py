@@ -1,0 +1,106 @@
+"""Generate the golden fixtures of tests/golden/ from the LIVE reference.
+
+Runs only in the dev container (needs /root/reference, imported read-only via
+ref_import.py with the native ops replaced by the CPU oracle).  What is
+committed is data: inputs, the captured random draws, and the reference's
+outputs -- never reference source.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_import as R          # noqa: E402
+from weights import fill_state  # noqa: E402
+
+
+def _sample(t, n=256):
+    flat = t.detach().reshape(-1)
+    idx = np.linspace(0, flat.numel() - 1, min(n, flat.numel())).astype(np.int64)
+    return flat[idx].numpy(), idx
+
+
+def transformer_fixture(name, B, seed, overrides):
+    from easydict import EasyDict
+    import yaml
+    import models.PointCAE_transformer as M
+    from oracle import model as OM
+    from point_dae_amd import corrupt_util_tensor as C
+    from point_dae_amd.point_cae_transformer import draw_mask
+    from point_dae_amd.synthetic import shapenet_like_clouds
+
+    cfg_path = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'
+    cfg = EasyDict(yaml.safe_load(open(os.path.join(R.REF, cfg_path)))['model'])
+    for k, v in overrides.items():
+        node = cfg
+        parts = k.split('.')
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    R.seed_all(seed)
+    ref = fill_state(M.PointCAE_transformer(cfg), seed)
+    ref.train()
+    pts = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed))
+
+    cap = {}
+    ref.group_divider.register_forward_hook(lambda m, i, o: cap.update(center=o[1]))
+    ref.MAE_encoder.encoder.register_forward_hook(lambda m, i, o: cap.update(tokens=o, t_nb=i[0]))
+    ref.MAE_encoder.register_forward_hook(lambda m, i, o: cap.update(x_vis=o[0], mask=o[1]))
+    ref.MAE_decoder.register_forward_hook(lambda m, i, o: cap.update(x_rec=o))
+
+    # the random draws the reference is about to make (same RNG calls, same order)
+    R.seed_all(seed + 1)
+    steps = C.draw_corruption(cfg.corrupt_type, B)
+    mask, _ = draw_mask(B, cfg.num_group, cfg.transformer_config.mask_ratio, cfg.transformer_config.rand_ratio)
+    R.seed_all(seed + 1)
+    loss, loss2 = ref(pts, pts)
+    loss.backward()
+    assert torch.equal(cap['mask'], mask), 'mask draw does not reproduce the reference'
+
+    # cross-check: the oracle model with the captured draws injected reproduces the reference bit for bit
+    orc = OM.PointCAE_transformer(cfg)
+    orc.load_state_dict(ref.state_dict())
+    osteps = [('mul', s[:, 1:4]) if s[0, 0] == 0 else ('mat', s[:, 1:].reshape(B, 3, 3)) for s in steps]
+    oloss, _ = orc(pts, pts, mask=mask, steps=osteps)
+    assert oloss.item() == loss.item(), (oloss.item(), loss.item())
+
+    out = dict(seed=np.int64(seed), B=np.int64(B), pts=pts.numpy(), steps=steps.numpy(), mask=mask.numpy(),
+               loss=np.float32(loss.item()), loss2=loss2.detach().numpy(),
+               center=cap['center'].numpy(), tokens=cap['tokens'].detach().numpy(),
+               t_nb=cap['t_nb'].detach().numpy()[:, ::8], x_vis=cap['x_vis'].detach().numpy(),
+               x_rec=cap['x_rec'].detach().numpy(),
+               overrides=np.array(repr(sorted(overrides.items()))))
+    for pname, p in ref.named_parameters():
+        g = p.grad
+        key = 'grad/' + pname
+        out[key + '/norm'] = np.float64(g.double().norm().item())
+        if g.numel() <= 1536:
+            out[key + '/full'] = g.numpy()
+        else:
+            out[key + '/sample'], _ = _sample(g)
+    for bname, b in ref.named_buffers():         # BatchNorm running statistics after one step
+        if b.dtype.is_floating_point:
+            out['buf/' + bname] = b.numpy()
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(name, 'loss', loss.item(), 'steps', steps.shape, 'masked', int(mask[0].sum()),
+          'size %.0f KB' % (os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    R.setup()
+    R.cpu_cuda_noop()
+    # cfg3 architecture at full size (384-d, 12+4 blocks), B=2, stochastic depth off
+    transformer_fixture('transformer_cfg3_b2.npz', 2, 11, {'transformer_config.drop_path_rate': 0.0})
+    # all_patch variant, cdl1 loss, smaller stack
+    transformer_fixture('transformer_allpatch_cdl1_b3.npz', 3, 12,
+                        {'transformer_config.drop_path_rate': 0.0, 'all_patch': 'True', 'loss': 'cdl1',
+                         'transformer_config.depth': 2, 'transformer_config.decoder_depth': 1})

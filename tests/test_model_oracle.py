@@ -1,0 +1,104 @@
+"""CPU tests: the plain-PyTorch oracle model (oracle/model.py) against the golden
+fixtures that were generated from the LIVE reference classes
+(tests/golden/make_fixtures.py), and -- when the reference tree is present, i.e.
+in the dev container only -- against the live reference itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_grads, fill_state, load_fixture, model_cfg
+
+FIXTURES = ['transformer_cfg3_b2.npz', 'transformer_allpatch_cdl1_b3.npz']
+
+
+def _osteps(steps):
+    B = steps.shape[1]
+    return [('mul', s[:, 1:4]) if s[0, 0] == 0 else ('mat', s[:, 1:].reshape(B, 3, 3))
+            for s in torch.from_numpy(steps)]
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_oracle_model_reproduces_reference_fixture(name):
+    from oracle import model as OM
+    fx = load_fixture(name)
+    cfg = model_cfg(fx)
+    torch.manual_seed(0)
+    model = fill_state(OM.PointCAE_transformer(cfg), int(fx['seed'])).train()
+    pts = torch.from_numpy(fx['pts'])
+    cap = {}
+    loss, loss2 = model(pts, pts, mask=torch.from_numpy(fx['mask']), steps=_osteps(fx['steps']), capture=cap)
+    loss.backward()
+    # same machine class, same torch build -> the restatement is bit-identical
+    assert abs(loss.item() - float(fx['loss'])) <= 1e-6 * abs(float(fx['loss']))
+    np.testing.assert_array_equal(cap['center'].numpy(), fx['center'])
+    np.testing.assert_allclose(cap['x_vis'].detach().numpy(), fx['x_vis'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cap['x_rec'].detach().numpy(), fx['x_rec'], rtol=1e-4, atol=1e-5)
+    assert loss2.shape == (1,) and loss2.item() == 0
+    check_grads(model, fx, 1e-4, name)
+    for bname, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            np.testing.assert_allclose(b.numpy(), fx['buf/' + bname], rtol=1e-5, atol=1e-6)
+
+
+def test_corruption_and_mask_draws_follow_reference_rng():
+    """Product-side host draws == oracle-side draws (which were bit-identical to
+    the live reference when the fixtures were made) under the same seeds."""
+    import random
+    from oracle import model as OM
+    from point_dae_amd import corrupt_util_tensor as C
+    from point_dae_amd.point_cae_transformer import draw_mask
+
+    def seed(s):
+        random.seed(s), np.random.seed(s), torch.manual_seed(s)
+    kinds = set()
+    for s in range(40):
+        seed(s)
+        a = OM.draw_corruption(['affine_r3', 'Drop-Patch'], 4)
+        ma = OM.draw_mask(4, 64, 0.6, 'True')
+        seed(s)
+        b = C.draw_corruption(['affine_r3', 'Drop-Patch'], 4)
+        mb, ratio = draw_mask(4, 64, 0.6, 'True')
+        assert len(a) == b.shape[0] and 1 <= len(a) <= 3
+        for (kind, p), row in zip(a, b):
+            kinds.add(kind)
+            if kind == 'mul':
+                assert (row[:, 0] == 0).all() and torch.equal(row[:, 1:4], p)
+            else:
+                assert (row[:, 0] == 1).all() and torch.equal(row[:, 1:].reshape(-1, 3, 3), p)
+        assert torch.equal(ma, mb) and 0.5 <= ratio <= 0.8
+        assert (mb.sum(1) == int(ratio * 64)).all()
+    assert kinds == {'mul', 'mat'}
+    assert C.draw_corruption(['clean', 'Drop-Patch'], 3).shape == (0, 3, 10)
+    with pytest.raises(NotImplementedError):
+        C.draw_corruption(['jitter'], 3)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/models'), reason='reference tree only exists in the dev container')
+def test_oracle_model_matches_live_reference():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import ref_import as R
+    R.setup()
+    R.cpu_cuda_noop()
+    import models.PointCAE_transformer as M
+    from oracle import model as OM
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    fx = load_fixture(FIXTURES[1])
+    cfg = model_cfg(fx)
+    cfg.transformer_config.drop_path_rate = 0.1          # stochastic depth ON: same RNG stream both sides
+    from easydict import EasyDict
+    ref = fill_state(M.PointCAE_transformer(EasyDict(cfg)), 5).train()
+    mine = fill_state(OM.PointCAE_transformer(cfg), 5).train()
+    x = torch.from_numpy(shapenet_like_clouds(2, 1024, seed=9))
+    R.seed_all(77)
+    l_ref, _ = ref(x, x)
+    l_ref.backward()
+    R.seed_all(77)
+    l_my, _ = mine(x, x)
+    l_my.backward()
+    assert l_ref.item() == l_my.item()
+    gr = dict(ref.named_parameters())
+    for n, p in mine.named_parameters():
+        assert torch.equal(p.grad, gr[n].grad), n
