@@ -1,0 +1,178 @@
+"""bench.py -- pretraining throughput of the Point-DAE hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimisation step (FPS -> kNN grouping -> in-forward
+corruption -> patch embedder -> masked Transformer encoder/decoder -> Chamfer
+loss -> backward -> AdamW [-> gradient all-reduce when N > 1]) over one batch of
+synthetic ShapeNet-shaped clouds already resident in HBM.
+
+Workload (config.workload): BASELINE.json configs[2]/[3] -- the Transformer
+experiment `..._maskpatch_p0005_whole.yaml`, local B=128, N=1024, G=64, k=32 --
+because the metric is quoted "(N=1024,G=64) at 1/2/4/8 MI355X": its N=1 point
+is cfg3 and its N>1 points are cfg4 (local B=128 per GPU, weak scaling).
+`--workload cfg2` times the PointNet++ experiment instead (when built).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: `roofline` for the dominant kernel, timed live with HIP events on the
+launch stream inside the timed region, and `cpu_baseline`, the CPU oracle
+(oracle/, "port") timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG3 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--workload', default='cfg3', choices=['cfg3'])
+    p.add_argument('--batch', type=int, default=128, help='clouds per GPU')
+    p.add_argument('--npoints', type=int, default=1024)
+    p.add_argument('--num_group', type=int, default=64)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=8)
+    p.add_argument('--cpu-steps', type=int, default=3)
+    return p.parse_args()
+
+
+def cpu_baseline(config, args):
+    """The CPU oracle (plain-PyTorch model + C restatement of the native ops)
+    on a bounded sample of the same workload: `cpu_steps` optimisation steps of
+    B=`cpu_batch` clouds (about 10-30 s), all host cores."""
+    import numpy as np
+    from oracle import model as OM, ops as O
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    O.build()
+    O.set_threads(cores)
+    torch.manual_seed(0)
+    model = OM.PointCAE_transformer(config.model).train()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if (p.dim() == 1 or n.endswith('.bias') or 'token' in n) else decay).append(p)
+    opt = torch.optim.AdamW([{'params': no_decay, 'weight_decay': 0.},
+                             {'params': decay, 'weight_decay': config.optimizer.kwargs.weight_decay}],
+                            lr=config.optimizer.kwargs.lr)
+    x = torch.from_numpy(shapenet_like_clouds(args.cpu_batch, args.npoints, seed=0))
+
+    def step():
+        loss, ln = model(x, x)
+        (loss + float(config.normal_weight) * ln.sum()).backward()
+        opt.step()
+        opt.zero_grad()
+    step()                                   # warm-up (allocations, thread pools)
+    t0 = time.time()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.time() - t0
+    return {'value': args.cpu_batch * args.cpu_steps / dt, 'unit': 'clouds/s', 'cores': cores,
+            'kind': 'port',
+            'sample': '%d steps of B=%d (N=%d, G=%d, k=32) full train step on the CPU oracle '
+                      '(oracle/model.py + oracle/pdae_oracle.c), %.1f s' % (
+                          args.cpu_steps, args.cpu_batch, args.npoints, args.num_group, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU path in point_dae_amd)')
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')       # RCCL over xGMI
+    device = torch.device('cuda', torch.cuda.current_device())
+
+    from point_dae_amd import builder, nn_ops
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.misc import set_random_seed
+    from point_dae_amd.runner_pretrain import train_step
+    from point_dae_amd.synthetic import shapenet_like_clouds
+
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG3))
+    config.npoints = args.npoints
+    config.model.num_group = args.num_group
+    set_random_seed(0 + rank)
+    model = FlatDataParallel(builder.model_builder(config.model).to(device))
+    optimizer, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+
+    pool = 4
+    clouds = torch.from_numpy(shapenet_like_clouds(args.batch * pool, args.npoints, seed=100 + rank)).to(device)
+    batches = list(clouds.split(args.batch))
+
+    for i in range(args.warmup):
+        train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    probe = nn_ops.Probe()
+    nn_ops.set_probe(probe)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nn_ops.set_probe(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        clouds_per_s = args.batch * world * args.steps / elapsed
+        kern = probe.summary()
+        roof = None
+        if kern:
+            ach = kern['flops'] / (kern['avg_ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None, 'kernel': kern['name'],
+                    'avg_us': kern['avg_ms'] * 1e3, 'launches': kern['launches'],
+                    'flops_per_launch': kern['flops']}
+        line = {
+            'metric': 'pretrain point-clouds/sec (N=1024,G=64)', 'value': clouds_per_s, 'unit': 'clouds/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
+                                   'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
+                       'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
+                       'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(config, args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

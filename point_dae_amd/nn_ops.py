@@ -9,6 +9,42 @@ import torch
 import torch.nn.functional as F
 
 
+class Probe:
+    """HIP-event timer for ONE named kernel launch site, used by bench.py's
+    roofline: events are recorded on the stream the kernel is launched on,
+    around every launch inside the timed region, and read after it."""
+
+    def __init__(self):
+        self.name, self.flops, self.events = None, 0.0, []
+
+    def record(self, name, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.name, self.flops = name, flops
+        self.events.append((s, e))
+        return out
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = [s.elapsed_time(e) for s, e in self.events]
+        return {'name': self.name, 'flops': self.flops, 'avg_ms': sum(ms) / len(ms), 'launches': len(ms)}
+
+
+_probe = None
+
+
+def set_probe(p):
+    global _probe
+    _probe = p
+
+
+def _probed(name, flops, fn):
+    return _probe.record(name, flops, fn) if _probe is not None else fn()
+
+
 def linear(x, lin, act=None):
     y = F.linear(x, lin.weight, lin.bias)
     if act == 'gelu':
@@ -82,5 +118,8 @@ def patch_embed(points, first_conv, second_conv, training):
     cg = g.shape[1]
     h = F.linear(f, w[:, cg:]).reshape(BG, n, -1) + F.linear(g, w[:, :cg], second_conv[0].bias).unsqueeze(1)
     h = F.relu(second_conv[1](h.reshape(BG * n, -1)))
-    h = conv1x1(h, second_conv[3])
+    # the largest GEMM of the step (M = BG*n rows, K = 512, N = C): bench.py's roofline kernel
+    cout = second_conv[3].weight.shape[0]
+    h = _probed('patch_embed.second_conv.3 fwd GEMM %dx%dx%d' % (h.shape[0], h.shape[1], cout),
+                2.0 * h.shape[0] * h.shape[1] * cout, lambda: conv1x1(h, second_conv[3]))
     return h.reshape(BG, n, -1).max(dim=1)[0]

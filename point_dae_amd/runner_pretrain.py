@@ -1,0 +1,98 @@
+"""Pretraining loop (tools/runner_pretrain.py:50-288 of the reference).
+
+Same control flow -- model(points, gt) -> (loss_xyz, loss_normal), loss mixing
+by `loss_type` (:161-186), backward, optimiser step every `step_per_update`,
+epoch-granular scheduler -- without its per-step host syncs: the reference
+calls .item() twice and cuda.synchronize() every step (:201-217); here losses
+accumulate on the device and are read back every `log_every` steps.
+"""
+import time
+
+import torch
+
+from . import builder, dist_utils
+from . import datasets  # noqa: F401  (registers the synthetic ShapeNet set)
+from .data_parallel import FlatDataParallel
+from .registry import DATASETS
+
+
+def mix_loss(config, loss_xyz, loss_normal, gradual_weight):
+    lt = config.loss_type
+    w = float(config.normal_weight)
+    if lt == 'xyz':
+        return loss_xyz
+    if lt == 'normal':
+        return w * loss_normal
+    if lt == 'xyznormal':
+        return loss_xyz + w * loss_normal
+    if lt in ('xyznormal_gradual', 'xyznormal_warm'):
+        return loss_xyz + w * loss_normal * gradual_weight
+    raise NotImplementedError(lt)
+
+
+def gradual_weight_of(config, epoch):
+    if config.loss_type == 'xyznormal_gradual':
+        return float(epoch) / float(config.max_epoch)
+    if config.loss_type == 'xyznormal_warm':
+        r = float(epoch) / float(config.max_epoch)
+        return r * 3 if r < 1.0 / 3.0 else 1.0
+    return 0
+
+
+def train_step(model, optimizer, config, points, gt, gradual_weight=0.):
+    """One optimisation step: the unit bench.py times."""
+    loss_xyz, loss_normal = model(points, gt)
+    loss = mix_loss(config, loss_xyz, loss_normal.sum(), gradual_weight)
+    loss.backward()
+    if isinstance(model, FlatDataParallel):
+        model.finish()
+    optimizer.step()
+    model.zero_grad()
+    return loss_xyz.detach(), loss_normal.detach()
+
+
+def run_net(args, config, train_writer=None, val_writer=None, log=print, log_every=50):
+    rank, world = dist_utils.get_dist_info()
+    device = torch.device('cuda', torch.cuda.current_device())
+    ds_cfg = dict(config.dataset.train.others)
+    ds_cfg.update(NAME=config.dataset.train._base_.NAME, seed=args.seed + rank, device=device,
+                  steps_per_epoch=getattr(args, 'steps_per_epoch', 50))
+    ds_cfg.setdefault('bs', config.total_bs // world)
+    train_loader = DATASETS.build(ds_cfg)
+
+    base_model = builder.model_builder(config.model).to(device)
+    start_epoch = 0
+    if args.resume:
+        start_epoch, _ = builder.resume_model(base_model, args)
+    elif args.start_ckpts is not None:
+        builder.load_model(base_model, args.start_ckpts)
+    if args.sync_bn and world > 1:
+        base_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(base_model)
+    model = FlatDataParallel(base_model)
+    optimizer, scheduler = builder.build_opti_sche(model, config)
+    model.zero_grad()
+
+    for epoch in range(start_epoch, config.max_epoch + 1):
+        model.train()
+        gw = gradual_weight_of(config, epoch)
+        acc = torch.zeros(2, device=device)
+        t0 = time.time()
+        n = 0
+        for idx, (_, _, corrupted, clean) in enumerate(train_loader):
+            lx, ln = train_step(model, optimizer, config, corrupted, clean, gw)
+            acc += torch.stack([lx.reshape(()), ln.sum().reshape(())])
+            n += 1
+            if (idx + 1) % log_every == 0 or idx + 1 == len(train_loader):
+                vals = acc.clone()
+                if world > 1:
+                    vals = dist_utils.reduce_tensor(vals, args)
+                vals = (vals / n * 1000).tolist()          # one host sync per log line
+                dt = time.time() - t0
+                if rank == 0:
+                    log('[Epoch %d/%d][Batch %d/%d] %.1f clouds/s Lossxyz = %.4f Lossnormal = %.4f lr = %.6f' % (
+                        epoch, config.max_epoch, idx + 1, len(train_loader),
+                        n * clean.shape[0] * world / dt, vals[0], vals[1], optimizer.param_groups[0]['lr']))
+        if scheduler is not None:
+            scheduler.step(epoch)
+        builder.save_checkpoint(model, optimizer, epoch, None, None, 'ckpt-last', args)
+    return model

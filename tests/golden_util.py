@@ -36,21 +36,23 @@ def grad_sample(g, n=256):
     return flat[idx].numpy()
 
 
-def check_grads(model, fx, rtol, what):
+def check_grads(model, fx, rtol, what, atol=2e-5):
     """Every parameter gradient against the reference's: L2 norm, plus the full
-    tensor (small parameters) or 256 evenly spaced entries (large ones)."""
+    tensor (small parameters) or 256 evenly spaced entries (large ones).  `atol`
+    covers gradients that are analytically zero (a conv bias feeding a training
+    mode BatchNorm) and therefore pure rounding noise on both sides."""
     worst = 0.0
     for name, p in model.named_parameters():
         key = 'grad/' + name
         ref_norm = float(fx[key + '/norm'])
         got_norm = p.grad.double().norm().item()
-        assert abs(got_norm - ref_norm) <= rtol * max(ref_norm, 1e-12), (what, name, got_norm, ref_norm)
+        assert abs(got_norm - ref_norm) <= rtol * ref_norm + atol, (what, name, got_norm, ref_norm)
         if key + '/full' in fx:
             ref, got = fx[key + '/full'], p.grad.detach().cpu().numpy()
         else:
             ref, got = fx[key + '/sample'], grad_sample(p.grad)
-        scale = max(np.abs(ref).max(), 1e-12)
-        err = np.abs(got - ref).max() / scale
-        worst = max(worst, err)
-        assert err <= rtol, (what, name, err)
+        scale = np.abs(ref).max()
+        diff = np.abs(got - ref).max()
+        worst = max(worst, diff / max(scale, atol))
+        assert diff <= rtol * scale + atol, (what, name, diff, scale)
     return worst

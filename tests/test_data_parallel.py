@@ -1,0 +1,98 @@
+"""CPU tests of the multi-rank path: world_size-2 gloo processes drive
+FlatDataParallel (flat parameter / gradient buffers, bucketed async all-reduce)
+and must reproduce single-process training on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(16, 64), nn.LayerNorm(64), nn.GELU(), nn.Linear(64, 64), nn.GELU(),
+                         nn.Linear(64, 8))
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(5, 8, 16, generator=g), torch.randn(5, 8, 8, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from point_dae_amd.data_parallel import FlatDataParallel
+    net = _net()
+    if rank == 1:                      # rank 1 starts from different weights: broadcast must fix it
+        for p in net.parameters():
+            p.data.add_(1.0)
+    model = FlatDataParallel(net, bucket_mb=0.004)      # several buckets
+    assert len(model.buckets) > 2
+    opt = torch.optim.AdamW(model.param_groups(0.05), lr=1e-2)
+    x, y = _data()
+    per = x.shape[1] // world
+    for step in range(x.shape[0]):
+        xs, ys = x[step, rank * per:(rank + 1) * per], y[step, rank * per:(rank + 1) * per]
+        loss = ((model(xs) - ys) ** 2).mean()
+        loss.backward()
+        model.finish()
+        opt.step()
+        model.zero_grad()
+    if rank == 0:
+        torch.save(model.flat_param.clone(), out)
+    flat = [torch.empty_like(model.flat_param) for _ in range(world)]
+    dist.all_gather(flat, model.flat_param)
+    assert torch.equal(flat[0], flat[1])                 # replicas stay identical
+    dist.destroy_process_group()
+
+
+def test_flat_data_parallel_world2_matches_single_process(tmp_path):
+    out = str(tmp_path / 'flat.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    from point_dae_amd.data_parallel import FlatDataParallel
+    net = _net()
+    model = FlatDataParallel(net)
+    opt = torch.optim.AdamW(model.param_groups(0.05), lr=1e-2)
+    x, y = _data()
+    for step in range(x.shape[0]):
+        # mean of per-rank means == mean over the whole batch (equal shards)
+        loss = ((model(x[step]) - y[step]) ** 2).mean()
+        loss.backward()
+        model.finish()
+        opt.step()
+        model.zero_grad()
+    got = torch.load(out)
+    assert torch.allclose(got, model.flat_param, rtol=1e-5, atol=1e-6)
+
+
+def test_flat_views_and_groups():
+    from point_dae_amd.data_parallel import FlatDataParallel
+    net = _net()
+    ref = [p.detach().clone() for p in net.parameters()]
+    model = FlatDataParallel(net)
+    for p, r in zip(net.parameters(), ref):
+        assert torch.equal(p, r)                                  # values preserved
+        assert p.data_ptr() >= model.flat_param.data_ptr()
+    groups = model.param_groups(0.05)
+    assert groups[0]['weight_decay'] == 0. and all(p.dim() == 1 for p in groups[0]['params'])
+    assert sum(p.numel() for p in groups[0]['params']) == model.no_decay_numel
+    loss = net(torch.randn(4, 16)).sum()
+    loss.backward()
+    assert model.flat_grad.abs().sum() > 0
+    for p in net.parameters():
+        assert p.grad.data_ptr() >= model.flat_grad.data_ptr()     # grads are views of the flat buffer
+    model.zero_grad()
+    assert model.flat_grad.abs().sum() == 0
