@@ -60,7 +60,9 @@ def cpu_baseline(config, args):
     import numpy as np
     from oracle import model as OM, ops as O
     from point_dae_amd.synthetic import shapenet_like_clouds
-    cores = os.cpu_count() or 1
+    # all host cores up to 16: beyond that torch's intra-op pools only contend on
+    # these small GEMMs (256 threads on the GPU box ran 20x SLOWER than 16)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     O.build()
     O.set_threads(cores)
@@ -79,11 +81,16 @@ def cpu_baseline(config, args):
         (loss + float(config.normal_weight) * ln.sum()).backward()
         opt.step()
         opt.zero_grad()
-    step()                                   # warm-up (allocations, thread pools)
     t0 = time.time()
-    for _ in range(args.cpu_steps):
-        step()
+    step()                                   # warm-up (allocations, thread pools)
+    warm = time.time() - t0
+    t0 = time.time()
+    done = 0
+    while done < args.cpu_steps and (done == 0 or time.time() - t0 + warm < 30.0):
+        step()                               # bounded: stop once ~30 s of CPU work is spent
+        done += 1
     dt = time.time() - t0
+    args.cpu_steps = done
     return {'value': args.cpu_batch * args.cpu_steps / dt, 'unit': 'clouds/s', 'cores': cores,
             'kind': 'port',
             'sample': '%d steps of B=%d (N=%d, G=%d, k=32) full train step on the CPU oracle '
