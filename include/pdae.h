@@ -168,6 +168,99 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
                             const float* match, float* grad1, float* grad2,
                             pdae_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Dense layers.  The reference runs nn.Linear / 1x1 nn.Conv1d through
+ * cuBLAS / cuDNN in fp32 (patch embedder models/PointCAE_transformer.py:24-51,
+ * qkv / proj :113-137, fc1 / fc2 :94-110, pos_embed :329-333, increase_dim
+ * :653-658).  Here: fp32-input MFMA (exact fp32 accumulation), row-major
+ * activations (rows, channels), weights in torch's (out, in) layout.
+ *   forward:          Y[M,N]  = act(X[M,K] . W[N,K]^T + bias[N]); act 0 none,
+ *                     1 ReLU, 2 GELU(erf); bias nullable; K % 4 == 0.
+ *   backward_data:    dX[M,K] = dY[M,N] . W[N,K], given Wt = W^T as [K,N].
+ *   backward_weight:  dW[N,K] = dY^T . X, dbias[N] = column sums of dY
+ *                     (nullable); both are overwritten (zero-filled, then
+ *                     accumulated with fp32 atomics over M-splits).
+ */
+int pdae_linear_forward(int M, int N, int K, const float* X, const float* W,
+                        const float* bias /*nullable*/, int act, float* Y,
+                        pdae_stream_t stream);
+int pdae_linear_backward_data(int M, int N, int K, const float* dY,
+                              const float* Wt, float* dX, pdae_stream_t stream);
+int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
+                                const float* X, float* dW,
+                                float* dbias /*nullable*/, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused layers of the patch embedder, Encoder.forward
+ * (models/PointCAE_transformer.py:37-51).  Rows are points, 32 consecutive rows
+ * form one group (patch); M % 32 == 0.  The reference runs each of these as a
+ * cuDNN 1x1 conv followed by separate BatchNorm / ReLU / max / concat passes
+ * over (B*G*32, C) tensors.
+ *
+ *   embed_conv_store_groupmax   (first_conv[3] + the max of :47)
+ *       Y[M,N] = X[M,K].W[N,K]^T + bias;  gmax[M/32,N] = max over each group's
+ *       32 rows of Y, garg[M/32,N] (u8) = first row inside the group attaining it.
+ *   embed_conv_groupbias_stats  (second_conv[0] on concat([global, local]), :48-49,
+ *       with the weight split into its global / local halves)
+ *       Y[M,N] = X[M,K].W[N,K]^T + gbias[M/32,N]   (gbias = global half + bias,
+ *       one row per group);  stats[8][2][N] receives 8 partial (sum, sum of
+ *       squares) of Y's columns -- BatchNorm batch statistics (:32) without a
+ *       pass over Y.  stats is zero-filled by the call.
+ *   embed_bnrelu_conv_groupmax  (second_conv[1..3] + the max of :50)
+ *       gmax[M/32,N] = max over groups of (relu(X*scale + shift).W^T + bias),
+ *       garg = argmax row; the (M,N) product itself is never written.
+ *   bnrelu_linear_backward_weight
+ *       dW[N,K] = dY[M,N]^T . relu(X[M,K]*scale + shift)  (activation recomputed
+ *       while it is staged); dW is overwritten.
+ */
+int pdae_embed_conv_store_groupmax(int M, int N, int K, const float* X,
+                                   const float* W, const float* bias, float* Y,
+                                   float* gmax, unsigned char* garg,
+                                   pdae_stream_t stream);
+int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float* X,
+                                    const float* W, const float* gbias,
+                                    float* Y, float* stats,
+                                    pdae_stream_t stream);
+int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,
+                                    const float* scale, const float* shift,
+                                    const float* W, const float* bias,
+                                    float* gmax, unsigned char* garg,
+                                    pdae_stream_t stream);
+int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
+                                       const float* X, const float* scale,
+                                       const float* shift, float* dW,
+                                       pdae_stream_t stream);
+/*   embed_bnrelu_conv_store_groupmax  (first_conv[1..3] + the max of :47)
+ *       Y[M,N] = relu(X*scale + shift).W^T + bias, plus its group max / argmax. */
+int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,
+                                          const float* scale, const float* shift,
+                                          const float* W, const float* bias,
+                                          float* Y, float* gmax,
+                                          unsigned char* garg,
+                                          pdae_stream_t stream);
+
+/* Memory-bound backward passes of the embedder (autograd of torch.max over the
+ * 32 points of a group, nn.ReLU and training-mode nn.BatchNorm1d, :26,:32,:47,:50),
+ * each a single fused sweep.  G groups of 32 rows, C channels (C % 4 == 0).
+ *   group_max_scatter: out[g*32+r][c] = (r == arg[g][c]) ? grad[g][c] : 0
+ *   group_scatter_add: dst[g*32+arg[g][c]][c] += grad[g][c]
+ *   bnrelu_backward:   t = dA * (X*scale+shift > 0); S[0][c] = sum t (= d beta),
+ *                      S[1][c] = sum t*xhat (= d gamma), xhat = (X-mean)*invstd;
+ *                      dA <- gamma*invstd*(t - S0/R - xhat*S1/R) in place;
+ *                      gsum[g][c] (nullable) = sum of the new dA over the group.
+ */
+int pdae_group_max_scatter(int G, int C, const float* grad,
+                           const unsigned char* arg, float* out,
+                           pdae_stream_t stream);
+int pdae_group_scatter_add(int G, int C, const float* grad,
+                           const unsigned char* arg, float* dst,
+                           pdae_stream_t stream);
+int pdae_bnrelu_backward(int G, int C, float* dA, const float* X,
+                         const float* scale, const float* shift,
+                         const float* mean, const float* invstd,
+                         const float* gamma, float* S, float* gsum /*nullable*/,
+                         pdae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

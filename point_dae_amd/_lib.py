@@ -28,6 +28,17 @@ _SIGNATURES = {
     "pdae_patch_affine": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "pdae_linear_backward_data": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_bnrelu_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_group_max_scatter": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdae_group_scatter_add": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,186 @@
+// embed.hip -- the memory-bound passes of the patch embedder's backward
+// (Encoder, models/PointCAE_transformer.py:20-51) as single fused sweeps.
+//
+// PyTorch runs the backward of max-pool / ReLU / BatchNorm (training mode) /
+// concat as ~10 separate kernels over (B*G*32, C) tensors; here:
+//   group_max_scatter      max-pool backward: grad (G,C) -> dense (G*32,C)
+//   group_scatter_add      adds grad (G,C) at the arg-max rows of a (G*32,C) grad
+//   bnrelu_backward_reduce S1[c] = sum t, S2[c] = sum t*xhat with
+//                          t = dA * (relu mask), xhat = (x - mean) * invstd
+//   bnrelu_backward_apply  dX = gamma*invstd * (t - S1/R - xhat*S2/R), in place
+//                          over dA, plus the per-group row sums of dX (needed by
+//                          the global half of the split concat GEMM)
+// All are float4-wide, one pass over each operand.
+#include "common.h"
+
+namespace pdae {
+
+// out[g*32 + r][c] = (r == arg[g][c]) ? grad[g][c] : 0
+__global__ __launch_bounds__(256) void group_max_scatter_kernel(int G, int C,
+                                                                const float* __restrict__ grad,
+                                                                const unsigned char* __restrict__ arg,
+                                                                float* __restrict__ out) {
+  const int c4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int rsub = threadIdx.x >> 6;  // 4 row phases
+  const int g = blockIdx.y;
+  if (c4 >= C) return;
+  const float4 v = *reinterpret_cast<const float4*>(grad + (size_t)g * C + c4);
+  const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (size_t)g * C + c4);
+  float* base = out + (size_t)g * 32 * C + c4;
+#pragma unroll
+  for (int r = rsub; r < 32; r += 4) {
+    float4 o;
+    o.x = a.x == r ? v.x : 0.f;
+    o.y = a.y == r ? v.y : 0.f;
+    o.z = a.z == r ? v.z : 0.f;
+    o.w = a.w == r ? v.w : 0.f;
+    *reinterpret_cast<float4*>(base + (size_t)r * C) = o;
+  }
+}
+
+// dst[g*32 + arg[g][c]][c] += grad[g][c]   (one writer per (g,c): no atomics)
+__global__ __launch_bounds__(256) void group_scatter_add_kernel(int G, int C,
+                                                                const float* __restrict__ grad,
+                                                                const unsigned char* __restrict__ arg,
+                                                                float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)G * C) return;
+  const int g = (int)(i / C), c = (int)(i - (long long)g * C);
+  dst[((size_t)g * 32 + arg[i]) * C + c] += grad[i];
+}
+
+// column sums over a slab of rows; thread owns 4 columns, 8 row lanes per block
+__global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
+    int R, int C, const float* __restrict__ dA, const float* __restrict__ X,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ S,
+    int rows_per_block) {
+  __shared__ float4 red[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c4 = (blockIdx.x * 32 + cl) * 4;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c4 < C) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const float4 d = *reinterpret_cast<const float4*>(dA + (size_t)r * C + c4);
+      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * C + c4);
+      const float tx = (x.x * sc.x + sh.x > 0.f) ? d.x : 0.f;
+      const float ty = (x.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+      const float tz = (x.z * sc.z + sh.z > 0.f) ? d.z : 0.f;
+      const float tw = (x.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+      s1.x += tx, s1.y += ty, s1.z += tz, s1.w += tw;
+      s2.x += tx * ((x.x - mu.x) * is.x);
+      s2.y += ty * ((x.y - mu.y) * is.y);
+      s2.z += tz * ((x.z - mu.z) * is.z);
+      s2.w += tw * ((x.w - mu.w) * is.w);
+    }
+  }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl < 2 && c4 < C) {
+    float4 t = red[rl][0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 u = red[rl][k][cl];
+      t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+    }
+    float* dst = S + (size_t)rl * C + c4;
+    atomicAdd(dst + 0, t.x);
+    atomicAdd(dst + 1, t.y);
+    atomicAdd(dst + 2, t.z);
+    atomicAdd(dst + 3, t.w);
+  }
+}
+
+// in place: dA <- gamma*invstd*(t - S1/R - xhat*S2/R); gsum[g][c] = sum over the
+// group's 32 rows of the result (nullable)
+__global__ __launch_bounds__(256) void bnrelu_backward_apply_kernel(
+    int G, int C, float* __restrict__ dA, const float* __restrict__ X,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ S, float inv_rows,
+    float* __restrict__ gsum) {
+  const int c4 = (blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
+  const int g = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (c4 >= C || g >= G) return;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+  const float4 s1 = *reinterpret_cast<const float4*>(S + c4);
+  const float4 s2 = *reinterpret_cast<const float4*>(S + C + c4);
+  const float kx = ga.x * is.x, ky = ga.y * is.y, kz = ga.z * is.z, kw = ga.w * is.w;
+  const float m1x = s1.x * inv_rows, m1y = s1.y * inv_rows, m1z = s1.z * inv_rows, m1w = s1.w * inv_rows;
+  const float m2x = s2.x * inv_rows, m2y = s2.y * inv_rows, m2z = s2.z * inv_rows, m2w = s2.w * inv_rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < 32; ++r) {
+    const size_t o = ((size_t)g * 32 + r) * C + c4;
+    const float4 d = *reinterpret_cast<const float4*>(dA + o);
+    const float4 x = *reinterpret_cast<const float4*>(X + o);
+    float4 y;
+    y.x = kx * (((x.x * sc.x + sh.x > 0.f) ? d.x : 0.f) - m1x - ((x.x - mu.x) * is.x) * m2x);
+    y.y = ky * (((x.y * sc.y + sh.y > 0.f) ? d.y : 0.f) - m1y - ((x.y - mu.y) * is.y) * m2y);
+    y.z = kz * (((x.z * sc.z + sh.z > 0.f) ? d.z : 0.f) - m1z - ((x.z - mu.z) * is.z) * m2z);
+    y.w = kw * (((x.w * sc.w + sh.w > 0.f) ? d.w : 0.f) - m1w - ((x.w - mu.w) * is.w) * m2w);
+    *reinterpret_cast<float4*>(dA + o) = y;
+    acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
+  }
+  if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)g * C + c4) = acc;
+}
+
+}  // namespace pdae
+
+using namespace pdae;
+
+extern "C" int pdae_group_max_scatter(int G, int C, const float* grad, const unsigned char* arg,
+                                      float* out, pdae_stream_t stream) {
+  if (G < 0 || C <= 0 || C % 4 != 0) return bad_arg("group_max_scatter: C must be a positive multiple of 4");
+  if (G == 0) return PDAE_OK;
+  if (!grad || !arg || !out) return bad_arg("group_max_scatter: null pointer");
+  if (G > 65535 * 32) return unsupported("group_max_scatter: too many groups");
+  hipLaunchKernelGGL(group_max_scatter_kernel, dim3((C / 4 + 63) / 64, G), dim3(256), 0,
+                     as_stream(stream), G, C, grad, arg, out);
+  return check_launch("group_max_scatter");
+}
+
+extern "C" int pdae_group_scatter_add(int G, int C, const float* grad, const unsigned char* arg,
+                                      float* dst, pdae_stream_t stream) {
+  if (G < 0 || C <= 0) return bad_arg("group_scatter_add: bad size");
+  if (G == 0) return PDAE_OK;
+  if (!grad || !arg || !dst) return bad_arg("group_scatter_add: null pointer");
+  const long long n = (long long)G * C;
+  hipLaunchKernelGGL(group_scatter_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), G, C, grad, arg, dst);
+  return check_launch("group_scatter_add");
+}
+
+extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd,
+                                    const float* gamma, float* S, float* gsum,
+                                    pdae_stream_t stream) {
+  if (G < 0 || C <= 0 || C % 4 != 0) return bad_arg("bnrelu_backward: C must be a positive multiple of 4");
+  if (!S) return bad_arg("bnrelu_backward: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)C, s);
+  if (G == 0) return check_launch("bnrelu_backward");
+  if (!dA || !X || !scale || !shift || !mean || !invstd || !gamma)
+    return bad_arg("bnrelu_backward: null pointer");
+  const int R = G * 32;
+  int rows = 512;
+  int by = (R + rows - 1) / rows;
+  if (by > 16384) {
+    rows = (R + 16383) / 16384;
+    by = (R + rows - 1) / rows;
+  }
+  hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, R, C,
+                     dA, X, scale, shift, mean, invstd, S, rows);
+  hipLaunchKernelGGL(bnrelu_backward_apply_kernel, dim3((C / 4 + 31) / 32, (G + 7) / 8), dim3(256), 0, s,
+                     G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)R, gsum);
+  return check_launch("bnrelu_backward");
+}

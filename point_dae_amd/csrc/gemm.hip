@@ -1,0 +1,598 @@
+// gemm.hip -- fp32 GEMMs on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32),
+// with the producer / epilogue fusions the patch embedder needs.
+//
+// The reference runs its dense layers (nn.Linear / 1x1 nn.Conv1d: patch
+// embedder models/PointCAE_transformer.py:24-51, attention and MLP :113-137,
+// :94-110, heads :329-333, :653-658) through cuBLAS/cuDNN in fp32, with
+// BatchNorm / ReLU / max-pool / concat as separate full passes over
+// (B*G*32, 512) tensors (537 MB each at B=128).  The fp32 MFMA of CDNA4 is exact
+// fp32 (a k-ordered fmaf chain) at the fp32 vector peak (157 TFLOP/s), so the
+// same arithmetic class is kept -- no TF32/bf16.
+//
+// Kernel "NT":  C[M,N] = epi( pro(A)[M,K] . B[N,K]^T )          (both K-contiguous)
+//   - block tile BM x BN (256x256 with 16 waves, or 128x128 with 4), BK = 32;
+//     every wave owns 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulators/lane).
+//     Measured on MI355X: the 128x128 tile is bound by the global->LDS load path
+//     (8 B/clk/CU of L2 traffic; 97 TFLOP/s), 256x256 halves the bytes per MAC
+//     and reaches ~126 TFLOP/s on the embedder's shapes.
+//   - The k index inside an 8-deep slab is permuted so that one ds_read_b128 per
+//     operand row feeds four MFMAs: lane (r = l&31, h = l>>5) supplies
+//     k = 8s + 4h + t to MFMA t (same permutation on A and B).  LDS rows are
+//     padded to 36 floats: the four 16-lane groups of a ds_read_b128 then hit 64
+//     distinct banks.  Fragment reads run one slab ahead of the MFMAs.
+//   - global -> registers -> LDS staging, two LDS buffers, ONE barrier per
+//     k-tile: the loads of tile t+1 are issued before the MFMAs of tile t and
+//     written to the other buffer after them.
+//   - blockIdx -> tile mapping is XCD-aware: blocks b, b+8, ... share an L2, so
+//     each XCD walks a contiguous range of tiles, n fastest.
+//   producers (applied to A while it is staged):
+//     PRO_BNRELU   a := max(0, a * scale[k] + shift[k])   -- BatchNorm + ReLU of
+//                  the previous layer never materialised
+//   epilogues:
+//     EPI_BIAS[_RELU|_GELU]  C = act(acc + bias[n])
+//     EPI_GROUPBIAS_STATS    C = acc + gbias[m/32][n]; per-column sum / sum of
+//                            squares of C accumulated into stats (BatchNorm
+//                            batch statistics without another pass over C)
+//     EPI_GROUPMAX           out[m/32][n] = max over the 32 rows of a group of
+//                            (acc + bias[n]), arg[m/32][n] = first row attaining
+//                            it; C itself is never written (max-pool fused)
+//     EPI_STORE_GROUPMAX     both C = acc + bias and the group max / argmax
+// Kernel "TN":  C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; reduction over
+//     the slow index M, split over blockIdx.z, fp32 atomics into C).
+#include "common.h"
+
+namespace pdae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GBK = 32, GLD = GBK + 4;
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1 };
+enum {
+  EPI_BIAS = 0,
+  EPI_BIAS_RELU = 1,
+  EPI_BIAS_GELU = 2,
+  EPI_GROUPBIAS_STATS = 3,
+  EPI_GROUPMAX = 4,
+  EPI_STORE_GROUPMAX = 5
+};
+
+struct NtArgs {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  float* C;
+  int ldc;
+  const float* bias;       // [N] or null
+  const float* pro_scale;  // [K]  PRO_BNRELU
+  const float* pro_shift;  // [K]
+  const float* gbias;      // [M/32][N]  EPI_GROUPBIAS_STATS
+  float* stats;            // [8][2][N]  per-XCD-slot partial sum / sumsq
+  float* gmax;             // [M/32][N]  EPI_*GROUPMAX
+  unsigned char* garg;     // [M/32][N]
+  int tiles_n, tiles;
+};
+
+// XCD-aware tile id: grid is 8 * chunk blocks; returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_tile(int tiles) {
+  const int chunk = (tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t = xcd * chunk + slot;
+  return (slot < chunk && t < tiles) ? t : -1;
+}
+
+__device__ __forceinline__ float act_relu(float v) { return v > 0.f ? v : 0.f; }
+__device__ __forceinline__ float act_gelu(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int PRO, int EPI>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(const NtArgs p) {
+  constexpr int WN = BN / 64;
+  constexpr int NT = (BM / 64) * (BN / 64) * 64;
+  constexpr int LA = (BM * 8 + NT - 1) / NT, LB = (BN * 8 + NT - 1) / NT;  // float4 per thread
+  extern __shared__ float lds[];    // [2][(BM + BN) * GLD]
+  const int tile = xcd_tile(p.tiles);
+  if (tile < 0) return;
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int scol = (tid & 7) * 4;
+  const int M = p.M, N = p.N, K = p.K;
+
+  // staging slot i of this thread is tile row (tid + i*NT) / 8; rows past the
+  // matrix edge are clamped (their results are never stored), slots past the
+  // tile (only when NT does not divide the tile) are skipped
+  const float* arow[LA];
+  const float* brow[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i)
+    arow[i] = p.A + (size_t)min(m0 + ((tid + i * NT) >> 3), M - 1) * p.lda + scol;
+#pragma unroll
+  for (int i = 0; i < LB; ++i)
+    brow[i] = p.B + (size_t)min(n0 + ((tid + i * NT) >> 3), N - 1) * p.ldb + scol;
+  auto a_ok = [&](int i) { return (BM * 8) % NT == 0 || ((tid + i * NT) >> 3) < BM; };
+  auto b_ok = [&](int i) { return (BN * 8) % NT == 0 || ((tid + i * NT) >> 3) < BN; };
+
+  float4 ra[LA], rb[LB];
+  auto gload = [&](int kt) {
+    const int k = kt * GBK;
+    if (k + GBK <= K) {
+#pragma unroll
+      for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(arow[i] + k);
+#pragma unroll
+      for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(brow[i] + k);
+    } else {  // partial last k-tile (K % 4 == 0): zero-fill
+      const bool in = k + scol < K;
+#pragma unroll
+      for (int i = 0; i < LA; ++i)
+        ra[i] = in ? *reinterpret_cast<const float4*>(arow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < LB; ++i)
+        rb[i] = in ? *reinterpret_cast<const float4*>(brow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PRO == PRO_BNRELU) {
+      const int kk = k + scol;
+      if (kk < K) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.pro_scale + kk);
+        const float4 sh = *reinterpret_cast<const float4*>(p.pro_shift + kk);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          ra[i].x = act_relu(ra[i].x * sc.x + sh.x);
+          ra[i].y = act_relu(ra[i].y * sc.y + sh.y);
+          ra[i].z = act_relu(ra[i].z * sc.z + sh.z);
+          ra[i].w = act_relu(ra[i].w * sc.w + sh.w);
+        }
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* As = lds + buf * (BM + BN) * GLD;
+    float* Bs = As + BM * GLD;
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      if (a_ok(i)) *reinterpret_cast<float4*>(As + ((tid + i * NT) >> 3) * GLD + scol) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      if (b_ok(i)) *reinterpret_cast<float4*>(Bs + ((tid + i * NT) >> 3) * GLD + scol) = rb[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = (K + GBK - 1) / GBK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) gload(kt + 1);
+    const float* As = lds + buf * (BM + BN) * GLD + (wm * 64 + r) * GLD + 4 * h;
+    const float* Bs = lds + buf * (BM + BN) * GLD + BM * GLD + (wn * 64 + r) * GLD + 4 * h;
+    // fragment reads run one 8-deep slab ahead of the MFMAs that consume them
+    float4 a[2][2], b[2][2];
+    a[0][0] = *reinterpret_cast<const float4*>(As);
+    a[0][1] = *reinterpret_cast<const float4*>(As + 32 * GLD);
+    b[0][0] = *reinterpret_cast<const float4*>(Bs);
+    b[0][1] = *reinterpret_cast<const float4*>(Bs + 32 * GLD);
+#pragma unroll
+    for (int s = 0; s < GBK / 8; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < GBK / 8) {
+        a[nxt][0] = *reinterpret_cast<const float4*>(As + (s + 1) * 8);
+        a[nxt][1] = *reinterpret_cast<const float4*>(As + 32 * GLD + (s + 1) * 8);
+        b[nxt][0] = *reinterpret_cast<const float4*>(Bs + (s + 1) * 8);
+        b[nxt][1] = *reinterpret_cast<const float4*>(Bs + 32 * GLD + (s + 1) * 8);
+      }
+      // keep the compiler from sinking those reads back to their first use
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].x, b[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].y, b[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].z, b[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].w, b[cur][j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
+  // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + r;
+    const bool colok = col < N;
+    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = m0 + wm * 64 + i * 32;  // one 32-row group per MFMA tile
+      float add = bv;
+      if (EPI == EPI_GROUPBIAS_STATS)
+        add = (colok && rbase < M) ? p.gbias[(size_t)(rbase >> 5) * N + col] : 0.f;
+      float vmax = -__builtin_huge_valf();
+      int amax = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int row = rbase + lr;
+        float v = acc[i][j][e] + add;
+        if (EPI == EPI_BIAS_RELU) v = act_relu(v);
+        if (EPI == EPI_BIAS_GELU) v = act_gelu(v);
+        if (EPI == EPI_GROUPBIAS_STATS && row < M) {
+          csum[j] += v;
+          csq[j] += v * v;
+        }
+        if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+          if (v > vmax) {  // e ascending => lr ascending within this half
+            vmax = v;
+            amax = lr;
+          }
+        }
+        if (EPI != EPI_GROUPMAX && colok && row < M) p.C[(size_t)row * p.ldc + col] = v;
+      }
+      if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+        // the other 16 rows of the group live in lane ^ 32
+        const float ov = __shfl_xor(vmax, 32, kWave);
+        const int oa = __shfl_xor(amax, 32, kWave);
+        const bool take = (ov > vmax) || (ov == vmax && oa < amax);
+        if (take) {
+          vmax = ov;
+          amax = oa;
+        }
+        if (h == 0 && colok && rbase < M) {
+          p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
+          p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
+        }
+      }
+    }
+  }
+  if (EPI == EPI_GROUPBIAS_STATS) {
+    // per-block column sums through LDS, then one atomic per column per block
+    // into the partial buffer of this block's XCD slot
+    __syncthreads();
+    float* red = lds;  // [2][BN]
+    for (int c = tid; c < 2 * BN; c += NT) red[c] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, kWave);
+      float q = csq[j] + __shfl_xor(csq[j], 32, kWave);
+      if (h == 0) {
+        atomicAdd(&red[wn * 64 + j * 32 + r], s);
+        atomicAdd(&red[BN + wn * 64 + j * 32 + r], q);
+      }
+    }
+    __syncthreads();
+    float* dst = p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
+    for (int c = tid; c < BN; c += NT) {
+      if (n0 + c < N) {
+        atomicAdd(dst + n0 + c, red[c]);
+        atomicAdd(dst + N + n0 + c, red[BN + c]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C[N,K] += sum_m A[m,n] B[m,k] over this block's slice of M.  Tiles are read
+// "down the columns": lane (r,h) of MFMA step t takes A[m = 2t + h][n = i0 + r].
+// Optional producer on B (PRO_BNRELU over B's columns k) recomputes the
+// activation that was never stored.
+constexpr int TBM = 128, TBN = 128, TBK = 16;
+struct TnArgs {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  float* C;
+  int ldc;
+  const float* pro_scale;  // [K]
+  const float* pro_shift;
+  int rows_per_split;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
+  __shared__ float lds[2][TBK * (TBM + TBN)];
+  const int n0 = blockIdx.y * TBM, k0 = blockIdx.x * TBN;
+  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+  if (mbeg >= mend) return;
+  const int N = p.N, K = p.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  // each of the 16 rows holds 128 floats of A and 128 of B = 32 float4 each
+  const int srow = tid >> 5, scol = (tid & 31) * 4;  // rows srow and srow + 8
+  const bool aok = n0 + scol < N, bok = k0 + scol < K;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRO == PRO_BNRELU && bok) {
+    sc = *reinterpret_cast<const float4*>(p.pro_scale + k0 + scol);
+    sh = *reinterpret_cast<const float4*>(p.pro_shift + k0 + scol);
+  }
+  float4 ra[2], rb[2];
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gm = mt + srow + 8 * i;
+      const bool inm = gm < mend;
+      ra[i] = (inm && aok) ? *reinterpret_cast<const float4*>(p.A + (size_t)gm * p.lda + n0 + scol)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = (inm && bok) ? *reinterpret_cast<const float4*>(p.B + (size_t)gm * p.ldb + k0 + scol)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == PRO_BNRELU && inm && bok) {
+        rb[i].x = act_relu(rb[i].x * sc.x + sh.x);
+        rb[i].y = act_relu(rb[i].y * sc.y + sh.y);
+        rb[i].z = act_relu(rb[i].z * sc.z + sh.z);
+        rb[i].w = act_relu(rb[i].w * sc.w + sh.w);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&lds[buf][(srow + 8 * i) * (TBM + TBN) + scol]) = ra[i];
+      *reinterpret_cast<float4*>(&lds[buf][(srow + 8 * i) * (TBM + TBN) + TBM + scol]) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gload(mbeg);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mt = mbeg; mt < mend; mt += TBK) {
+    if (mt + TBK < mend) gload(mt + TBK);
+    const float* T = lds[buf];
+#pragma unroll
+    for (int t = 0; t < TBK / 2; ++t) {
+      const float* row = T + (2 * t + h) * (TBM + TBN);
+      const float a0 = row[wm * 64 + r], a1 = row[wm * 64 + 32 + r];
+      const float b0 = row[TBM + wn * 64 + r], b1 = row[TBM + wn * 64 + 32 + r];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (mt + TBK < mend) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wn * 64 + j * 32 + r;
+    if (col >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < N) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][e]);
+      }
+    }
+  }
+}
+
+// out[c] += sum_m X[m, c]  (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ X,
+                                                     int ldx, float* __restrict__ out,
+                                                     int rows_per_split) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  float s = 0.f;
+  if (c < N)
+    for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * ldx + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < N)
+    atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                           part[3][threadIdx.x]);
+}
+
+template <int BM, int BN, int PRO, int EPI>
+static void launch_nt_cfg(NtArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  a.tiles = tiles_m * a.tiles_n;
+  const int grid = 8 * ((a.tiles + 7) / 8);
+  constexpr int NTH = (BM / 64) * (BN / 64) * 64;
+  const size_t lds = 2 * (size_t)(BM + BN) * GLD * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<BM, BN, PRO, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, PRO, EPI>), dim3(grid), dim3(NTH), lds, s, a);
+}
+
+// 256x256 tiles when they fill the chip (>= 3/4 of the 256 CUs busy in the last
+// wave of blocks is not worth modelling: big problems only), else 128x128.
+template <int PRO, int EPI>
+static int launch_nt(NtArgs& a, hipStream_t s) {
+  const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (big_tiles >= 512 && a.N % 256 != 0 && a.N % 384 == 0) launch_nt_cfg<128, 384, PRO, EPI>(a, s);
+  else if (big_tiles >= 512) launch_nt_cfg<256, 256, PRO, EPI>(a, s);
+  else launch_nt_cfg<128, 128, PRO, EPI>(a, s);
+  return check_launch("gemm_nt");
+}
+
+static int check_nt(const char* who, int M, int N, int K) {
+  if (M < 0 || N <= 0 || K <= 0) return bad_arg(who);
+  if (K % 4 != 0) return unsupported("gemm: the reduction length must be a multiple of 4");
+  return PDAE_OK;
+}
+
+}  // namespace pdae
+
+using namespace pdae;
+
+extern "C" int pdae_linear_forward(int M, int N, int K, const float* X, const float* W,
+                                   const float* bias, int act, float* Y, pdae_stream_t stream) {
+  int rc = check_nt("linear_forward: bad size", M, N, K);
+  if (rc) return rc;
+  if (act < 0 || act > 2) return bad_arg("linear_forward: act must be 0, 1 or 2");
+  if (M == 0) return PDAE_OK;
+  if (!X || !W || !Y) return bad_arg("linear_forward: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N, a.bias = bias;
+  hipStream_t s = as_stream(stream);
+  if (act == 0) return launch_nt<PRO_NONE, EPI_BIAS>(a, s);
+  if (act == 1) return launch_nt<PRO_NONE, EPI_BIAS_RELU>(a, s);
+  return launch_nt<PRO_NONE, EPI_BIAS_GELU>(a, s);
+}
+
+extern "C" int pdae_linear_backward_data(int M, int N, int K, const float* dY, const float* Wt,
+                                         float* dX, pdae_stream_t stream) {
+  // dX[M,K] = dY[M,N] . W[N,K]  ==  NT product with W^T [K,N] (N contiguous)
+  int rc = check_nt("linear_backward_data: bad size", M, K, N);
+  if (rc) return rc;
+  if (M == 0) return PDAE_OK;
+  if (!dY || !Wt || !dX) return bad_arg("linear_backward_data: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = K, a.K = N, a.A = dY, a.lda = N, a.B = Wt, a.ldb = N, a.C = dX, a.ldc = K;
+  return launch_nt<PRO_NONE, EPI_BIAS>(a, as_stream(stream));
+}
+
+static int launch_tn(TnArgs& t, bool bnrelu, hipStream_t s) {
+  const int tn = (t.N + TBM - 1) / TBM, tk = (t.K + TBN - 1) / TBN;
+  // enough M-splits to cover the chip about four times, each at least 256 rows
+  int splits = (4 * 256 + tn * tk - 1) / (tn * tk);
+  int rows = (t.M + splits - 1) / splits;
+  rows = ((rows + TBK - 1) / TBK) * TBK;
+  if (rows < 256) rows = 256;
+  splits = (t.M + rows - 1) / rows;
+  t.rows_per_split = rows;
+  if (bnrelu) hipLaunchKernelGGL((gemm_tn_kernel<PRO_BNRELU>), dim3(tk, tn, splits), dim3(256), 0, s, t);
+  else hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), dim3(tk, tn, splits), dim3(256), 0, s, t);
+  return check_launch("gemm_tn");
+}
+
+extern "C" int pdae_linear_backward_weight(int M, int N, int K, const float* dY, const float* X,
+                                           float* dW, float* dbias, pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0) return bad_arg("linear_backward_weight: bad size");
+  if (!dW) return bad_arg("linear_backward_weight: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+  if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)N, s);
+  if (M == 0) return check_launch("linear_backward_weight");
+  if (!dY || !X) return bad_arg("linear_backward_weight: null pointer");
+  if (N % 4 != 0 || K % 4 != 0) return unsupported("linear_backward_weight: N, K multiples of 4");
+  TnArgs t = {};
+  t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
+  int rc = launch_tn(t, false, s);
+  if (rc) return rc;
+  if (dbias) {
+    int bs = (M + 4095) / 4096;
+    if (bs > 1024) bs = 1024;
+    const int brows = (M + bs - 1) / bs;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, bs), dim3(256), 0, s, M, N, dY, N, dbias,
+                       brows);
+  }
+  return check_launch("linear_backward_weight");
+}
+
+// ---- fused patch-embedder layers (models/PointCAE_transformer.py:37-51) ------
+extern "C" int pdae_embed_conv_store_groupmax(int M, int N, int K, const float* X, const float* W,
+                                              const float* bias, float* Y, float* gmax,
+                                              unsigned char* garg, pdae_stream_t stream) {
+  int rc = check_nt("embed_conv_store_groupmax: bad size", M, N, K);
+  if (rc) return rc;
+  if (M % 32 != 0) return bad_arg("embed_conv_store_groupmax: M must be a multiple of 32");
+  if (M == 0) return PDAE_OK;
+  if (!X || !W || !Y || !gmax || !garg) return bad_arg("embed_conv_store_groupmax: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N, a.bias = bias;
+  a.gmax = gmax, a.garg = garg;
+  return launch_nt<PRO_NONE, EPI_STORE_GROUPMAX>(a, as_stream(stream));
+}
+
+extern "C" int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float* X, const float* W,
+                                               const float* gbias, float* Y, float* stats,
+                                               pdae_stream_t stream) {
+  int rc = check_nt("embed_conv_groupbias_stats: bad size", M, N, K);
+  if (rc) return rc;
+  if (M % 32 != 0) return bad_arg("embed_conv_groupbias_stats: M must be a multiple of 32");
+  if (!stats) return bad_arg("embed_conv_groupbias_stats: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(stats, 0, sizeof(float) * 16 * (size_t)N, s);
+  if (M == 0) return check_launch("embed_conv_groupbias_stats");
+  if (!X || !W || !Y || !gbias) return bad_arg("embed_conv_groupbias_stats: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
+  a.gbias = gbias, a.stats = stats;
+  return launch_nt<PRO_NONE, EPI_GROUPBIAS_STATS>(a, s);
+}
+
+extern "C" int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,
+                                               const float* scale, const float* shift,
+                                               const float* W, const float* bias, float* gmax,
+                                               unsigned char* garg, pdae_stream_t stream) {
+  int rc = check_nt("embed_bnrelu_conv_groupmax: bad size", M, N, K);
+  if (rc) return rc;
+  if (M % 32 != 0) return bad_arg("embed_bnrelu_conv_groupmax: M must be a multiple of 32");
+  if (M == 0) return PDAE_OK;
+  if (!X || !scale || !shift || !W || !gmax || !garg)
+    return bad_arg("embed_bnrelu_conv_groupmax: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.bias = bias;
+  a.pro_scale = scale, a.pro_shift = shift, a.gmax = gmax, a.garg = garg;
+  return launch_nt<PRO_BNRELU, EPI_GROUPMAX>(a, as_stream(stream));
+}
+
+extern "C" int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
+                                                  const float* X, const float* scale,
+                                                  const float* shift, float* dW,
+                                                  pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0) return bad_arg("bnrelu_linear_backward_weight: bad size");
+  if (!dW) return bad_arg("bnrelu_linear_backward_weight: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+  if (M == 0) return check_launch("bnrelu_linear_backward_weight");
+  if (!dY || !X || !scale || !shift) return bad_arg("bnrelu_linear_backward_weight: null pointer");
+  if (N % 4 != 0 || K % 4 != 0) return unsupported("bnrelu_linear_backward_weight: N, K multiples of 4");
+  TnArgs t = {};
+  t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
+  t.pro_scale = scale, t.pro_shift = shift;
+  return launch_tn(t, true, s);
+}
+
+extern "C" int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,
+                                                     const float* scale, const float* shift,
+                                                     const float* W, const float* bias, float* Y,
+                                                     float* gmax, unsigned char* garg,
+                                                     pdae_stream_t stream) {
+  int rc = check_nt("embed_bnrelu_conv_store_groupmax: bad size", M, N, K);
+  if (rc) return rc;
+  if (M % 32 != 0) return bad_arg("embed_bnrelu_conv_store_groupmax: M must be a multiple of 32");
+  if (M == 0) return PDAE_OK;
+  if (!X || !scale || !shift || !W || !Y || !gmax || !garg)
+    return bad_arg("embed_bnrelu_conv_store_groupmax: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N, a.bias = bias;
+  a.pro_scale = scale, a.pro_shift = shift, a.gmax = gmax, a.garg = garg;
+  return launch_nt<PRO_BNRELU, EPI_STORE_GROUPMAX>(a, as_stream(stream));
+}

@@ -9,40 +9,8 @@ import torch
 import torch.nn.functional as F
 
 
-class Probe:
-    """HIP-event timer for ONE named kernel launch site, used by bench.py's
-    roofline: events are recorded on the stream the kernel is launched on,
-    around every launch inside the timed region, and read after it."""
-
-    def __init__(self):
-        self.name, self.flops, self.events = None, 0.0, []
-
-    def record(self, name, flops, fn):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = fn()
-        e.record()
-        self.name, self.flops = name, flops
-        self.events.append((s, e))
-        return out
-
-    def summary(self):
-        if not self.events:
-            return None
-        ms = [s.elapsed_time(e) for s, e in self.events]
-        return {'name': self.name, 'flops': self.flops, 'avg_ms': sum(ms) / len(ms), 'launches': len(ms)}
-
-
-_probe = None
-
-
-def set_probe(p):
-    global _probe
-    _probe = p
-
-
-def _probed(name, flops, fn):
-    return _probe.record(name, flops, fn) if _probe is not None else fn()
+from .patch_embed import patch_embed  # noqa: F401  (fused gfx950 embedder)
+from .probe import Probe, set_probe  # noqa: F401
 
 
 def linear(x, lin, act=None):
@@ -97,29 +65,3 @@ def transformer_block(x, pos, B, T, blk, training):
     x = x + drop_path(attention(layer_norm(x, blk.norm1), B, T, blk.attn), B, blk.drop_prob, training)
     h = linear(layer_norm(x, blk.norm2), blk.mlp.fc1, 'gelu')
     return x + drop_path(linear(h, blk.mlp.fc2), B, blk.drop_prob, training)
-
-
-def patch_embed(points, first_conv, second_conv, training):
-    """mini-PointNet of Encoder.forward (PointCAE_transformer.py:37-51) on
-    points (BG, n, 3) -> (BG, C).
-
-    The 512->512 layer consumes concat([global.expand(n), local]); its weight
-    is split so the global half is multiplied once per GROUP instead of once
-    per point (BG x 256 x 512 instead of BG*n x 256 x 512): the same sum,
-    associated differently.
-    """
-    BG, n, _ = points.shape
-    rows = points.reshape(BG * n, 3)
-    f = conv1x1(rows, first_conv[0])
-    f = F.relu(first_conv[1](f))                    # BatchNorm1d on (rows, C): batch statistics
-    f = conv1x1(f, first_conv[3])                   # (BG*n, 256)
-    g = f.reshape(BG, n, -1).max(dim=1)[0]          # (BG, 256)
-    w = second_conv[0].weight.squeeze(-1)           # (512, 512) = [global | local]
-    cg = g.shape[1]
-    h = F.linear(f, w[:, cg:]).reshape(BG, n, -1) + F.linear(g, w[:, :cg], second_conv[0].bias).unsqueeze(1)
-    h = F.relu(second_conv[1](h.reshape(BG * n, -1)))
-    # the largest GEMM of the step (M = BG*n rows, K = 512, N = C): bench.py's roofline kernel
-    cout = second_conv[3].weight.shape[0]
-    h = _probed('patch_embed.second_conv.3 fwd GEMM %dx%dx%d' % (h.shape[0], h.shape[1], cout),
-                2.0 * h.shape[0] * h.shape[1] * cout, lambda: conv1x1(h, second_conv[3]))
-    return h.reshape(BG, n, -1).max(dim=1)[0]

@@ -1,0 +1,170 @@
+"""Fused patch embedder (mini-PointNet) of the Transformer DAE.
+
+Computes Encoder.forward of the reference (models/PointCAE_transformer.py:37-51)
+
+    f  = conv2(relu(bn1(conv1(x))))                     (R, 256)   R = B*G*32 points
+    g  = max over each group's 32 points of f           (BG, 256)
+    h3 = conv3(concat([g expanded, f]))                 (R, 512)
+    t  = max over the group of conv4(relu(bn2(h3)))     (BG, C)
+
+with the gfx950 kernels of csrc/gemm.hip and csrc/embed.hip instead of a chain of
+cuDNN convs and separate BatchNorm / ReLU / max / concat / add passes:
+
+  forward   conv2: BN1+ReLU applied while A is staged, epilogue stores f AND the
+                   group max / argmax;
+            conv3: the concat is never built -- the weight is split, the global
+                   half is one small GEMM per group and enters as a per-group
+                   bias; the epilogue accumulates BatchNorm's batch statistics;
+            conv4: BN2+ReLU applied while A is staged, epilogue keeps only the
+                   group max / argmax: the (R, C) product is never written.
+  backward  max-pool / ReLU / BatchNorm backward are three fused sweeps
+            (group_max_scatter, bnrelu_backward, group_scatter_add); weight
+            gradients recompute the BN+ReLU activations in the GEMM producer;
+            plain data-gradient GEMMs go to the BLAS library.
+
+Training-mode BatchNorm semantics are PyTorch's: biased batch variance for the
+normalisation, unbiased for the running estimate, momentum 0.1.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .probe import probed
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _bn_affine(bn, mean, var_biased, rows, training):
+    """scale / shift of y = x*scale + shift for this BatchNorm, plus invstd; in
+    training mode also updates the running statistics like nn.BatchNorm1d."""
+    if training:
+        invstd = torch.rsqrt(var_biased + bn.eps)
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var_biased * (rows / max(rows - 1, 1)), alpha=m)
+            bn.num_batches_tracked += 1
+    else:
+        mean = bn.running_mean
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = (bn.weight * invstd).contiguous()
+    shift = (bn.bias - mean * scale).contiguous()
+    return scale, shift, mean.contiguous(), invstd.contiguous()
+
+
+class PatchEmbedFunction(torch.autograd.Function):
+    """points (R,3) + the 12 parameter tensors of Encoder -> tokens (R/32, C)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, first_conv, second_conv, training):
+        R = x.shape[0]
+        BG = R // 32
+        x = x.contiguous()
+        w1m, w2m = w1.squeeze(-1), w2.squeeze(-1).contiguous()
+        w3m, w4m = w3.squeeze(-1), w4.squeeze(-1).contiguous()
+        c1, c2, c3, c4 = w1m.shape[0], w2m.shape[0], w3m.shape[0], w4m.shape[0]
+        # conv1 (K = 3) + BN1 statistics
+        y1 = F.linear(x, w1m, b1)
+        if training:
+            var1, mean1 = torch.var_mean(y1, dim=0, unbiased=False)
+        else:
+            var1 = mean1 = None
+        sc1, sh1, mean1, is1 = _bn_affine(first_conv[1], mean1, var1, R, training)
+        # conv2: BN1+ReLU producer, store f, group max
+        f = _empty((R, c2), x)
+        g = _empty((BG, c2), x)
+        arg2 = _empty((BG, c2), x, torch.uint8)
+        _lib.call('pdae_embed_bnrelu_conv_store_groupmax', x, R, c2, c1, _lib.ptr(y1), _lib.ptr(sc1),
+                  _lib.ptr(sh1), _lib.ptr(w2m), _lib.ptr(b2), _lib.ptr(f), _lib.ptr(g), _lib.ptr(arg2))
+        # conv3 on concat([g, f]): global half once per group, local half as the GEMM
+        wg = w3m[:, :c2].contiguous()
+        wl = w3m[:, c2:].contiguous()
+        gb = F.linear(g, wg, b3)
+        h3 = _empty((R, c3), x)
+        stats = _empty((8, 2, c3), x)
+        _lib.call('pdae_embed_conv_groupbias_stats', x, R, c3, c2, _lib.ptr(f), _lib.ptr(wl), _lib.ptr(gb),
+                  _lib.ptr(h3), _lib.ptr(stats))
+        if training:
+            s = stats.sum(0)
+            mean2 = s[0] / R
+            var2 = (s[1] / R - mean2 * mean2).clamp_min_(0.)
+        else:
+            mean2 = var2 = None
+        sc2, sh2, mean2, is2 = _bn_affine(second_conv[1], mean2, var2, R, training)
+        # conv4: BN2+ReLU producer, only the group max leaves the kernel
+        tok = _empty((BG, c4), x)
+        arg4 = _empty((BG, c4), x, torch.uint8)
+        # the largest GEMM of the step: bench.py's roofline kernel
+        probed('gemm_nt_kernel<128,384,BNRELU,GROUPMAX> patch_embed.second_conv fwd %dx%dx%d' % (R, c4, c3),
+               2.0 * R * c4 * c3,
+               lambda: _lib.call('pdae_embed_bnrelu_conv_groupmax', x, R, c4, c3, _lib.ptr(h3), _lib.ptr(sc2),
+                                 _lib.ptr(sh2), _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4)))
+        ctx.save_for_backward(x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
+                              w1m, w2m, wg, wl, w4m, g1, g2)
+        ctx.training = training
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        if not ctx.training:
+            raise NotImplementedError('patch embedder backward is implemented for training-mode BatchNorm')
+        (x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
+         w1m, w2m, wg, wl, w4m, g1, g2) = ctx.saved_tensors
+        R, BG = x.shape[0], x.shape[0] // 32
+        c1, c2, c3, c4 = w1m.shape[0], w2m.shape[0], wl.shape[0], w4m.shape[0]
+        dtok = dtok.contiguous()
+        # ---- conv4 + max-pool
+        dy4 = _empty((R, c4), x)
+        _lib.call('pdae_group_max_scatter', x, BG, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
+        db4 = dtok.sum(0)
+        dw4 = _empty((c4, c3), x)
+        _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
+                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4))
+        d3 = torch.mm(dy4, w4m)                                   # (R, 512) grad of relu(bn2(h3))
+        del dy4
+        # ---- ReLU + BN2 backward (in place) + per-group sums for the global half
+        S2 = _empty((2, c3), x)
+        dgb = _empty((BG, c3), x)
+        _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb))
+        dbe2, dg2 = S2[0], S2[1]
+        # ---- conv3 (split weight)
+        dwl = _empty((c3, c2), x)
+        _lib.call('pdae_linear_backward_weight', x, R, c3, c2, _lib.ptr(d3), _lib.ptr(f), _lib.ptr(dwl), None)
+        dwg = torch.mm(dgb.t(), g)
+        db3 = dgb.sum(0)
+        dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
+        df = torch.mm(d3, wl)                                     # (R, 256)
+        del d3
+        dg = torch.mm(dgb, wg)                                    # (BG, 256) -> arg-max rows of f
+        _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
+        # ---- conv2
+        dw2 = _empty((c2, c1), x)
+        _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c2, c1, _lib.ptr(df), _lib.ptr(y1),
+                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2))
+        db2 = df.sum(0)
+        d1 = torch.mm(df, w2m)                                    # (R, 128)
+        del df
+        # ---- ReLU + BN1 backward, conv1 (K = 3)
+        S1 = _empty((2, c1), x)
+        _lib.call('pdae_bnrelu_backward', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
+                  _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None)
+        dbe1, dg1 = S1[0], S1[1]
+        dw1 = torch.mm(d1.t(), x).unsqueeze(-1)
+        db1 = d1.sum(0)
+        return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
+                dw4.unsqueeze(-1), db4, None, None, None)
+
+
+def patch_embed(points, first_conv, second_conv, training):
+    """points (BG, n=32, 3) -> (BG, C)."""
+    BG, n, _ = points.shape
+    if n != 32:
+        raise NotImplementedError('the fused embedder is written for group_size 32')
+    return PatchEmbedFunction.apply(
+        points.reshape(BG * n, 3), first_conv[0].weight, first_conv[0].bias, first_conv[1].weight,
+        first_conv[1].bias, first_conv[3].weight, first_conv[3].bias, second_conv[0].weight,
+        second_conv[0].bias, second_conv[1].weight, second_conv[1].bias, second_conv[3].weight,
+        second_conv[3].bias, first_conv, second_conv, training)
