@@ -48,6 +48,7 @@ def parse():
     p.add_argument('--npoints', type=int, default=1024)
     p.add_argument('--num_group', type=int, default=64)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying hipGraphs')
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--cpu-steps', type=int, default=3)
     return p.parse_args()
@@ -115,6 +116,7 @@ def main():
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.misc import set_random_seed
+    from point_dae_amd.graph_step import GraphedTrainStep
     from point_dae_amd.runner_pretrain import train_step
     from point_dae_amd.synthetic import shapenet_like_clouds
 
@@ -131,8 +133,22 @@ def main():
     clouds = torch.from_numpy(shapenet_like_clouds(args.batch * pool, args.npoints, seed=100 + rank)).to(device)
     batches = list(clouds.split(args.batch))
 
+    if args.eager:
+        def step(x):
+            return train_step(model, optimizer, config, x, x)
+    else:
+        step = GraphedTrainStep(model, optimizer, config, args.batch, args.npoints)
+        # capture every graph (one per visible-token count) before the warm-up
+        # and timed steps; captures are set-up, not steps
+        for tvis in range(args.num_group - int(0.8 * args.num_group), args.num_group - int(0.5 * args.num_group) + 1):
+            step.pts.copy_(batches[0])
+            step._draw()
+            if tvis not in step.graphs:
+                step._capture(tvis)
+        step.eager_left = 0
+        model.zero_grad()
     for i in range(args.warmup):
-        train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+        step(batches[i % pool])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -141,7 +157,7 @@ def main():
     nn_ops.set_probe(probe)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+        step(batches[i % pool])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,7 +187,7 @@ def main():
             'config': {'workload': 'cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
                        'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
-                       'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world},
+                       'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay'},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

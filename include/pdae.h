@@ -261,6 +261,55 @@ int pdae_bnrelu_backward(int G, int C, float* dA, const float* X,
                          const float* gamma, float* S, float* gsum /*nullable*/,
                          pdae_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Transformer block, Block.forward (models/PointCAE_transformer.py:155-158 with
+ * the per-block position add of :174-177) and Attention.forward (:125-137).
+ * Activations are rows (B*T, C); T tokens per sample, H heads of D = 64.
+ *
+ *   attention_forward   qkv (B*T, 3*H*D) as laid out by the qkv Linear
+ *                       ([3][H][D] per row) -> o (B*T, H*D) =
+ *                       softmax(q k^T * scale) v per (sample, head), and
+ *                       lse (B,H,T) = log-sum-exp of each score row (saved for
+ *                       the backward).  T <= 128.
+ *   attention_backward  -> dqkv (B*T, 3*H*D), fully written.
+ *   add_layernorm_forward  s = x (+ pos, nullable; then xsum receives s);
+ *                       y = LayerNorm(s) * gamma + beta; mean/rstd (M) saved.
+ *   layernorm_backward  dx = LayerNorm'(dy) (+ dres, nullable: the gradient
+ *                       arriving over the skip connection); dgamma/dbeta (C)
+ *                       are overwritten.
+ *   gelu_forward / gelu_backward   exact (erf) GELU, nn.GELU default (:97,:107).
+ *   scale_residual      y = res + keep[row/T] * (a + bias): Linear bias, timm
+ *                       DropPath (keep[b] is 0 or 1/keep_prob) and the residual
+ *                       add in one pass; bias / keep / res nullable.
+ *   colsum              out[c] = sum over rows of X[:, c] (bias gradients).
+ */
+int pdae_attention_forward(int B, int T, int H, int D, float scale,
+                           const float* qkv, float* o, float* lse,
+                           pdae_stream_t stream);
+int pdae_attention_backward(int B, int T, int H, int D, float scale,
+                            const float* qkv, const float* o, const float* lse,
+                            const float* d_o, float* dqkv, pdae_stream_t stream);
+int pdae_add_layernorm_forward(int M, int C, const float* x,
+                               const float* pos /*nullable*/, const float* gamma,
+                               const float* beta, float eps,
+                               float* xsum /*nullable*/, float* y, float* mean,
+                               float* rstd, pdae_stream_t stream);
+int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
+                            const float* mean, const float* rstd,
+                            const float* gamma, const float* dres /*nullable*/,
+                            float* dx, float* dgamma, float* dbeta,
+                            pdae_stream_t stream);
+int pdae_gelu_forward(long long n, const float* z, float* h,
+                      pdae_stream_t stream);
+int pdae_gelu_backward(long long n, const float* z, const float* dh, float* dz,
+                       pdae_stream_t stream);
+int pdae_scale_residual(int M, int C, int T, const float* a,
+                        const float* bias /*nullable*/,
+                        const float* keep /*nullable*/,
+                        const float* res /*nullable*/, float* y,
+                        pdae_stream_t stream);
+int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

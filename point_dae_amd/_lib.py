@@ -39,6 +39,14 @@ _SIGNATURES = {
     "pdae_group_max_scatter": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_group_scatter_add": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_attention_forward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "pdae_attention_backward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_add_layernorm_forward": [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "pdae_layernorm_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_gelu_forward": [ctypes.c_longlong, _vp, _vp, _vp],
+    "pdae_gelu_backward": [ctypes.c_longlong, _vp, _vp, _vp, _vp],
+    "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_colsum": [_i, _i, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,306 @@
+// block.hip -- the row-wise (memory-bound) pieces of a pre-LN Transformer block,
+// each as one fused sweep.  Block.forward of the reference
+// (models/PointCAE_transformer.py:155-158 with :174-177):
+//     x = x + pos;  x = x + dp(attn(ln1(x)));  x = x + dp(mlp(ln2(x)))
+// PyTorch runs add, LayerNorm, bias, GELU, DropPath's div/mul, the residual adds
+// and every backward twin as separate kernels (~80 launches per block and step).
+//   add_layernorm_fwd   s = x (+ pos);  y = LN(s);  saves mean / rstd
+//   layernorm_bwd       dx = LN'(dy) (+ skip-connection gradient), dgamma/dbeta
+//   gelu_fwd / gelu_bwd exact (erf) GELU and its derivative
+//   scale_residual      y = res + keep[b] * (a + bias)   (DropPath + bias + skip)
+//   rowscale            da = keep[b] * dy                (its backward)
+//   colsum              bias gradients
+// One wave per row for the LayerNorm kernels (C <= 2048), float4 everywhere.
+#include "common.h"
+
+namespace pdae {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+
+constexpr int LN_MAX4 = 8;  // float4 per lane: C <= 2048
+
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
+    int M, int C, const float* __restrict__ x, const float* __restrict__ pos,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float* __restrict__ xsum, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = lane_id();
+  const int n4 = C >> 2;
+  float4 v[LN_MAX4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX4; ++i) {
+    const int c4 = lane + i * kWave;
+    if (c4 < n4) {
+      float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * C + c4 * 4);
+      if (pos) {
+        const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)row * C + c4 * 4);
+        a.x += p.x, a.y += p.y, a.z += p.z, a.w += p.w;
+        *reinterpret_cast<float4*>(xsum + (size_t)row * C + c4 * 4) = a;
+      }
+      v[i] = a;
+      s += (a.x + a.y) + (a.z + a.w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX4; ++i) {
+    const int c4 = lane + i * kWave;
+    if (c4 < n4) {
+      const float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAX4; ++i) {
+    const int c4 = lane + i * kWave;
+    if (c4 < n4) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c4 * 4);
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x;
+      o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z;
+      o.w = (v[i].w - mu) * rs * g.w + b.w;
+      *reinterpret_cast<float4*>(y + (size_t)row * C + c4 * 4) = o;
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);
+// dgamma += sum dy*xhat, dbeta += sum dy over this block's rows (LDS, then atomics)
+constexpr int LNB_ROWS = 32;  // rows per block (4 waves x 8)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    int M, int C, const float* __restrict__ dy, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float red[];  // [2][C]
+  for (int c = threadIdx.x; c < 2 * C; c += 256) red[c] = 0.f;
+  __syncthreads();
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int n4 = C >> 2;
+  float4 ag[LN_MAX4], ab[LN_MAX4];
+#pragma unroll
+  for (int i = 0; i < LN_MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+    const int row = blockIdx.x * LNB_ROWS + rr * 4 + w;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float4 gd[LN_MAX4], xh[LN_MAX4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX4; ++i) {
+      const int c4 = lane + i * kWave;
+      if (c4 < n4) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + c4 * 4);
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * C + c4 * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+        ag[i].x += d.x * xh[i].x, ag[i].y += d.y * xh[i].y, ag[i].z += d.z * xh[i].z, ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x, ab[i].y += d.y, ab[i].z += d.z, ab[i].w += d.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAX4; ++i) {
+      const int c4 = lane + i * kWave;
+      if (c4 < n4) {
+        float4 o;
+        o.x = rs * (gd[i].x - m1 - xh[i].x * m2);
+        o.y = rs * (gd[i].y - m1 - xh[i].y * m2);
+        o.z = rs * (gd[i].z - m1 - xh[i].z * m2);
+        o.w = rs * (gd[i].w - m1 - xh[i].w * m2);
+        if (dres) {
+          const float4 e = *reinterpret_cast<const float4*>(dres + (size_t)row * C + c4 * 4);
+          o.x += e.x, o.y += e.y, o.z += e.z, o.w += e.w;
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)row * C + c4 * 4) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAX4; ++i) {
+    const int c4 = lane + i * kWave;
+    if (c4 < n4) {
+      atomicAdd(&red[c4 * 4 + 0], ag[i].x), atomicAdd(&red[c4 * 4 + 1], ag[i].y);
+      atomicAdd(&red[c4 * 4 + 2], ag[i].z), atomicAdd(&red[c4 * 4 + 3], ag[i].w);
+      atomicAdd(&red[C + c4 * 4 + 0], ab[i].x), atomicAdd(&red[C + c4 * 4 + 1], ab[i].y);
+      atomicAdd(&red[C + c4 * 4 + 2], ab[i].z), atomicAdd(&red[C + c4 * 4 + 3], ab[i].w);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, red[c]);
+    atomicAdd(dbeta + c, red[C + c]);
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  // d/dv [v Phi(v)] = Phi(v) + v phi(v)
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(long long n4, const float4* __restrict__ z,
+                                                       float4* __restrict__ h) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = z[i];
+  h[i] = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(long long n4, const float4* __restrict__ z,
+                                                       const float4* __restrict__ dh,
+                                                       float4* __restrict__ dz) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = z[i], d = dh[i];
+  dz[i] = make_float4(d.x * gelu_grad_f(v.x), d.y * gelu_grad_f(v.y), d.z * gelu_grad_f(v.z),
+                      d.w * gelu_grad_f(v.w));
+}
+
+// y[row] = res[row] + keep[row / T] * (a[row] + bias)     (keep, bias, res nullable)
+__global__ __launch_bounds__(256) void scale_residual_kernel(long long n4, int C4, int T,
+                                                             const float4* __restrict__ a,
+                                                             const float4* __restrict__ bias,
+                                                             const float* __restrict__ keep,
+                                                             const float4* __restrict__ res,
+                                                             float4* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long long row = i / C4;
+  float4 v = a[i];
+  if (bias) {
+    const float4 b = bias[i - row * C4];
+    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  }
+  if (keep) {
+    const float k = keep[row / T];
+    v.x *= k, v.y *= k, v.z *= k, v.w *= k;
+  }
+  if (res) {
+    const float4 r = res[i];
+    v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+  }
+  y[i] = v;
+}
+
+__global__ __launch_bounds__(256) void colsum2_kernel(int M, int N, const float* __restrict__ X,
+                                                      float* __restrict__ out, int rows_per_split) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  float s = 0.f;
+  if (c < N)
+    for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * N + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < N)
+    atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                           part[3][threadIdx.x]);
+}
+
+}  // namespace pdae
+
+using namespace pdae;
+
+extern "C" int pdae_add_layernorm_forward(int M, int C, const float* x, const float* pos,
+                                          const float* gamma, const float* beta, float eps,
+                                          float* xsum, float* y, float* mean, float* rstd,
+                                          pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4)
+    return bad_arg("add_layernorm_forward: C must be a multiple of 4, at most 2048");
+  if (M == 0) return PDAE_OK;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || (pos && !xsum))
+    return bad_arg("add_layernorm_forward: null pointer");
+  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), M,
+                     C, x, pos, gamma, beta, eps, xsum, y, mean, rstd);
+  return check_launch("add_layernorm_forward");
+}
+
+extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
+                                       const float* mean, const float* rstd, const float* gamma,
+                                       const float* dres, float* dx, float* dgamma, float* dbeta,
+                                       pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4)
+    return bad_arg("layernorm_backward: C must be a multiple of 4, at most 2048");
+  if (!dgamma || !dbeta) return bad_arg("layernorm_backward: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, s);
+  (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, s);
+  if (M == 0) return check_launch("layernorm_backward");
+  if (!dy || !x || !mean || !rstd || !gamma || !dx) return bad_arg("layernorm_backward: null pointer");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256),
+                     2 * C * sizeof(float), s, M, C, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+  return check_launch("layernorm_backward");
+}
+
+extern "C" int pdae_gelu_forward(long long n, const float* z, float* h, pdae_stream_t stream) {
+  if (n < 0 || n % 4 != 0) return bad_arg("gelu_forward: n must be a multiple of 4");
+  if (n == 0) return PDAE_OK;
+  if (!z || !h) return bad_arg("gelu_forward: null pointer");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), n / 4, reinterpret_cast<const float4*>(z),
+                     reinterpret_cast<float4*>(h));
+  return check_launch("gelu_forward");
+}
+
+extern "C" int pdae_gelu_backward(long long n, const float* z, const float* dh, float* dz,
+                                  pdae_stream_t stream) {
+  if (n < 0 || n % 4 != 0) return bad_arg("gelu_backward: n must be a multiple of 4");
+  if (n == 0) return PDAE_OK;
+  if (!z || !dh || !dz) return bad_arg("gelu_backward: null pointer");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), n / 4, reinterpret_cast<const float4*>(z),
+                     reinterpret_cast<const float4*>(dh), reinterpret_cast<float4*>(dz));
+  return check_launch("gelu_backward");
+}
+
+extern "C" int pdae_scale_residual(int M, int C, int T, const float* a, const float* bias,
+                                   const float* keep, const float* res, float* y,
+                                   pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || T <= 0) return bad_arg("scale_residual: bad size");
+  if (M == 0) return PDAE_OK;
+  if (!a || !y) return bad_arg("scale_residual: null pointer");
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(scale_residual_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), n4, C / 4, T, reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<const float4*>(bias), keep, reinterpret_cast<const float4*>(res),
+                     reinterpret_cast<float4*>(y));
+  return check_launch("scale_residual");
+}
+
+extern "C" int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream) {
+  if (M < 0 || N <= 0) return bad_arg("colsum: bad size");
+  if (!out) return bad_arg("colsum: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+  if (M == 0) return check_launch("colsum");
+  if (!X) return bad_arg("colsum: null pointer");
+  int bs = (M + 511) / 512;
+  if (bs > 2048) bs = 2048;
+  const int rows = (M + bs - 1) / bs;
+  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 63) / 64, bs), dim3(256), 0, s, M, N, X, out, rows);
+  return check_launch("colsum");
+}

@@ -1,0 +1,111 @@
+"""The optimisation step as replayed hipGraphs.
+
+An eager step of this model is ~1800 kernel launches; on MI355X the kernels of
+one step take ~25 ms while the Python/launch path needs ~33 ms, so the eager
+step is host-bound.  Here forward + loss + backward are captured once per
+number of visible tokens (the mask ratio is drawn per batch, so the encoder's
+token count T_vis takes ~20 values) and replayed; the host only draws the
+random mask / affine maps with the reference's RNG calls (MaskTransformer
+._mask_center_rand, corrupt_data) and copies them into static device buffers.
+All graphs share one memory pool (activations of one step, ~6 GB of the 288 GB).
+
+The gradient all-reduce (world > 1) and the optimiser run right after the
+replay, outside the graph.
+"""
+import torch
+
+from .corrupt_util_tensor import draw_corruption
+from .data_parallel import FlatDataParallel
+from .point_cae_transformer import draw_mask, mask_row_ids
+
+
+class GraphedTrainStep:
+    MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
+
+    def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2):
+        assert isinstance(model, FlatDataParallel)
+        self.model, self.optimizer, self.config = model, optimizer, config
+        self.net = model.module
+        dev = model.flat_param.device
+        self.B, self.G = batch_size, self.net.num_group
+        self.pts = torch.zeros(batch_size, npoints, 3, device=dev)
+        self.steps = torch.zeros(self.MAX_STEPS, batch_size, 10, device=dev)
+        self.steps_host = torch.zeros(self.MAX_STEPS, batch_size, 10).pin_memory()
+        self.vis = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
+        self.msk = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
+        self.vis_host = torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory()
+        self.msk_host = torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory()
+        self.graphs, self.outputs = {}, {}
+        self.pool = None
+        self.eager_left = warmup_eager
+        self.normal_weight = float(config.normal_weight)
+        if config.loss_type not in ('xyz', 'xyznormal'):
+            raise NotImplementedError('graphed step: loss_type %s' % config.loss_type)
+
+    def _draw(self):
+        """Host RNG, in the order the eager forward consumes it: corruption
+        (corrupt_util_tensor.py:706-727) first, then the mask (:395-422)."""
+        enc = self.net.MAE_encoder
+        steps = draw_corruption(self.net.corrupt_type, self.B)
+        mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
+        enc.num_mask = int(enc.mask_ratio * self.G)
+        n = steps.shape[0]
+        self.steps_host.zero_()
+        self.steps_host[:, :, 1:4] = 1.0                       # identity 'multiply' steps
+        if n:
+            self.steps_host[:n].copy_(steps)
+        vis_rows, mask_rows = mask_row_ids(mask)
+        tvis = vis_rows.numel() // self.B
+        self.vis_host[:vis_rows.numel()].copy_(vis_rows)
+        self.msk_host[:mask_rows.numel()].copy_(mask_rows)
+        self.steps.copy_(self.steps_host, non_blocking=True)
+        self.vis.copy_(self.vis_host, non_blocking=True)
+        self.msk.copy_(self.msk_host, non_blocking=True)
+        return tvis
+
+    def _fwd_bwd(self, tvis):
+        nv = self.B * tvis
+        nm = self.B * (self.G - tvis)
+        self.model.flat_grad.zero_()
+        lx, ln = self.model(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+        loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
+        loss.backward()
+        return lx.detach(), ln.detach()
+
+    def _capture(self, tvis):
+        sync = self.model.require_sync
+        self.model.require_sync = False
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # warm-up on a side stream (PyTorch recipe)
+            self._fwd_bwd(tvis)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self.pool):
+            out = self._fwd_bwd(tvis)
+        self.model.require_sync = sync
+        self.graphs[tvis], self.outputs[tvis] = g, out
+        return g
+
+    def __call__(self, points, gt=None):
+        self.pts.copy_(points[:, :, :3], non_blocking=True)
+        tvis = self._draw()
+        if self.eager_left > 0:                                # first steps eager: library init, autotuning
+            self.eager_left -= 1
+            sync = self.model.require_sync
+            self.model.require_sync = False
+            out = self._fwd_bwd(tvis)
+            self.model.require_sync = sync
+        else:
+            g = self.graphs.get(tvis)
+            if g is None:
+                g = self._capture(tvis)
+            g.replay()
+            out = self.outputs[tvis]
+        if self.model.world_size > 1:
+            torch.distributed.all_reduce(self.model.flat_grad, group=self.model.process_group)
+            self.model.flat_grad.div_(self.model.world_size)
+        self.optimizer.step()
+        return out

@@ -1,22 +1,169 @@
 """Dense layers of the pretraining step on flat (rows, channels) activations.
 
 The model code (point_cae_transformer.py, point_cae_pointnetv2.py) only calls
-the functions below, so each can move from a PyTorch-ROCm library call to a
-hand-written gfx950 kernel without touching the models.  Parameters are read
-from the reference-layout nn.Modules that own them.
+the functions below.  Plain GEMMs (nn.Linear without a fusable neighbour) go to
+the BLAS library (hipBLASLt through torch.mm / addmm); everything around them --
+the fused patch embedder (patch_embed.py), the attention core, LayerNorm with
+the position / residual adds, GELU, bias + DropPath + residual -- runs on the
+hand-written gfx950 kernels of csrc/{gemm,embed,attention,block}.hip through
+autograd Functions whose backward calls the matching backward kernels.
+Parameters are read from the reference-layout nn.Modules that own them.
 """
 import torch
 import torch.nn.functional as F
 
-
+from . import _lib
 from .patch_embed import patch_embed  # noqa: F401  (fused gfx950 embedder)
 from .probe import Probe, set_probe  # noqa: F401
 
 
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _colsum(x):
+    out = _empty((x.shape[1],), x)
+    _lib.call('pdae_colsum', x, x.shape[0], x.shape[1], _lib.ptr(x), _lib.ptr(out))
+    return out
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(s, y) = (x + pos, LayerNorm(x + pos)); pos may be None (then s is x)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, gamma, beta, eps):
+        x = x.contiguous()
+        M, C = x.shape
+        y = torch.empty_like(x)
+        mean, rstd = _empty((M,), x), _empty((M,), x)
+        if pos is not None:
+            pos = pos.contiguous()
+            s = torch.empty_like(x)
+        else:
+            s = x
+        _lib.call('pdae_add_layernorm_forward', x, M, C, _lib.ptr(x), _lib.ptr(pos), _lib.ptr(gamma),
+                  _lib.ptr(beta), float(eps), _lib.ptr(s) if pos is not None else None, _lib.ptr(y),
+                  _lib.ptr(mean), _lib.ptr(rstd))
+        ctx.save_for_backward(s, mean, rstd, gamma)
+        ctx.has_pos = pos is not None
+        ctx.mark_non_differentiable(mean, rstd)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, mean, rstd, gamma = ctx.saved_tensors
+        M, C = s.shape
+        dx = torch.empty_like(s)
+        dg, db = _empty((C,), s), _empty((C,), s)
+        dres = ds.contiguous() if ds is not None else None
+        _lib.call('pdae_layernorm_backward', s, M, C, _lib.ptr(dy.contiguous()), _lib.ptr(s), _lib.ptr(mean),
+                  _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db))
+        return dx, (dx if ctx.has_pos else None), dg, db, None
+
+
+def add_layer_norm(x, pos, ln):
+    """-> (x + pos, LN(x + pos)); the sum feeds the residual stream."""
+    return _AddLayerNorm.apply(x, pos, ln.weight, ln.bias, ln.eps)
+
+
+def layer_norm(x, ln):
+    return _AddLayerNorm.apply(x, None, ln.weight, ln.bias, ln.eps)[1]
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, B, T, H, scale):
+        qkv = qkv.contiguous()
+        D = qkv.shape[1] // (3 * H)
+        o = _empty((B * T, H * D), qkv)
+        lse = _empty((B, H, T), qkv)
+        _lib.call('pdae_attention_forward', qkv, B, T, H, D, float(scale), _lib.ptr(qkv), _lib.ptr(o),
+                  _lib.ptr(lse))
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.dims = (B, T, H, D, float(scale))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, T, H, D, scale = ctx.dims
+        dqkv = torch.empty_like(qkv)
+        _lib.call('pdae_attention_backward', qkv, B, T, H, D, scale, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse),
+                  _lib.ptr(do.contiguous()), _lib.ptr(dqkv))
+        return dqkv, None, None, None, None
+
+
+def attention_core(qkv, B, T, H, scale):
+    """softmax(q k^T * scale) v per (sample, head) on qkv rows (B*T, 3*H*64)."""
+    return _Attention.apply(qkv, B, T, H, scale)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        h = torch.empty_like(z)
+        _lib.call('pdae_gelu_forward', z, z.numel(), _lib.ptr(z), _lib.ptr(h))
+        ctx.save_for_backward(z)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (z,) = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        _lib.call('pdae_gelu_backward', z, z.numel(), _lib.ptr(z), _lib.ptr(dh.contiguous()), _lib.ptr(dz))
+        return dz
+
+
+def gelu(z):
+    return _Gelu.apply(z)
+
+
+class _ScaleResidual(torch.autograd.Function):
+    """y = res + keep[b] * (a + bias): Linear bias + DropPath + residual add."""
+
+    @staticmethod
+    def forward(ctx, a, bias, keep, res, T):
+        a = a.contiguous()
+        M, C = a.shape
+        y = torch.empty_like(a)
+        _lib.call('pdae_scale_residual', a, M, C, T, _lib.ptr(a), _lib.ptr(bias), _lib.ptr(keep),
+                  _lib.ptr(res.contiguous()), _lib.ptr(y))
+        ctx.save_for_backward(keep)
+        ctx.T = T
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, C = dy.shape
+        if keep is not None:
+            da = torch.empty_like(dy)
+            _lib.call('pdae_scale_residual', dy, M, C, ctx.T, _lib.ptr(dy), None, _lib.ptr(keep), None,
+                      _lib.ptr(da))
+        else:
+            da = dy
+        dbias = _colsum(da) if ctx.has_bias else None
+        return da, dbias, None, dy, None
+
+
+def drop_path_keep(B, drop_prob, training, like):
+    """timm 0.4.5 DropPath as a per-sample factor: floor(keep + U[0,1)) / keep
+    (None when the path is always kept)."""
+    if drop_prob == 0. or not training:
+        return None
+    keep = 1 - drop_prob
+    r = keep + torch.rand((B,), dtype=like.dtype, device=like.device)
+    return r.floor_().div_(keep)
+
+
 def linear(x, lin, act=None):
+    """Plain nn.Linear on rows -> BLAS library GEMM (bias in its epilogue)."""
     y = F.linear(x, lin.weight, lin.bias)
     if act == 'gelu':
-        y = F.gelu(y)
+        y = gelu(y)
     elif act == 'relu':
         y = F.relu(y)
     return y
@@ -27,41 +174,21 @@ def conv1x1(x_rows, conv):
     return F.linear(x_rows, conv.weight.squeeze(-1), conv.bias)
 
 
-def layer_norm(x, ln):
-    return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
-
-
 def pos_embed(xyz_rows, seq):
     """Linear(3,128) -> GELU -> Linear(128,C) (PointCAE_transformer.py:329-333)."""
     return linear(linear(xyz_rows, seq[0], 'gelu'), seq[2])
 
 
-def drop_path(x, B, drop_prob, training):
-    """timm 0.4.5 DropPath: per-sample keep mask, x / keep * floor(keep + U)."""
-    if drop_prob == 0. or not training:
-        return x
-    keep = 1 - drop_prob
-    r = keep + torch.rand((B, 1, 1), dtype=x.dtype, device=x.device)
-    r.floor_()
-    rows = x.shape[0] // B
-    return (x.reshape(B, rows, -1).div(keep) * r).reshape(x.shape)
-
-
-def attention(x, B, T, attn):
-    """softmax(q k^T * scale) v with 6 heads of 64 (Attention.forward :125-137);
-    x: (B*T, C) rows."""
-    C = x.shape[-1]
-    H = attn.num_heads
-    qkv = F.linear(x, attn.qkv.weight, attn.qkv.bias).reshape(B, T, 3, H, C // H).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0], qkv[1], qkv[2]
-    a = ((q @ k.transpose(-2, -1)) * attn.scale).softmax(dim=-1)
-    o = (a @ v).transpose(1, 2).reshape(B * T, C)
-    return F.linear(o, attn.proj.weight, attn.proj.bias)
-
-
 def transformer_block(x, pos, B, T, blk, training):
-    """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))."""
-    x = x + pos
-    x = x + drop_path(attention(layer_norm(x, blk.norm1), B, T, blk.attn), B, blk.drop_prob, training)
-    h = linear(layer_norm(x, blk.norm2), blk.mlp.fc1, 'gelu')
-    return x + drop_path(linear(h, blk.mlp.fc2), B, blk.drop_prob, training)
+    """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
+    (PointCAE_transformer.py:155-158, :174-177) in 11 launches."""
+    attn = blk.attn
+    x1, n1 = add_layer_norm(x, pos, blk.norm1)
+    qkv = F.linear(n1, attn.qkv.weight, attn.qkv.bias)
+    o = attention_core(qkv, B, T, attn.num_heads, attn.scale)
+    keep1 = drop_path_keep(B, blk.drop_prob, training, x)
+    x2 = _ScaleResidual.apply(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T)
+    n2 = layer_norm(x2, blk.norm2)
+    h = gelu(F.linear(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+    keep2 = drop_path_keep(B, blk.drop_prob, training, x)
+    return _ScaleResidual.apply(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)

@@ -204,13 +204,18 @@ class MaskTransformer(nn.Module):
         self.num_mask = int(self.mask_ratio * G)
         return mask
 
-    def forward(self, neighborhood, center, noaug=False, mask=None):
-        """-> x_vis rows (B*Tvis, C), host bool mask (B,G), (vis_rows, mask_rows) on device."""
+    def forward(self, neighborhood, center, noaug=False, mask=None, rows=None):
+        """-> x_vis rows (B*Tvis, C), host bool mask (B,G), (vis_rows, mask_rows) on device.
+        `rows` = (vis_rows, mask_rows) already on the device skips the host-side
+        mask draw (hipGraph replay: nothing on this path may touch the host)."""
         tokens = self.encoder(neighborhood)                    # every group is embedded (:437)
         B, G, C = tokens.shape
-        if mask is None:
-            mask = self._mask_center_rand(center, noaug=noaug)
-        vis_rows, mask_rows = (r.to(tokens.device) for r in mask_row_ids(mask.cpu()))
+        if rows is not None:
+            vis_rows, mask_rows = rows
+        else:
+            if mask is None:
+                mask = self._mask_center_rand(center, noaug=noaug)
+            vis_rows, mask_rows = (r.to(tokens.device) for r in mask_row_ids(mask.cpu()))
         Tvis = vis_rows.numel() // B
         x_vis = tokens.reshape(B * G, C).index_select(0, vis_rows)
         pos = nn_ops.pos_embed(center.reshape(B * G, 3).index_select(0, vis_rows), self.pos_embed)
@@ -252,7 +257,7 @@ class PointCAE_transformer(nn.Module):
         else:
             raise NotImplementedError(loss_type)
 
-    def forward(self, corrupted_pts, pts, vis=False, mask=None, steps=None, capture=None, **kwargs):
+    def forward(self, corrupted_pts, pts, vis=False, mask=None, steps=None, capture=None, rows=None, **kwargs):
         """`corrupted_pts` is ignored on this path, as in the reference (:676).
         `mask` (B,G) bool and `steps` (nsteps,B,10) inject the random draws
         (parity tests); by default they come from the host RNGs like the
@@ -264,7 +269,7 @@ class PointCAE_transformer(nn.Module):
             steps = draw_corruption(self.corrupt_type, B)
         gt_nb, t_nb, t_c = corrupt_patches(neighborhood, center, steps)
 
-        x_vis, mask, (vis_rows, mask_rows) = self.MAE_encoder(t_nb, t_c, mask=mask)
+        x_vis, mask, (vis_rows, mask_rows) = self.MAE_encoder(t_nb, t_c, mask=mask, rows=rows)
         C = x_vis.shape[-1]
         G = self.num_group
         Tvis = vis_rows.numel() // B

@@ -1,0 +1,114 @@
+"""GPU numerics of the Transformer-block kernels (attention core, LayerNorm with
+fused adds, GELU, bias+DropPath+residual) against plain PyTorch fp32 / fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    scale = b.abs().max().item() + 1e-12
+    err = (a.double() - b.double()).abs().max().item() / scale
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize('B,T,H', [(128, 23, 6), (64, 64, 6), (8, 13, 6), (5, 32, 2), (3, 100, 6), (2, 128, 6), (7, 1, 3)])
+def test_attention_forward_backward(B, T, H):
+    from point_dae_amd import nn_ops
+    D, scale = 64, 64 ** -0.5
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + T)
+    qkv = torch.randn(B * T, 3 * H * D, device='cuda', generator=g, requires_grad=True)
+    go = torch.randn(B * T, H * D, device='cuda', generator=g)
+    o = nn_ops.attention_core(qkv, B, T, H, scale)
+    o.backward(go)
+    q64 = qkv.detach().double().requires_grad_(True)
+    t = q64.reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    a = ((t[0] @ t[1].transpose(-2, -1)) * scale).softmax(dim=-1)
+    ref = (a @ t[2]).transpose(1, 2).reshape(B * T, H * D)
+    ref.backward(go.double())
+    _close(o, ref, 2e-6)
+    _close(qkv.grad, q64.grad, 5e-6)
+
+
+@pytest.mark.parametrize('M,C', [(2944, 384), (8192, 384), (37, 128), (100, 2048), (5, 4)])
+@pytest.mark.parametrize('with_pos', [True, False])
+def test_add_layernorm(M, C, with_pos):
+    from point_dae_amd import nn_ops
+    ln = torch.nn.LayerNorm(C).cuda()
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.normal_()
+    x = torch.randn(M, C, device='cuda', requires_grad=True)
+    pos = torch.randn(M, C, device='cuda', requires_grad=True) if with_pos else None
+    gs, gy = torch.randn(M, C, device='cuda'), torch.randn(M, C, device='cuda')
+    s, y = nn_ops.add_layer_norm(x, pos, ln)
+    (s * gs).sum().backward(retain_graph=True) if with_pos else None
+    (y * gy).sum().backward()
+    got = [x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()] + ([pos.grad.clone()] if with_pos else [])
+    x64 = x.detach().double().requires_grad_(True)
+    p64 = pos.detach().double().requires_grad_(True) if with_pos else None
+    ln64 = torch.nn.LayerNorm(C).cuda().double()
+    ln64.load_state_dict(ln.state_dict())
+    s64 = x64 + p64 if with_pos else x64
+    y64 = ln64(s64)
+    loss = (y64 * gy.double()).sum() + ((s64 * gs.double()).sum() if with_pos else 0)
+    loss.backward()
+    _close(y, y64, 2e-6)
+    _close(s, s64, 1e-6)
+    want = [x64.grad, ln64.weight.grad, ln64.bias.grad] + ([p64.grad] if with_pos else [])
+    for a, b in zip(got, want):
+        _close(a, b, 2e-5)
+
+
+def test_gelu_and_scale_residual():
+    from point_dae_amd import nn_ops
+    z = torch.randn(8192, 1536, device='cuda', requires_grad=True)
+    gh = torch.randn_like(z)
+    h = nn_ops.gelu(z)
+    h.backward(gh)
+    z64 = z.detach().double().requires_grad_(True)
+    F.gelu(z64).backward(gh.double())
+    _close(h, F.gelu(z64), 1e-6)
+    _close(z.grad, z64.grad, 2e-6)
+    B, T, C = 16, 23, 384
+    a = torch.randn(B * T, C, device='cuda', requires_grad=True)
+    bias = torch.randn(C, device='cuda', requires_grad=True)
+    res = torch.randn(B * T, C, device='cuda', requires_grad=True)
+    keep = (torch.rand(B, device='cuda') > 0.3).float() / 0.7
+    gy = torch.randn(B * T, C, device='cuda')
+    for kp in (keep, None):
+        for t in (a, bias, res):
+            t.grad = None
+        y = nn_ops._ScaleResidual.apply(a, bias, kp, res, T)
+        y.backward(gy)
+        k = kp.repeat_interleave(T).unsqueeze(1) if kp is not None else 1.0
+        ref = res + k * (a + bias)
+        _close(y, ref.detach(), 1e-6)
+        _close(a.grad, (gy * k), 1e-6)
+        _close(res.grad, gy, 0)
+        _close(bias.grad, (gy * k).double().sum(0), 1e-5)
+
+
+def test_transformer_block_matches_pytorch():
+    """nn_ops.transformer_block against the reference composition (oracle/model.py Block)."""
+    from oracle.model import Block as RefBlock
+    from point_dae_amd import nn_ops
+    from point_dae_amd.point_cae_transformer import Block
+    torch.manual_seed(0)
+    B, T, C = 32, 23, 384
+    ref = RefBlock(C, 6, 0.0).cuda().double()
+    mine = Block(C, 6, 0.0).cuda()
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = torch.randn(B * T, C, device='cuda', requires_grad=True)
+    pos = torch.randn(B * T, C, device='cuda', requires_grad=True)
+    gy = torch.randn(B * T, C, device='cuda')
+    y = mine(x, pos, B, T)
+    y.backward(gy)
+    x64, p64 = x.detach().double().requires_grad_(True), pos.detach().double().requires_grad_(True)
+    y64 = ref((x64 + p64).reshape(B, T, C)).reshape(B * T, C)
+    y64.backward(gy.double())
+    _close(y, y64, 5e-6)
+    _close(x.grad, x64.grad, 2e-5)
+    _close(pos.grad, p64.grad, 2e-5)
+    for (n, a), (_, b) in zip(sorted(mine.named_parameters()), sorted(ref.named_parameters())):
+        _close(a.grad, b.grad, 5e-5)
