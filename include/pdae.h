@@ -310,6 +310,18 @@ int pdae_scale_residual(int M, int C, int T, const float* a,
                         pdae_stream_t stream);
 int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused AdamW over a contiguous fp32 range (torch.optim.AdamW arithmetic:
+ * decoupled weight decay, bias correction, eps added to sqrt(v_hat)); the
+ * reference builds it over two parameter groups, tools/builder.py:41-101.
+ * step is the 1-based update count.  One streaming pass: 16 B read + 12 B
+ * written per parameter.
+ */
+int pdae_adamw_step(long long n, float* param, const float* grad,
+                    float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step,
+                    pdae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

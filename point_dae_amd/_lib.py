@@ -47,6 +47,7 @@ _SIGNATURES = {
     "pdae_gelu_backward": [ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_colsum": [_i, _i, _vp, _vp, _vp],
+    "pdae_adamw_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

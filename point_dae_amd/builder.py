@@ -96,8 +96,14 @@ def build_opti_sche(base_model, config):
     oc = config.optimizer
     if oc.type != 'AdamW':
         raise NotImplementedError(oc.type)
-    groups = add_weight_decay(base_model, oc.kwargs.weight_decay, part=oc.get('part', 'all'), lr=oc.kwargs.lr)
-    optimizer = torch.optim.AdamW(groups, **oc.kwargs)
+    from .data_parallel import FlatDataParallel
+    if (isinstance(base_model, FlatDataParallel) and base_model.flat_param.is_cuda
+            and oc.get('part', 'all') == 'all'):
+        from .optim import FlatAdamW            # two fused launches over the flat buffers
+        optimizer = FlatAdamW(base_model, **oc.kwargs)
+    else:
+        groups = add_weight_decay(base_model, oc.kwargs.weight_decay, part=oc.get('part', 'all'), lr=oc.kwargs.lr)
+        optimizer = torch.optim.AdamW(groups, **oc.kwargs)
     sc = config.scheduler
     kw = sc.kwargs
     if sc.type == 'CosLR':

@@ -205,20 +205,28 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(long long n4, int C
   y[i] = v;
 }
 
+// out[c] += sum over a slab of rows; lane owns 4 adjacent columns, 4 waves stride the rows
 __global__ __launch_bounds__(256) void colsum2_kernel(int M, int N, const float* __restrict__ X,
                                                       float* __restrict__ out, int rows_per_split) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
   const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
-  float s = 0.f;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N)
-    for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * N + c];
-  part[w][threadIdx.x & 63] = s;
+    for (int m = mbeg + w; m < mend; m += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(X + (size_t)m * N + c);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  part[w][lane] = s;
   __syncthreads();
-  if (w == 0 && c < N)
-    atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
-                           part[3][threadIdx.x]);
+  if (w == 0 && c < N) {
+    const float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
+    atomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
+    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
+    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
+    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
+  }
 }
 
 }  // namespace pdae
@@ -292,15 +300,15 @@ extern "C" int pdae_scale_residual(int M, int C, int T, const float* a, const fl
 }
 
 extern "C" int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream) {
-  if (M < 0 || N <= 0) return bad_arg("colsum: bad size");
+  if (M < 0 || N <= 0 || N % 4 != 0) return bad_arg("colsum: N must be a positive multiple of 4");
   if (!out) return bad_arg("colsum: null pointer");
   hipStream_t s = as_stream(stream);
   (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("colsum");
   if (!X) return bad_arg("colsum: null pointer");
-  int bs = (M + 511) / 512;
-  if (bs > 2048) bs = 2048;
+  int bs = (M + 63) / 64;
+  if (bs > 1024) bs = 1024;
   const int rows = (M + bs - 1) / bs;
-  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 63) / 64, bs), dim3(256), 0, s, M, N, X, out, rows);
+  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 255) / 256, bs), dim3(256), 0, s, M, N, X, out, rows);
   return check_launch("colsum");
 }

@@ -40,19 +40,25 @@ class FlatDataParallel(nn.Module):
         params = [p for _, p in nd + wd]
         dev, dt = params[0].device, params[0].dtype
         sizes = [p.numel() for p in params]
-        total = sum(sizes)
-        self.flat_param = torch.empty(total, device=dev, dtype=dt)
-        self.flat_grad = torch.zeros(total, device=dev, dtype=dt)
         self.no_decay_numel = sum(p.numel() for _, p in nd)
+        pad = (-self.no_decay_numel) % 64          # decay range starts 256-byte aligned
+        total = sum(sizes) + pad
+        self.flat_param = torch.zeros(total, device=dev, dtype=dt)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=dt)
+        self.no_decay_range = (0, self.no_decay_numel)
+        self.decay_range = (self.no_decay_numel + pad, total)
         self.offsets = []
         off = 0
-        for p, n in zip(params, sizes):
+        for i, (p, n) in enumerate(zip(params, sizes)):
+            if i == len(nd):
+                off += pad
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             p.grad = self.flat_grad[off:off + n].view_as(p)
             self.offsets.append((off, n))
             off += n
         self.params = params
+        self.grad_views = [p.grad for p in params]
         if self.world_size > 1 and broadcast:
             dist.broadcast(self.flat_param, src=0, group=process_group)
             for b in module.buffers():
@@ -118,10 +124,9 @@ class FlatDataParallel(nn.Module):
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
-        for i, p in enumerate(self.params):
-            if p.grad is None:
-                off, n = self.offsets[i]
-                p.grad = self.flat_grad[off:off + n].view_as(p)
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is not v:
+                p.grad = v
 
     def param_groups(self, weight_decay):
         """The two AdamW groups of the reference over the flat ranges."""

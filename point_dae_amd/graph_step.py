@@ -66,10 +66,21 @@ class GraphedTrainStep:
     def _fwd_bwd(self, tvis):
         nv = self.B * tvis
         nm = self.B * (self.G - tvis)
-        self.model.flat_grad.zero_()
-        lx, ln = self.model(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+        # gradients are produced as fresh tensors (autograd ASSIGNS them: no 203
+        # accumulate-add launches, no memset of the flat buffer) and gathered into
+        # the flat gradient buffer with one multi-tensor copy
+        m = self.model
+        for p in m.params:
+            p.grad = None
+        lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
         loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
         loss.backward()
+        have = [(v, p.grad) for p, v in zip(m.params, m.grad_views) if p.grad is not None]
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for p, v in zip(m.params, m.grad_views):
+            if p.grad is None:
+                v.zero_()
+            p.grad = v
         return lx.detach(), ln.detach()
 
     def _capture(self, tvis):

@@ -112,3 +112,31 @@ def test_transformer_block_matches_pytorch():
     _close(pos.grad, p64.grad, 2e-5)
     for (n, a), (_, b) in zip(sorted(mine.named_parameters()), sorted(ref.named_parameters())):
         _close(a.grad, b.grad, 5e-5)
+
+
+def test_flat_adamw_matches_torch():
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.optim import FlatAdamW
+    import copy
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.LayerNorm(64), torch.nn.Linear(64, 13)).cuda()
+    ref = copy.deepcopy(net)
+    model = FlatDataParallel(net)
+    opt = FlatAdamW(model, lr=1e-2, weight_decay=0.05)
+    decay = [p for n, p in ref.named_parameters() if p.dim() > 1]
+    no_decay = [p for n, p in ref.named_parameters() if p.dim() <= 1]
+    ropt = torch.optim.AdamW([{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': 0.05}], lr=1e-2)
+    for step in range(5):
+        x = torch.randn(16, 37, device='cuda')
+        for mdl, o in ((model, opt), (ref, ropt)):
+            loss = (mdl(x) ** 2).mean()
+            loss.backward()
+            o.step()
+            o.zero_grad()
+        if step == 2:
+            for g in opt.param_groups + ropt.param_groups:
+                g['lr'] = 3e-3
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+    sd = opt.state_dict()
+    assert sd['state']['step'] == 5 and len(sd['param_groups']) == 2
