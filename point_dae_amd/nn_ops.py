@@ -149,14 +149,22 @@ class _ScaleResidual(torch.autograd.Function):
         return da, dbias, None, dy, None
 
 
-def drop_path_keep(B, drop_prob, training, like):
-    """timm 0.4.5 DropPath as a per-sample factor: floor(keep + U[0,1)) / keep
-    (None when the path is always kept)."""
-    if drop_prob == 0. or not training:
-        return None
-    keep = 1 - drop_prob
-    r = keep + torch.rand((B,), dtype=like.dtype, device=like.device)
-    return r.floor_().div_(keep)
+def drop_path_keep_buffer(drop_probs):
+    """(2*depth, 1) keep probabilities, one row per stochastic-depth site."""
+    return torch.tensor([1.0 - p for p in drop_probs for _ in range(2)], dtype=torch.float32).unsqueeze(1)
+
+
+def draw_drop_path(B, drop_probs, training, keep):
+    """timm 0.4.5 DropPath for a whole stack of blocks at once: every block has
+    two stochastic-depth sites (after attention, after the MLP), each keeping a
+    sample with probability 1-p and scaling it by 1/(1-p).  The reference draws
+    torch.rand((B,1,1)) at each of the 2*depth sites; here all sites of a stack
+    come from ONE torch.rand launch.  -> list of (keep_attn, keep_mlp) per block,
+    None where p == 0.  `keep` is drop_path_keep_buffer(drop_probs) on the device."""
+    if not training or all(p == 0. for p in drop_probs):
+        return [(None, None)] * len(drop_probs)
+    r = (torch.rand((2 * len(drop_probs), B), dtype=keep.dtype, device=keep.device) + keep).floor_() / keep
+    return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(drop_probs)]
 
 
 def linear(x, lin, act=None):
@@ -179,16 +187,16 @@ def pos_embed(xyz_rows, seq):
     return linear(linear(xyz_rows, seq[0], 'gelu'), seq[2])
 
 
-def transformer_block(x, pos, B, T, blk, training):
+def transformer_block(x, pos, B, T, blk, keeps):
     """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
-    (PointCAE_transformer.py:155-158, :174-177) in 11 launches."""
+    (PointCAE_transformer.py:155-158, :174-177) in 11 launches.  `keeps` =
+    (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path."""
     attn = blk.attn
     x1, n1 = add_layer_norm(x, pos, blk.norm1)
     qkv = F.linear(n1, attn.qkv.weight, attn.qkv.bias)
     o = attention_core(qkv, B, T, attn.num_heads, attn.scale)
-    keep1 = drop_path_keep(B, blk.drop_prob, training, x)
+    keep1, keep2 = keeps
     x2 = _ScaleResidual.apply(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T)
     n2 = layer_norm(x2, blk.norm2)
     h = gelu(F.linear(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-    keep2 = drop_path_keep(B, blk.drop_prob, training, x)
     return _ScaleResidual.apply(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)

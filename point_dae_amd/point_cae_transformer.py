@@ -93,19 +93,25 @@ class Block(nn.Module):
         self.attn = Attention(dim, num_heads)
         self.drop_prob = float(drop_path)
 
-    def forward(self, x, pos, B, T):
+    def forward(self, x, pos, B, T, keeps=(None, None)):
         """x, pos: (B*T, C) rows; computes block(x + pos)."""
-        return nn_ops.transformer_block(x, pos, B, T, self, self.training)
+        return nn_ops.transformer_block(x, pos, B, T, self, keeps)
+
+
+def _stack_keeps(stack, B):
+    return nn_ops.draw_drop_path(B, [blk.drop_prob for blk in stack.blocks], stack.training, stack.dp_keep)
 
 
 class TransformerEncoder(nn.Module):
     def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
         super().__init__()
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+        self.register_buffer('dp_keep', nn_ops.drop_path_keep_buffer(drop_path_rate[:depth]), persistent=False)
 
     def forward(self, x, pos, B, T):
-        for blk in self.blocks:        # position re-added before EVERY block (:174-177)
-            x = blk(x, pos, B, T)
+        keeps = _stack_keeps(self, B)
+        for blk, k in zip(self.blocks, keeps):   # position re-added before EVERY block (:174-177)
+            x = blk(x, pos, B, T, k)
         return x
 
 
@@ -113,6 +119,7 @@ class TransformerDecoder(nn.Module):
     def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
         super().__init__()
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, drop_path_rate[i]) for i in range(depth)])
+        self.register_buffer('dp_keep', nn_ops.drop_path_keep_buffer(drop_path_rate[:depth]), persistent=False)
         self.norm = nn.LayerNorm(embed_dim)
         self.head = nn.Identity()
         self.apply(self._init_weights)
@@ -128,8 +135,9 @@ class TransformerDecoder(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, x, pos, B, T, return_token_num=-1):
-        for blk in self.blocks:
-            x = blk(x, pos, B, T)
+        keeps = _stack_keeps(self, B)
+        for blk, k in zip(self.blocks, keeps):
+            x = blk(x, pos, B, T, k)
         C = x.shape[-1]
         if return_token_num != -1:     # the masked tokens sit last in every sample (:229-231)
             x = x.reshape(B, T, C)[:, -return_token_num:].reshape(-1, C)

@@ -102,7 +102,7 @@ def test_transformer_block_matches_pytorch():
     x = torch.randn(B * T, C, device='cuda', requires_grad=True)
     pos = torch.randn(B * T, C, device='cuda', requires_grad=True)
     gy = torch.randn(B * T, C, device='cuda')
-    y = mine(x, pos, B, T)
+    y = mine(x, pos, B, T, (None, None))
     y.backward(gy)
     x64, p64 = x.detach().double().requires_grad_(True), pos.detach().double().requires_grad_(True)
     y64 = ref((x64 + p64).reshape(B, T, C)).reshape(B * T, C)

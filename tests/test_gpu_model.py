@@ -44,7 +44,7 @@ def test_product_model_reproduces_reference_fixture(name):
     worst = check_grads(model, fx, 2e-3, name)
     print('worst grad err', worst)
     for bname, b in model.named_buffers():
-        if b.dtype.is_floating_point:
+        if b.dtype.is_floating_point and 'buf/' + bname in fx:      # BatchNorm running statistics
             _close(b, fx['buf/' + bname], 1e-4, bname)
 
 
