@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 CFG3 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'
+CFG2 = 'cfgs/pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 HBM_PEAK_GBS = 8000.0
 
@@ -43,7 +44,7 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--workload', default='cfg3', choices=['cfg3'])
+    p.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg2'])
     p.add_argument('--batch', type=int, default=128, help='clouds per GPU')
     p.add_argument('--npoints', type=int, default=1024)
     p.add_argument('--num_group', type=int, default=64)
@@ -117,13 +118,15 @@ def main():
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.misc import set_random_seed
-    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.graph_step import GraphedStaticStep, GraphedTrainStep
     from point_dae_amd.runner_pretrain import train_step
     from point_dae_amd.synthetic import shapenet_like_clouds
 
-    config = cfg_from_yaml_file(os.path.join(ROOT, CFG3))
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG3 if args.workload == 'cfg3' else CFG2))
     config.npoints = args.npoints
     config.model.num_group = args.num_group
+    if args.workload == 'cfg2':
+        args.no_cpu_baseline = True         # the cpu_baseline leg times the cfg3 oracle model
     set_random_seed(0 + rank)
     model = FlatDataParallel(builder.model_builder(config.model).to(device))
     optimizer, _ = builder.build_opti_sche(model, config)
@@ -134,7 +137,15 @@ def main():
     clouds = torch.from_numpy(shapenet_like_clouds(args.batch * pool, args.npoints, seed=100 + rank)).to(device)
     batches = list(clouds.split(args.batch))
 
-    if args.eager:
+    if args.workload == 'cfg2':
+        # Point_CAE_PointNetv2: corrupted input = another cloud of the pool (the reference corrupts in the
+        # data loader); loss mix 'xyznormal_gradual' at mid-training (gradual weight 0.5)
+        gstep = GraphedStaticStep(model, optimizer, lambda a, b: a + float(config.normal_weight) * b * 0.5,
+                                  args.batch, args.npoints)
+
+        def step(x):
+            return gstep(torch.roll(x, 1, 0), x)
+    elif args.eager:
         def step(x):
             return train_step(model, optimizer, config, x, x)
     else:
@@ -166,7 +177,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe_mode = 'HIP events around every launch of the kernel inside the timed region (eager launches)'
-    if not args.eager and rank == 0:
+    if not args.eager and rank == 0 and args.workload == 'cfg3':
         # hipGraph replay hides individual launches from host-recorded events, so
         # the dominant kernel is timed with HIP events on its launch stream over
         # `probe_steps` eager optimisation steps of the same workload, run right
@@ -207,7 +218,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
+            'config': {'workload': ('cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
+                                    if args.workload == 'cfg3' else
+                                    'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2) ') +
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
                        'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
                        'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay'},

@@ -358,3 +358,115 @@ class PointCAE_transformer(nn.Module):
             capture.update(center=center, neighborhood=neighborhood, t_nb=t_nb, t_c=t_c, mask=mask,
                            x_vis=x_vis, x_rec=x_rec, rebuild=rebuild, gt=gt)
         return loss1, torch.zeros(1)
+
+
+# ======================================================================
+# Point_CAE_PointNetv2 (BASELINE configs 1-2): models/PointCAE_pointnetv2.py
+# :61-173 with the PointNet++ encoder of models/pointnetv2_util.py:319-346.
+# The set-abstraction module is third-party pointnet2_ops; its vendored twin
+# (extensions/pointnet2/pointnet2_modules.py:31-72,124-158, pytorch_utils.py
+# SharedMLP) gives the parameter names used here.
+# ======================================================================
+def _fps_gather(xyz, npoint):
+    idx, ctr = O.furthest_point_sample(_np(xyz), npoint, return_centres=True)
+    return torch.from_numpy(ctr)
+
+
+def _ball_query(radius, nsample, xyz, new_xyz):
+    return torch.from_numpy(O.ball_query(radius, nsample, _np(xyz), _np(new_xyz)))
+
+
+class _ConvBN(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module('conv', nn.Conv2d(cin, cout, kernel_size=(1, 1), bias=False))
+        bn = nn.Sequential()
+        bn.add_module('bn', nn.BatchNorm2d(cout))
+        self.add_module('bn', bn)
+        self.add_module('activation', nn.ReLU(inplace=True))
+        nn.init.kaiming_normal_(self.conv.weight)
+
+
+class _SharedMLP(nn.Sequential):
+    def __init__(self, spec):
+        super().__init__()
+        for i in range(len(spec) - 1):
+            self.add_module('layer{}'.format(i), _ConvBN(spec[i], spec[i + 1]))
+
+
+class SAModule(nn.Module):
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        spec = list(mlp)
+        spec[0] += 3                                   # use_xyz=True
+        self.mlps = nn.ModuleList([_SharedMLP(spec)])
+
+    def forward(self, xyz, features=None):
+        if self.npoint is not None:
+            new_xyz = _fps_gather(xyz, self.npoint)
+            idx = _ball_query(self.radius, self.nsample, xyz, new_xyz)
+            grouped = _Grouping.apply(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+            if features is not None:
+                grouped = torch.cat([grouped, _Grouping.apply(features, idx)], dim=1)
+        else:
+            new_xyz = None
+            grouped = xyz.transpose(1, 2).unsqueeze(2)
+            if features is not None:
+                grouped = torch.cat([grouped, features.unsqueeze(2)], dim=1)
+        f = self.mlps[0](grouped)
+        f = F.max_pool2d(f, kernel_size=[1, f.size(3)]).squeeze(-1)
+        return new_xyz, f
+
+
+class PointNetv2_encoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.sa1 = SAModule(npoint=512, radius=0.2, nsample=32, mlp=[0, 64, 64, 128])
+        self.sa2 = SAModule(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256])
+        self.sa3 = SAModule(mlp=[256, 256, 512, 1024])
+
+    def forward(self, xyz):
+        l1_xyz, l1 = self.sa1(xyz, None)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        _, l3 = self.sa3(l2_xyz, l2)
+        return l3.view(xyz.shape[0], 1024)
+
+
+class Point_CAE_PointNetv2(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.corrupt_type = config.corrupt_type
+        self.grid_size, self.grid_scale, self.num_coarse = 4, 0.05, 1024
+        self.num_fine = self.grid_size ** 2 * self.num_coarse
+        self.pointnetv2_encoder = PointNetv2_encoder()
+        self.folding1 = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024), nn.ReLU(),
+                                      nn.Linear(1024, self.num_coarse * 3))
+        self.folding2 = nn.Sequential(nn.Conv1d(1024 + 2 + 3, 512, 1), nn.ReLU(), nn.Conv1d(512, 512, 1), nn.ReLU(),
+                                      nn.Conv1d(512, 3, 1))
+        self.loss_func = {'cdl1': chamfer_l1, 'cdl2': chamfer_l2}[config.loss]
+
+    def build_grid(self, batch_size):
+        import itertools
+        x = np.linspace(-self.grid_scale, self.grid_scale, self.grid_size)
+        pts = np.array(list(itertools.product(x, x)))
+        return torch.tensor(np.repeat(pts[np.newaxis, ...], batch_size, axis=0)).float()
+
+    def forward(self, corrupted_pts, pts, capture=None, **kwargs):
+        corrupted_pts = corrupted_pts[:, :, :3].contiguous()
+        pts = pts[:, :, :3].contiguous()
+        for item in self.corrupt_type:                 # only the CUDA-side dropouts act here (:144-149)
+            if item in ('dropout_patch_pointmae', 'dropout_global'):
+                raise NotImplementedError(item)
+        feature = self.pointnetv2_encoder(corrupted_pts)
+        B = pts.shape[0]
+        coarse = self.folding1(feature).view(-1, self.num_coarse, 3)
+        g2 = self.grid_size ** 2
+        grid_feat = self.build_grid(B).repeat(1, self.num_coarse, 1)
+        point_feat = coarse.repeat_interleave(g2, dim=1)
+        global_feat = feature.unsqueeze(1).expand(-1, self.num_fine, -1)
+        feat = torch.cat([grid_feat, point_feat, global_feat], dim=2)
+        fine = self.folding2(feat.transpose(2, 1)).transpose(2, 1) + point_feat
+        if capture is not None:
+            capture.update(feature=feature, coarse=coarse, fine=fine)
+        return self.loss_func(coarse, pts), self.loss_func(fine, pts)

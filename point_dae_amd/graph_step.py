@@ -120,3 +120,59 @@ class GraphedTrainStep:
             self.model.flat_grad.div_(self.model.world_size)
         self.optimizer.step()
         return out
+
+
+class GraphedStaticStep:
+    """Same idea for models whose step has static shapes and no host-side random
+    draws (Point_CAE_PointNetv2: the corruption is applied by the data loader):
+    ONE captured forward+loss+backward graph, replayed every step."""
+
+    def __init__(self, model, optimizer, loss_mix, batch_size, npoints, warmup_eager=2):
+        assert isinstance(model, FlatDataParallel)
+        self.model, self.optimizer, self.loss_mix = model, optimizer, loss_mix
+        dev = model.flat_param.device
+        self.corrupted = torch.zeros(batch_size, npoints, 3, device=dev)
+        self.clean = torch.zeros(batch_size, npoints, 3, device=dev)
+        self.graph, self.out = None, None
+        self.eager_left = warmup_eager
+
+    def _fwd_bwd(self):
+        m = self.model
+        for p in m.params:
+            p.grad = None
+        l1, l2 = m(self.corrupted, self.clean)
+        self.loss_mix(l1, l2).backward()
+        have = [(v, p.grad) for p, v in zip(m.params, m.grad_views) if p.grad is not None]
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for p, v in zip(m.params, m.grad_views):
+            if p.grad is None:
+                v.zero_()
+            p.grad = v
+        return l1.detach(), l2.detach()
+
+    def __call__(self, corrupted, clean):
+        self.corrupted.copy_(corrupted[:, :, :3], non_blocking=True)
+        self.clean.copy_(clean[:, :, :3], non_blocking=True)
+        sync = self.model.require_sync
+        self.model.require_sync = False
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            out = self._fwd_bwd()
+        else:
+            if self.graph is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._fwd_bwd()
+                torch.cuda.current_stream().wait_stream(side)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = self._fwd_bwd()
+            self.graph.replay()
+            out = self.out
+        self.model.require_sync = sync
+        if self.model.world_size > 1:
+            torch.distributed.all_reduce(self.model.flat_grad, group=self.model.process_group)
+            self.model.flat_grad.div_(self.model.world_size)
+        self.optimizer.step()
+        return out

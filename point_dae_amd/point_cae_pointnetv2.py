@@ -1,0 +1,159 @@
+"""PointNet++ denoising auto-encoder (BASELINE configs 1-2), MI355X host side.
+
+Reference: models/PointCAE_pointnetv2.py:61-173 (`Point_CAE_PointNetv2`) with the
+encoder of models/pointnetv2_util.py:319-346; the set-abstraction module is the
+third-party pointnet2_ops `PointnetSAModule`, whose vendored twin
+(extensions/pointnet2/pointnet2_modules.py:31-72,124-158, pytorch_utils.py)
+gives the parameter names kept here (`...mlps.0.layer{i}.conv.weight`,
+`...layer{i}.bn.bn.weight`).
+
+    model(corrupted_pts, pts) -> (loss_coarse, loss_fine)
+
+Data path on MI355X: FPS+centre gather, ball query and the Chamfer losses are the
+gfx950 kernels; activations are rows (points) x channels, so grouping is a row
+gather and max-pool a reduction over consecutive rows.  folding2's first layer
+is not run on the materialised (B,16384,1029) tensor (67 MB per cloud in the
+reference, :157-163): its weight is split into the grid (2), coarse-point (3) and
+global-feature (1024) column blocks, which are multiplied once per grid cell,
+once per coarse point and once per cloud and added by broadcasting -- the same
+sum, 25.9 -> 8.7 GFLOP per cloud.
+"""
+import itertools
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from .pointnet2_utils import ball_query, furthest_point_sample_with_centres
+from .registry import MODELS
+
+
+class _ConvBN(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module('conv', nn.Conv2d(cin, cout, kernel_size=(1, 1), bias=False))
+        bn = nn.Sequential()
+        bn.add_module('bn', nn.BatchNorm2d(cout))
+        self.add_module('bn', bn)
+        self.add_module('activation', nn.ReLU(inplace=True))
+        nn.init.kaiming_normal_(self.conv.weight)
+
+    def rows(self, x):
+        """(rows, cin) -> relu(bn(conv)) (rows, cout); BatchNorm statistics over the rows."""
+        bn = self.bn.bn
+        y = F.linear(x, self.conv.weight.reshape(self.conv.weight.shape[0], -1))
+        if self.training:
+            bn.num_batches_tracked += 1
+        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training,
+                         bn.momentum, bn.eps)
+        return F.relu(y)
+
+
+class SharedMLP(nn.Sequential):
+    def __init__(self, spec):
+        super().__init__()
+        for i in range(len(spec) - 1):
+            self.add_module('layer{}'.format(i), _ConvBN(spec[i], spec[i + 1]))
+
+
+class PointnetSAModule(nn.Module):
+    """FPS -> ball query -> group (centre-subtracted xyz || features) -> shared MLP -> max."""
+
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None, use_xyz=True):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        spec = list(mlp)
+        if use_xyz:
+            spec[0] += 3
+        self.mlps = nn.ModuleList([SharedMLP(spec)])
+
+    def forward(self, xyz, features=None):
+        """xyz (B,N,3); features rows (B*N, C) or None -> new_xyz (B,np,3), rows (B*np, C')."""
+        B, N, _ = xyz.shape
+        if self.npoint is not None:
+            with torch.no_grad():
+                _, new_xyz = furthest_point_sample_with_centres(xyz, self.npoint)
+                idx = ball_query(self.radius, self.nsample, xyz, new_xyz)          # (B,np,ns) i32
+                flat = (idx.long() + torch.arange(B, device=xyz.device).view(B, 1, 1) * N).reshape(-1)
+            g = xyz.reshape(B * N, 3).index_select(0, flat).reshape(B, self.npoint, self.nsample, 3)
+            g = (g - new_xyz.unsqueeze(2)).reshape(-1, 3)
+            if features is not None:
+                g = torch.cat([g, features.index_select(0, flat)], dim=1)
+            groups, per = B * self.npoint, self.nsample
+        else:
+            new_xyz = None
+            g = xyz.reshape(B * N, 3)
+            if features is not None:
+                g = torch.cat([g, features], dim=1)
+            groups, per = B, N
+        for layer in self.mlps[0]:
+            g = layer.rows(g)
+        return new_xyz, g.reshape(groups, per, -1).max(dim=1)[0]
+
+
+class PointNetv2_encoder(nn.Module):
+    def __init__(self, num_channel=3):
+        super().__init__()
+        self.sa1 = PointnetSAModule(npoint=512, radius=0.2, nsample=32, mlp=[0, 64, 64, 128])
+        self.sa2 = PointnetSAModule(npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 128, 256])
+        self.sa3 = PointnetSAModule(mlp=[256, 256, 512, 1024])
+
+    def forward(self, xyz):
+        l1_xyz, l1 = self.sa1(xyz, None)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        _, l3 = self.sa3(l2_xyz, l2)
+        return l3                                                  # (B, 1024)
+
+
+@MODELS.register_module()
+class Point_CAE_PointNetv2(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.corrupt_type = config.corrupt_type
+        self.grid_size, self.grid_scale, self.num_coarse = 4, 0.05, 1024
+        self.num_fine = self.grid_size ** 2 * self.num_coarse
+        self.pointnetv2_encoder = PointNetv2_encoder()
+        self.folding1 = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024), nn.ReLU(),
+                                      nn.Linear(1024, self.num_coarse * 3))
+        self.folding2 = nn.Sequential(nn.Conv1d(1024 + 2 + 3, 512, 1), nn.ReLU(), nn.Conv1d(512, 512, 1),
+                                      nn.ReLU(), nn.Conv1d(512, 3, 1))
+        x = np.linspace(-self.grid_scale, self.grid_scale, self.grid_size)
+        grid = torch.tensor(np.array(list(itertools.product(x, x)))).float()   # (16, 2), build_grid :94-99
+        self.register_buffer('grid', grid, persistent=False)
+        self.loss = config.loss
+        self.build_loss_func(self.loss)
+
+    def build_loss_func(self, loss_type):
+        if loss_type == 'cdl1':
+            self.loss_func = ChamferDistanceL1()
+        elif loss_type == 'cdl2':
+            self.loss_func = ChamferDistanceL2()
+        else:
+            raise NotImplementedError(loss_type)
+
+    def forward(self, corrupted_pts, pts, vis=False, capture=None, **kwargs):
+        corrupted_pts = corrupted_pts[:, :, :3].contiguous()
+        pts = pts[:, :, :3].contiguous()
+        for item in self.corrupt_type:
+            if item in ('dropout_patch_pointmae', 'dropout_global'):
+                raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
+        B = pts.shape[0]
+        feature = self.pointnetv2_encoder(corrupted_pts)                       # (B, 1024)
+        coarse = self.folding1(feature).view(B, self.num_coarse, 3)
+        # folding2[0] on [grid(2) | coarse point(3) | global feature(1024)], split by column block
+        w = self.folding2[0].weight.squeeze(-1)                                # (512, 1029)
+        g2 = self.grid_size ** 2
+        a = F.linear(feature, w[:, 5:], self.folding2[0].bias)                 # (B, 512)      once per cloud
+        p = F.linear(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
+        gd = F.linear(self.grid, w[:, :2])                                     # (16, 512)     once per grid cell
+        h = F.relu(a.view(B, 1, 1, -1) + p + gd.view(1, 1, g2, -1)).reshape(B * self.num_fine, -1)
+        h = F.relu(F.linear(h, self.folding2[2].weight.squeeze(-1), self.folding2[2].bias))
+        off = F.linear(h, self.folding2[4].weight.squeeze(-1), self.folding2[4].bias)
+        fine = off.reshape(B, self.num_coarse, g2, 3) + coarse.unsqueeze(2)
+        fine = fine.reshape(B, self.num_fine, 3)
+        if capture is not None:
+            capture.update(feature=feature, coarse=coarse, fine=fine)
+        return self.loss_func(coarse, pts), self.loss_func(fine, pts)

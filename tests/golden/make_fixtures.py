@@ -95,9 +95,54 @@ def transformer_fixture(name, B, seed, overrides):
           'size %.0f KB' % (os.path.getsize(path) / 1024))
 
 
+def pointnetv2_fixture(name, B, seed):
+    """BASELINE config 1: pretrain_PointCAE_clean.yaml, Point_CAE_PointNetv2, B=2, N=1024."""
+    from easydict import EasyDict
+    import yaml
+    import pointnet2_utils as vendored
+    vendored.GroupAll.ret_grouped_xyz = False     # attribute read at pointnet2_utils.py:421, never set (:386-389)
+    import models.PointCAE_pointnetv2 as M
+    from oracle import model as OM
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    cfg = EasyDict(yaml.safe_load(open(os.path.join(R.REF, 'cfgs/pretrain_PointCAE_clean.yaml')))['model'])
+    R.seed_all(seed)
+    ref = M.Point_CAE_PointNetv2(cfg)
+    ref.device = torch.device('cpu')
+    fill_state(ref, seed)
+    ref.train()
+    clean = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed))
+    corrupted = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed + 100))
+    cap = {}
+    ref.pointnetv2_encoder.register_forward_hook(lambda m, i, o: cap.update(feature=o))
+    ref.folding1.register_forward_hook(lambda m, i, o: cap.update(coarse=o))
+    l_coarse, l_fine = ref(corrupted, clean)
+    (l_coarse + 0.5 * l_fine).backward()
+    orc = fill_state(OM.Point_CAE_PointNetv2(cfg), seed).train()
+    o1, o2 = orc(corrupted, clean)
+    assert o1.item() == l_coarse.item() and o2.item() == l_fine.item(), (o1.item(), l_coarse.item())
+    out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
+               loss_coarse=np.float32(l_coarse.item()), loss_fine=np.float32(l_fine.item()),
+               feature=cap['feature'].detach().numpy(), coarse=cap['coarse'].detach().numpy().reshape(B, 1024, 3))
+    for pname, p in ref.named_parameters():
+        g = p.grad
+        key = 'grad/' + pname
+        out[key + '/norm'] = np.float64(g.double().norm().item())
+        if g.numel() <= 1536:
+            out[key + '/full'] = g.numpy()
+        else:
+            out[key + '/sample'], _ = _sample(g)
+    for bname, b in ref.named_buffers():
+        if b.dtype.is_floating_point:
+            out['buf/' + bname] = b.numpy()
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(name, 'loss', l_coarse.item(), l_fine.item(), 'size %.0f KB' % (os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
     R.setup()
     R.cpu_cuda_noop()
+    pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
     # cfg3 architecture at full size (384-d, 12+4 blocks), B=2, stochastic depth off
     transformer_fixture('transformer_cfg3_b2.npz', 2, 11, {'transformer_config.drop_path_rate': 0.0})
     # all_patch variant, cdl1 loss, smaller stack
