@@ -115,6 +115,8 @@ def main():
     device = torch.device('cuda', torch.cuda.current_device())
 
     from point_dae_amd import builder, nn_ops
+    from point_dae_amd.tuning import enable_tuned_gemms
+    tuned = enable_tuned_gemms()
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.misc import set_random_seed
@@ -223,7 +225,8 @@ def main():
                                     'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2) ') +
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
                        'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
-                       'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay'},
+                       'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'library_gemm_selection': 'TunableOp lookup of point_dae_amd/tunableop_gfx950.csv' if tuned else 'default heuristic'},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

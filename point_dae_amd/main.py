@@ -6,6 +6,7 @@ from . import dist_utils, parser
 from .config import get_config
 from .misc import set_random_seed
 from .runner_pretrain import run_net
+from .tuning import enable_tuned_gemms
 
 
 def main(argv=None):
@@ -21,6 +22,7 @@ def main(argv=None):
         args.distributed = True
         dist_utils.init_dist(args.launcher)
         _, args.world_size = dist_utils.get_dist_info()
+    enable_tuned_gemms()
     config = get_config(args)
     if args.model_name != 'none':
         config.model.NAME = args.model_name
