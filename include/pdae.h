@@ -276,7 +276,7 @@ int pdae_bnrelu_backward(int G, int C, float* dA, const float* X,
  *                       y = LayerNorm(s) * gamma + beta; mean/rstd (M) saved.
  *   layernorm_backward  dx = LayerNorm'(dy) (+ dres, nullable: the gradient
  *                       arriving over the skip connection); dgamma/dbeta (C)
- *                       are overwritten.
+ *                       are overwritten (or added to, see `accumulate`).
  *   gelu_forward / gelu_backward   exact (erf) GELU, nn.GELU default (:97,:107).
  *   scale_residual      y = res + keep[row/T] * (a + bias): Linear bias, timm
  *                       DropPath (keep[b] is 0 or 1/keep_prob) and the residual
@@ -298,7 +298,7 @@ int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
                             const float* mean, const float* rstd,
                             const float* gamma, const float* dres /*nullable*/,
                             float* dx, float* dgamma, float* dbeta,
-                            pdae_stream_t stream);
+                            int accumulate, pdae_stream_t stream);
 int pdae_gelu_forward(long long n, const float* z, float* h,
                       pdae_stream_t stream);
 int pdae_gelu_backward(long long n, const float* z, const float* dh, float* dz,
@@ -308,7 +308,19 @@ int pdae_scale_residual(int M, int C, int T, const float* a,
                         const float* keep /*nullable*/,
                         const float* res /*nullable*/, float* y,
                         pdae_stream_t stream);
-int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream);
+int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
+                pdae_stream_t stream);
+/*   bias_gelu_forward   h = GELU(z + bias)            (fc1 epilogue, :104-106)
+ *   bias_gelu_backward  dz = dh * GELU'(z + bias), dbias = column sums of dz
+ * `accumulate` != 0 (layernorm_backward, colsum, bias_gelu_backward): the small
+ * reduction outputs (dgamma/dbeta, out, dbias) are added to instead of being
+ * zero-filled first, so a caller can hand in slices of ONE pre-zeroed arena and
+ * save a memset node per call.                                              */
+int pdae_bias_gelu_forward(int M, int C, const float* z, const float* bias,
+                           float* h, pdae_stream_t stream);
+int pdae_bias_gelu_backward(int M, int C, const float* z, const float* bias,
+                            const float* dh, float* dz, float* dbias,
+                            int accumulate, pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused AdamW over a contiguous fp32 range (torch.optim.AdamW arithmetic:

@@ -42,11 +42,13 @@ _SIGNATURES = {
     "pdae_attention_forward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "pdae_attention_backward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_add_layernorm_forward": [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
-    "pdae_layernorm_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_layernorm_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_bias_gelu_forward": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdae_bias_gelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_gelu_forward": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdae_gelu_backward": [ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pdae_colsum": [_i, _i, _vp, _vp, _vp],
+    "pdae_colsum": [_i, _i, _vp, _vp, _i, _vp],
     "pdae_adamw_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -153,15 +153,17 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int T, int H, float 
 }
 
 // ---------------------------------------------------------------- backward
-// dqkv (B*T, 3*H*64) fully written.  grid (H, B), block = 64 * ceil(T/32).
-__global__ __launch_bounds__(256) void attention_bwd_kernel(int T, int H, float scale,
+// dqkv (B*T, 3*H*64) fully written.  grid (H, B), block = 2 * 64 * ceil(T/32): the
+// first half of the waves computes dQ (one wave per query tile), the second half
+// dK and dV (one wave per key tile), concurrently.
+__global__ __launch_bounds__(512) void attention_bwd_kernel(int T, int H, float scale,
                                                             const float* __restrict__ qkv,
                                                             const float* __restrict__ o,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ d_o,
                                                             float* __restrict__ dqkv) {
   extern __shared__ float lds[];
-  const int NW = blockDim.x >> 6;
+  const int NW = blockDim.x >> 7;
   const int Tpad = NW * 32;
   float* Qs = lds;
   float* Ks = Qs + Tpad * ALD;
@@ -188,11 +190,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(int T, int H, float 
     Ds[q] = dl;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int part = (threadIdx.x >> 6) / NW, w = (threadIdx.x >> 6) % NW;
   const int r = lane & 31, h = lane >> 5;
 
   // ---- part 1: dQ for query tile w.  X = dS^T (rows = keys, lane = query w*32+r)
-  {
+  if (part == 0) {
     const int q = w * 32 + r;
     const float lq = Ls[q], dq_delta = Ds[q];
     f32x16 dqa[2];
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(int T, int H, float 
       }
   }
   // ---- part 2: dK, dV for key tile w.  X = P, dS (rows = queries, lane = key w*32+r)
-  {
+  if (part == 1) {
     const int key = w * 32 + r;
     f32x16 dka[2], dva[2];
     zero16(dka[0]);
@@ -314,7 +317,7 @@ extern "C" int pdae_attention_backward(int B, int T, int H, int D, float scale, 
                               (4 * AMAXT * ALD + 2 * AMAXT) * 4);
     once = true;
   }
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(H, B), dim3(64 * NW), lds, as_stream(stream), T, H,
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(H, B), dim3(128 * NW), lds, as_stream(stream), T, H,
                      scale, qkv, o, lse, d_o, dqkv);
   return check_launch("attention_backward");
 }

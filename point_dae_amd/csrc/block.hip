@@ -161,6 +161,54 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
   return cdf + v * pdf;
 }
 
+// h = gelu(z + bias[col]); backward: dz = dh * gelu'(z + bias), dbias += colsum(dz)
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(long long n4, int C4,
+                                                            const float4* __restrict__ z,
+                                                            const float4* __restrict__ bias,
+                                                            float4* __restrict__ h) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = z[i], b = bias[i % C4];
+  h[i] = make_float4(gelu_f(v.x + b.x), gelu_f(v.y + b.y), gelu_f(v.z + b.z), gelu_f(v.w + b.w));
+}
+
+// one block = 64 column-quads x 4 row phases over a slab of rows
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(int M, int C, const float* __restrict__ z,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ dh,
+                                                            float* __restrict__ dz,
+                                                            float* __restrict__ dbias,
+                                                            int rows_per_split) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    for (int m = mbeg + w; m < mend; m += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(z + (size_t)m * C + c);
+      const float4 d = *reinterpret_cast<const float4*>(dh + (size_t)m * C + c);
+      float4 o;
+      o.x = d.x * gelu_grad_f(v.x + b.x);
+      o.y = d.y * gelu_grad_f(v.y + b.y);
+      o.z = d.z * gelu_grad_f(v.z + b.z);
+      o.w = d.w * gelu_grad_f(v.w + b.w);
+      *reinterpret_cast<float4*>(dz + (size_t)m * C + c) = o;
+      s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+    }
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const float4 a = part[0][lane], b2 = part[1][lane], d2 = part[2][lane], e = part[3][lane];
+    atomicAdd(dbias + c + 0, (a.x + b2.x) + (d2.x + e.x));
+    atomicAdd(dbias + c + 1, (a.y + b2.y) + (d2.y + e.y));
+    atomicAdd(dbias + c + 2, (a.z + b2.z) + (d2.z + e.z));
+    atomicAdd(dbias + c + 3, (a.w + b2.w) + (d2.w + e.w));
+  }
+}
+
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(long long n4, const float4* __restrict__ z,
                                                        float4* __restrict__ h) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -250,13 +298,15 @@ extern "C" int pdae_add_layernorm_forward(int M, int C, const float* x, const fl
 extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
                                        const float* mean, const float* rstd, const float* gamma,
                                        const float* dres, float* dx, float* dgamma, float* dbeta,
-                                       pdae_stream_t stream) {
+                                       int accumulate, pdae_stream_t stream) {
   if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4)
     return bad_arg("layernorm_backward: C must be a multiple of 4, at most 2048");
   if (!dgamma || !dbeta) return bad_arg("layernorm_backward: null pointer");
   hipStream_t s = as_stream(stream);
-  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, s);
-  (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, s);
+  if (!accumulate) {
+    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, s);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, s);
+  }
   if (M == 0) return check_launch("layernorm_backward");
   if (!dy || !x || !mean || !rstd || !gamma || !dx) return bad_arg("layernorm_backward: null pointer");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256),
@@ -285,6 +335,35 @@ extern "C" int pdae_gelu_backward(long long n, const float* z, const float* dh, 
   return check_launch("gelu_backward");
 }
 
+extern "C" int pdae_bias_gelu_forward(int M, int C, const float* z, const float* bias, float* h,
+                                      pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0) return bad_arg("bias_gelu_forward: C must be a positive multiple of 4");
+  if (M == 0) return PDAE_OK;
+  if (!z || !bias || !h) return bad_arg("bias_gelu_forward: null pointer");
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), n4, C / 4, reinterpret_cast<const float4*>(z),
+                     reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(h));
+  return check_launch("bias_gelu_forward");
+}
+
+extern "C" int pdae_bias_gelu_backward(int M, int C, const float* z, const float* bias,
+                                       const float* dh, float* dz, float* dbias, int accumulate,
+                                       pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0) return bad_arg("bias_gelu_backward: C must be a positive multiple of 4");
+  if (!dbias) return bad_arg("bias_gelu_backward: null pointer");
+  hipStream_t s = as_stream(stream);
+  if (!accumulate) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s);
+  if (M == 0) return check_launch("bias_gelu_backward");
+  if (!z || !bias || !dh || !dz) return bad_arg("bias_gelu_backward: null pointer");
+  int bs = (M + 63) / 64;
+  if (bs > 1024) bs = 1024;
+  const int rows = (M + bs - 1) / bs;
+  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((C + 255) / 256, bs), dim3(256), 0, s, M, C, z, bias, dh,
+                     dz, dbias, rows);
+  return check_launch("bias_gelu_backward");
+}
+
 extern "C" int pdae_scale_residual(int M, int C, int T, const float* a, const float* bias,
                                    const float* keep, const float* res, float* y,
                                    pdae_stream_t stream) {
@@ -299,11 +378,12 @@ extern "C" int pdae_scale_residual(int M, int C, int T, const float* a, const fl
   return check_launch("scale_residual");
 }
 
-extern "C" int pdae_colsum(int M, int N, const float* X, float* out, pdae_stream_t stream) {
+extern "C" int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
+                           pdae_stream_t stream) {
   if (M < 0 || N <= 0 || N % 4 != 0) return bad_arg("colsum: N must be a positive multiple of 4");
   if (!out) return bad_arg("colsum: null pointer");
   hipStream_t s = as_stream(stream);
-  (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+  if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("colsum");
   if (!X) return bad_arg("colsum: null pointer");
   int bs = (M + 63) / 64;

@@ -21,9 +21,43 @@ def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
+class ZeroArena:
+    """One pre-zeroed device buffer per step for the small reduction outputs of
+    the backward (LayerNorm dgamma/dbeta, bias gradients): `reset()` is ONE
+    memset at the start of a step, kernels then accumulate into `take()`n slices
+    (accumulate=1) instead of each issuing its own memset node (~110 per step)."""
+
+    def __init__(self, numel=1 << 20):
+        self.numel, self.buf, self.used = numel, None, 0
+
+    def reset(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(self.numel, device=device)
+        else:
+            self.buf.zero_()
+        self.used = 0
+
+    def take(self, n, like):
+        """-> (zeroed float tensor of n elements, came_from_arena)"""
+        n_pad = (n + 63) & ~63
+        if self.buf is None or self.buf.device != like.device or self.used + n_pad > self.numel:
+            return torch.zeros(n, device=like.device), True
+        t = self.buf[self.used:self.used + n]
+        self.used += n_pad
+        return t, True
+
+
+arena = ZeroArena()
+
+
+def begin_step(device):
+    """Call once at the start of a forward pass (the models do)."""
+    arena.reset(device)
+
+
 def _colsum(x):
-    out = _empty((x.shape[1],), x)
-    _lib.call('pdae_colsum', x, x.shape[0], x.shape[1], _lib.ptr(x), _lib.ptr(out))
+    out, _ = arena.take(x.shape[1], x)
+    _lib.call('pdae_colsum', x, x.shape[0], x.shape[1], _lib.ptr(x), _lib.ptr(out), 1)
     return out
 
 
@@ -54,10 +88,11 @@ class _AddLayerNorm(torch.autograd.Function):
         s, mean, rstd, gamma = ctx.saved_tensors
         M, C = s.shape
         dx = torch.empty_like(s)
-        dg, db = _empty((C,), s), _empty((C,), s)
+        gb, _ = arena.take(2 * C, s)
+        dg, db = gb[:C], gb[C:]
         dres = ds.contiguous() if ds is not None else None
         _lib.call('pdae_layernorm_backward', s, M, C, _lib.ptr(dy.contiguous()), _lib.ptr(s), _lib.ptr(mean),
-                  _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db))
+                  _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), 1)
         return dx, (dx if ctx.has_pos else None), dg, db, None
 
 
@@ -117,6 +152,33 @@ class _Gelu(torch.autograd.Function):
 
 def gelu(z):
     return _Gelu.apply(z)
+
+
+class _BiasGelu(torch.autograd.Function):
+    """h = GELU(z + bias); backward also yields the bias gradient in the same pass."""
+
+    @staticmethod
+    def forward(ctx, z, bias):
+        z = z.contiguous()
+        M, C = z.shape
+        h = torch.empty_like(z)
+        _lib.call('pdae_bias_gelu_forward', z, M, C, _lib.ptr(z), _lib.ptr(bias), _lib.ptr(h))
+        ctx.save_for_backward(z, bias)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        z, bias = ctx.saved_tensors
+        M, C = z.shape
+        dz = torch.empty_like(z)
+        db, _ = arena.take(C, z)
+        _lib.call('pdae_bias_gelu_backward', z, M, C, _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dh.contiguous()),
+                  _lib.ptr(dz), _lib.ptr(db), 1)
+        return dz, db
+
+
+def bias_gelu(z, bias):
+    return _BiasGelu.apply(z, bias)
 
 
 class _ScaleResidual(torch.autograd.Function):
@@ -198,5 +260,5 @@ def transformer_block(x, pos, B, T, blk, keeps):
     keep1, keep2 = keeps
     x2 = _ScaleResidual.apply(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T)
     n2 = layer_norm(x2, blk.norm2)
-    h = gelu(F.linear(n2, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+    h = bias_gelu(torch.mm(n2, blk.mlp.fc1.weight.t()), blk.mlp.fc1.bias)
     return _ScaleResidual.apply(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)

@@ -272,6 +272,7 @@ class PointCAE_transformer(nn.Module):
         reference's."""
         pts = pts[:, :, :3].contiguous()
         B = pts.shape[0]
+        nn_ops.begin_step(pts.device)
         neighborhood, center = self.group_divider(pts)
         if steps is None:
             steps = draw_corruption(self.corrupt_type, B)

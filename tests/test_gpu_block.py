@@ -66,6 +66,16 @@ def test_gelu_and_scale_residual():
     gh = torch.randn_like(z)
     h = nn_ops.gelu(z)
     h.backward(gh)
+    bias = torch.randn(1536, device='cuda', requires_grad=True)
+    z2 = z.detach().clone().requires_grad_(True)
+    nn_ops.begin_step(z.device)
+    h2 = nn_ops.bias_gelu(z2, bias)
+    h2.backward(gh)
+    zb = (z.detach().double() + bias.detach().double()).requires_grad_(True)
+    F.gelu(zb).backward(gh.double())
+    _close(h2, F.gelu(zb), 1e-6)
+    _close(z2.grad, zb.grad, 2e-6)
+    _close(bias.grad, zb.grad.sum(0), 2e-5)
     z64 = z.detach().double().requires_grad_(True)
     F.gelu(z64).backward(gh.double())
     _close(h, F.gelu(z64), 1e-6)
