@@ -292,7 +292,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 // "down the columns": lane (r,h) of MFMA step t takes A[m = 2t + h][n = i0 + r].
 // Optional producer on B (PRO_BNRELU over B's columns k) recomputes the
 // activation that was never stored.
-constexpr int TBM = 128, TBN = 128, TBK = 16;
+constexpr int TBK = 16;
 struct TnArgs {
   int M, N, K;
   const float* A;
@@ -306,49 +306,70 @@ struct TnArgs {
   int rows_per_split;
 };
 
-template <int PRO>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
-  __shared__ float lds[2][TBK * (TBM + TBN)];
-  const int n0 = blockIdx.y * TBM, k0 = blockIdx.x * TBN;
+// Block tile TM (columns n of A) x TN_ (columns k of B); every wave 64x64.  Bigger
+// tiles = fewer bytes staged per MAC (the 128x128 version ran at 69 TFLOP/s).
+template <int TM, int TN_, int PRO>
+__global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(const TnArgs p) {
+  constexpr int WN = TN_ / 64;
+  constexpr int NT = (TM / 64) * (TN_ / 64) * 64;
+  constexpr int ROW4 = (TM + TN_) / 4;              // float4 per staged row
+  constexpr int SLOTS = (TBK * ROW4 + NT - 1) / NT;  // float4 per thread per tile
+  __shared__ float lds[2][TBK * (TM + TN_)];
+  const int n0 = blockIdx.y * TM, k0 = blockIdx.x * TN_;
   const int mbeg = blockIdx.z * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
   if (mbeg >= mend) return;
   const int N = p.N, K = p.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-  // each of the 16 rows holds 128 floats of A and 128 of B = 32 float4 each
-  const int srow = tid >> 5, scol = (tid & 31) * 4;  // rows srow and srow + 8
-  const bool aok = n0 + scol < N, bok = k0 + scol < K;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (PRO == PRO_BNRELU && bok) {
-    sc = *reinterpret_cast<const float4*>(p.pro_scale + k0 + scol);
-    sh = *reinterpret_cast<const float4*>(p.pro_shift + k0 + scol);
+
+  int srow[SLOTS], scol[SLOTS];
+  bool isb[SLOTS], ok[SLOTS];
+  float4 sc[SLOTS], sh[SLOTS];
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int f = tid + i * NT;
+    srow[i] = f / ROW4;
+    const int c = (f % ROW4) * 4;
+    isb[i] = c >= TM;
+    scol[i] = c;
+    const int g = isb[i] ? k0 + c - TM : n0 + c;
+    ok[i] = f < TBK * ROW4 && (isb[i] ? g < K : g < N);
+    sc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRO == PRO_BNRELU && isb[i] && ok[i]) {
+      sc[i] = *reinterpret_cast<const float4*>(p.pro_scale + g);
+      sh[i] = *reinterpret_cast<const float4*>(p.pro_shift + g);
+    }
   }
-  float4 ra[2], rb[2];
+  float4 rg[SLOTS];
   auto gload = [&](int mt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int gm = mt + srow + 8 * i;
-      const bool inm = gm < mend;
-      ra[i] = (inm && aok) ? *reinterpret_cast<const float4*>(p.A + (size_t)gm * p.lda + n0 + scol)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = (inm && bok) ? *reinterpret_cast<const float4*>(p.B + (size_t)gm * p.ldb + k0 + scol)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PRO == PRO_BNRELU && inm && bok) {
-        rb[i].x = act_relu(rb[i].x * sc.x + sh.x);
-        rb[i].y = act_relu(rb[i].y * sc.y + sh.y);
-        rb[i].z = act_relu(rb[i].z * sc.z + sh.z);
-        rb[i].w = act_relu(rb[i].w * sc.w + sh.w);
+    for (int i = 0; i < SLOTS; ++i) {
+      const int gm = mt + srow[i];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[i] && gm < mend) {
+        if (isb[i]) {
+          v = *reinterpret_cast<const float4*>(p.B + (size_t)gm * p.ldb + k0 + scol[i] - TM);
+          if (PRO == PRO_BNRELU) {
+            v.x = act_relu(v.x * sc[i].x + sh[i].x);
+            v.y = act_relu(v.y * sc[i].y + sh[i].y);
+            v.z = act_relu(v.z * sc[i].z + sh[i].z);
+            v.w = act_relu(v.w * sc[i].w + sh[i].w);
+          }
+        } else {
+          v = *reinterpret_cast<const float4*>(p.A + (size_t)gm * p.lda + n0 + scol[i]);
+        }
       }
+      rg[i] = v;
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&lds[buf][(srow + 8 * i) * (TBM + TBN) + scol]) = ra[i];
-      *reinterpret_cast<float4*>(&lds[buf][(srow + 8 * i) * (TBM + TBN) + TBM + scol]) = rb[i];
-    }
+    for (int i = 0; i < SLOTS; ++i)
+      if (tid + i * NT < TBK * ROW4)
+        *reinterpret_cast<float4*>(&lds[buf][srow[i] * (TM + TN_) + scol[i]]) = rg[i];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -364,16 +385,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
   int buf = 0;
   for (int mt = mbeg; mt < mend; mt += TBK) {
     if (mt + TBK < mend) gload(mt + TBK);
-    const float* T = lds[buf];
+    const float* T = lds[buf] + h * (TM + TN_);
+    // fragment reads run two k-steps ahead of the MFMAs that consume them
+    float fa[2][2][2], fb[2][2][2];   // [stage][step within stage][tile]
+    auto fread = [&](int st, int t) {
+      const float* row = T + 2 * t * (TM + TN_);
+      fa[st][t & 1][0] = row[wm * 64 + r];
+      fa[st][t & 1][1] = row[wm * 64 + 32 + r];
+      fb[st][t & 1][0] = row[TM + wn * 64 + r];
+      fb[st][t & 1][1] = row[TM + wn * 64 + 32 + r];
+    };
+    fread(0, 0);
+    fread(0, 1);
 #pragma unroll
-    for (int t = 0; t < TBK / 2; ++t) {
-      const float* row = T + (2 * t + h) * (TBM + TBN);
-      const float a0 = row[wm * 64 + r], a1 = row[wm * 64 + 32 + r];
-      const float b0 = row[TBM + wn * 64 + r], b1 = row[TBM + wn * 64 + 32 + r];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int tt = 0; tt < TBK / 4; ++tt) {
+      const int cur = tt & 1, nxt = cur ^ 1;
+      if (tt + 1 < TBK / 4) {
+        fread(nxt, 2 * tt + 2);
+        fread(nxt, 2 * tt + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][0], fb[cur][u][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][0], fb[cur][u][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][1], fb[cur][u][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][1], fb[cur][u][1], acc[1][1], 0, 0, 0);
+      }
     }
     if (mt + TBK < mend) lstore(buf ^ 1);
     __syncthreads();
@@ -477,17 +515,29 @@ extern "C" int pdae_linear_backward_data(int M, int N, int K, const float* dY, c
   return launch_nt<PRO_NONE, EPI_BIAS>(a, as_stream(stream));
 }
 
-static int launch_tn(TnArgs& t, bool bnrelu, hipStream_t s) {
-  const int tn = (t.N + TBM - 1) / TBM, tk = (t.K + TBN - 1) / TBN;
-  // enough M-splits to cover the chip about four times, each at least 256 rows
-  int splits = (4 * 256 + tn * tk - 1) / (tn * tk);
+template <int TM, int TN_>
+static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
+  const int tn = (t.N + TM - 1) / TM, tk = (t.K + TN_ - 1) / TN_;
+  constexpr int NTH = (TM / 64) * (TN_ / 64) * 64;
+  // enough M-splits to cover the chip about twice (one block per CU), each at least 256 rows
+  int splits = (2 * 256 + tn * tk - 1) / (tn * tk);
   int rows = (t.M + splits - 1) / splits;
   rows = ((rows + TBK - 1) / TBK) * TBK;
   if (rows < 256) rows = 256;
   splits = (t.M + rows - 1) / rows;
   t.rows_per_split = rows;
-  if (bnrelu) hipLaunchKernelGGL((gemm_tn_kernel<PRO_BNRELU>), dim3(tk, tn, splits), dim3(256), 0, s, t);
-  else hipLaunchKernelGGL((gemm_tn_kernel<PRO_NONE>), dim3(tk, tn, splits), dim3(256), 0, s, t);
+  if (bnrelu)
+    hipLaunchKernelGGL((gemm_tn_kernel<TM, TN_, PRO_BNRELU>), dim3(tk, tn, splits), dim3(NTH), 0, s, t);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<TM, TN_, PRO_NONE>), dim3(tk, tn, splits), dim3(NTH), 0, s, t);
+}
+
+static int launch_tn(TnArgs& t, bool bnrelu, hipStream_t s) {
+  const bool big = t.M >= 32768;
+  if (big && t.N % 192 == 0 && t.K % 256 == 0) launch_tn_cfg<192, 256>(t, bnrelu, s);
+  else if (big && t.N % 256 == 0 && t.K % 256 == 0) launch_tn_cfg<256, 256>(t, bnrelu, s);
+  else if (big && t.N % 256 == 0) launch_tn_cfg<256, 128>(t, bnrelu, s);
+  else launch_tn_cfg<128, 128>(t, bnrelu, s);
   return check_launch("gemm_tn");
 }
 

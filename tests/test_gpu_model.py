@@ -190,3 +190,27 @@ def test_cfg2_full_batch_step_runs():
         opt.step()
         model.zero_grad()
     assert torch.isfinite(lc) and torch.isfinite(lf)
+
+
+def test_cfg5_shape_runs():
+    """BASELINE config 5 shape: N=2048, G=128, k=32 (decoder T=128, T_vis up to 64)."""
+    import os
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(
+        root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_double.yaml'))
+    config.npoints = 2048
+    config.model.num_group = 128
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    torch.manual_seed(0)
+    model = FlatDataParallel(builder.model_builder(config.model).cuda().train())
+    opt, _ = builder.build_opti_sche(model, config)
+    x = torch.from_numpy(shapenet_like_clouds(8, 2048, seed=1)).cuda()
+    step = GraphedTrainStep(model, opt, config, 8, 2048, warmup_eager=1)
+    losses = [step(x)[0].item() for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
