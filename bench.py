@@ -116,7 +116,7 @@ def main():
 
     from point_dae_amd import builder, nn_ops
     from point_dae_amd.tuning import enable_tuned_gemms
-    tuned = enable_tuned_gemms()
+    tuned = enable_tuned_gemms(retune=os.environ.get('PDAE_RETUNE') == '1', out=os.environ.get('PDAE_RETUNE_OUT'))
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.misc import set_random_seed
