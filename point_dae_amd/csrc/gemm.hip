@@ -519,8 +519,8 @@ template <int TM, int TN_>
 static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
   const int tn = (t.N + TM - 1) / TM, tk = (t.K + TN_ - 1) / TN_;
   constexpr int NTH = (TM / 64) * (TN_ / 64) * 64;
-  // enough M-splits to cover the chip about twice (one block per CU), each at least 256 rows
-  int splits = (2 * 256 + tn * tk - 1) / (tn * tk);
+  // enough M-splits to cover the chip about four times, each at least 256 rows
+  int splits = (4 * 256 + tn * tk - 1) / (tn * tk);
   int rows = (t.M + splits - 1) / splits;
   rows = ((rows + TBK - 1) / TBK) * TBK;
   if (rows < 256) rows = 256;
@@ -533,11 +533,9 @@ static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
 }
 
 static int launch_tn(TnArgs& t, bool bnrelu, hipStream_t s) {
-  const bool big = t.M >= 32768;
-  if (big && t.N % 192 == 0 && t.K % 256 == 0) launch_tn_cfg<192, 256>(t, bnrelu, s);
-  else if (big && t.N % 256 == 0 && t.K % 256 == 0) launch_tn_cfg<256, 256>(t, bnrelu, s);
-  else if (big && t.N % 256 == 0) launch_tn_cfg<256, 128>(t, bnrelu, s);
-  else launch_tn_cfg<128, 128>(t, bnrelu, s);
+  // measured on the embedder's weight gradients (M = 262144): the 128x128 tile at two
+  // blocks per CU (654 us for dW4) beats 192x256 / 256x256 at one block per CU (767 us)
+  launch_tn_cfg<128, 128>(t, bnrelu, s);
   return check_launch("gemm_tn");
 }
 
