@@ -71,15 +71,38 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     model = FlatDataParallel(base_model)
     optimizer, scheduler = builder.build_opti_sche(model, config)
     model.zero_grad()
+    # the step is replayed as hipGraphs (graph_step.py); eager launches only as a fallback
+    # for configurations the graphed steps do not cover
+    from .graph_step import GraphedStaticStep, GraphedTrainStep
+    from .point_cae_pointnetv2 import Point_CAE_PointNetv2
+    from .point_cae_transformer import PointCAE_transformer
+    bs = ds_cfg['bs']
+    gw_dev = torch.zeros((), device=device)                 # gradual weight, read inside the captured graph
+    if isinstance(base_model, PointCAE_transformer) and config.loss_type in ('xyz', 'xyznormal') \
+            and config.step_per_update == 1:
+        graphed = GraphedTrainStep(model, optimizer, config, bs, config.npoints)
+        step_fn = lambda corrupted, clean: graphed(clean)   # noqa: E731  (corrupted input unused on this path)
+    elif isinstance(base_model, Point_CAE_PointNetv2) and config.step_per_update == 1:
+        w = float(config.normal_weight)
+        mixes = {'xyz': lambda a, b: a, 'normal': lambda a, b: w * b, 'xyznormal': lambda a, b: a + w * b,
+                 'xyznormal_gradual': lambda a, b: a + w * b * gw_dev, 'xyznormal_warm': lambda a, b: a + w * b * gw_dev}
+        graphed = GraphedStaticStep(model, optimizer, mixes[config.loss_type], bs, config.npoints)
+        step_fn = graphed
+    else:
+        step_fn = None
 
     for epoch in range(start_epoch, config.max_epoch + 1):
         model.train()
         gw = gradual_weight_of(config, epoch)
+        gw_dev.fill_(float(gw))
         acc = torch.zeros(2, device=device)
         t0 = time.time()
         n = 0
         for idx, (_, _, corrupted, clean) in enumerate(train_loader):
-            lx, ln = train_step(model, optimizer, config, corrupted, clean, gw)
+            if step_fn is not None:
+                lx, ln = step_fn(corrupted, clean)
+            else:
+                lx, ln = train_step(model, optimizer, config, corrupted, clean, gw)
             acc += torch.stack([lx.reshape(()), ln.sum().reshape(())])
             n += 1
             if (idx + 1) % log_every == 0 or idx + 1 == len(train_loader):

@@ -214,3 +214,33 @@ def test_cfg5_shape_runs():
     step = GraphedTrainStep(model, opt, config, 8, 2048, warmup_eager=1)
     losses = [step(x)[0].item() for _ in range(5)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_main_cli_trains_and_resumes(tmp_path):
+    """python -m point_dae_amd.main with the reference's flags: one tiny epoch, checkpoint, --resume."""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml')
+    cfg = yaml.safe_load(open(src))
+    cfg['model']['transformer_config'].update(depth=2, decoder_depth=1)
+    cfg['max_epoch'] = 1
+    cfgdir = tmp_path / 'cfgs'
+    cfgdir.mkdir()
+    path = cfgdir / 'tiny.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'))
+    base = [sys.executable, '-m', 'point_dae_amd.main', '--config', str(path), '--total_bs', '8', '--steps_per_epoch', '3',
+            '--exp_name', 'ci', '--root_folder', os.path.relpath(str(tmp_path / 'exp'), root)]
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run(base, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'clouds/s' in r.stdout
+    ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == 'ckpt-last.pth']
+    assert len(ckpts) == 1
+    sd = torch.load(ckpts[0], map_location='cpu')
+    assert {'base_model', 'optimizer', 'epoch'} <= set(sd) and sd['epoch'] == 1
+    assert 'MAE_encoder.encoder.first_conv.0.weight' in sd['base_model']          # reference key layout
+    r = subprocess.run(base + ['--resume'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
