@@ -360,6 +360,76 @@ class PointCAE_transformer(nn.Module):
         return loss1, torch.zeros(1)
 
 
+class PointCAE_transformer_fc_global_folding_local(nn.Module):
+    """models/PointCAE_transformer.py:919-1088 ('Drop-Patch' branch): FoldingNet
+    patch head + FC global head, the variant of the released checkpoints."""
+
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.trans_dim = C = tc.trans_dim
+        assert 'Drop-Patch' in config.corrupt_type
+        self.MAE_encoder = MaskTransformer(config)
+        self.group_size, self.num_group = config.group_size, config.num_group
+        self.corrupt_type, self.all_patch = config.corrupt_type, config.all_patch
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, C))
+        self.decoder_pos_embed = _pos_embed(C)
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
+        self.MAE_decoder = TransformerDecoder(C, tc.decoder_depth, tc.decoder_num_heads, dpr)
+        self.coarse_pred = nn.Sequential(nn.Linear(C, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1024),
+                                         nn.ReLU(inplace=True), nn.Linear(1024, 3 * 64))
+        self.folding1 = nn.Sequential(nn.Conv1d(C + 2, C, 1), nn.ReLU(), nn.Conv1d(C, C, 1), nn.ReLU(),
+                                      nn.Conv1d(C, 3, 1))
+        self.folding2 = nn.Sequential(nn.Conv1d(C + 3, C, 1), nn.ReLU(), nn.Conv1d(C, C, 1), nn.ReLU(),
+                                      nn.Conv1d(C, 3, 1))
+        nn.init.trunc_normal_(self.mask_token, std=.02, a=-2., b=2.)
+        self.loss_func = {'cdl1': chamfer_l1, 'cdl2': chamfer_l2}[config.loss]
+
+    def build_grid(self, n):
+        import itertools
+        x = np.linspace(-0.3, 0.3, 6)
+        pts = np.array(list(itertools.product(x, x)))
+        return torch.tensor(np.repeat(pts[np.newaxis, ...], n, axis=0)).float()
+
+    def forward(self, corrupted_pts, pts, mask=None, steps=None, capture=None, return_feat=False):
+        pts = pts[:, :, :3].contiguous()
+        neighborhood, center = group_divider(pts, self.num_group, self.group_size)
+        neighborhood = neighborhood + center.unsqueeze(2)
+        if steps is None:
+            steps = draw_corruption(self.corrupt_type, pts.shape[0])
+        t_nb, t_c = apply_corruption(neighborhood, center, steps)
+        neighborhood = neighborhood - center.unsqueeze(2)
+        t_nb = t_nb - t_c.unsqueeze(2)
+        x_vis, mask = self.MAE_encoder(t_nb, t_c, mask)
+        B, _, C = x_vis.shape
+        global_feature = torch.max(x_vis.transpose(1, 2), dim=-1)[0] + x_vis.mean(1)
+        if return_feat:
+            return global_feature
+        coarse = self.coarse_pred(global_feature).reshape(B, -1, 3)
+        pos_vis = self.decoder_pos_embed(center[~mask]).reshape(B, -1, C)
+        pos_mask = self.decoder_pos_embed(center[mask]).reshape(B, -1, C)
+        N = pos_mask.shape[1]
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1)], dim=1)
+        pos_full = torch.cat([pos_vis, pos_mask], dim=1)
+        x_rec = self.MAE_decoder(x_full, pos_full) if self.all_patch == 'True' else self.MAE_decoder(x_full, pos_full, N)
+        B, M, C = x_rec.shape
+        tok = x_rec.reshape(B * M, C).unsqueeze(-1).repeat(1, 1, 36)
+        grid = self.build_grid(B * M).transpose(1, 2)
+        f1 = self.folding1(torch.cat((tok, grid), dim=1))
+        f2 = self.folding2(torch.cat((tok, f1), dim=1)).transpose(1, 2)
+        if self.all_patch == 'True':
+            gt = torch.cat((neighborhood[~mask].reshape(B, -1, self.group_size, 3),
+                            neighborhood[mask].reshape(B, -1, self.group_size, 3)), dim=1).reshape(B * M, -1, 3)
+        else:
+            gt = neighborhood[mask].reshape(B * M, -1, 3)
+        loss1 = self.loss_func(f2, gt)
+        loss2 = self.loss_func(coarse, center)
+        if capture is not None:
+            capture.update(center=center, mask=mask, x_vis=x_vis, x_rec=x_rec, coarse=coarse, fold=f2,
+                           global_feature=global_feature)
+        return loss1, loss2
+
+
 # ======================================================================
 # Point_CAE_PointNetv2 (BASELINE configs 1-2): models/PointCAE_pointnetv2.py
 # :61-173 with the PointNet++ encoder of models/pointnetv2_util.py:319-346.

@@ -18,6 +18,7 @@ kernels.  There is no CPU path: the geometry operators raise off-GPU.
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import nn_ops
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
@@ -265,11 +266,10 @@ class PointCAE_transformer(nn.Module):
         else:
             raise NotImplementedError(loss_type)
 
-    def forward(self, corrupted_pts, pts, vis=False, mask=None, steps=None, capture=None, rows=None, **kwargs):
-        """`corrupted_pts` is ignored on this path, as in the reference (:676).
-        `mask` (B,G) bool and `steps` (nsteps,B,10) inject the random draws
-        (parity tests); by default they come from the host RNGs like the
-        reference's."""
+    def trunk(self, pts, mask=None, steps=None, rows=None, encoder_only=False):
+        """Group -> corrupt -> masked encoder -> decoder, shared by the reconstruction
+        heads.  -> dict with x_rec rows (B*R, C), the ground-truth patch rows they
+        are compared with, and the intermediates the heads / tests need."""
         pts = pts[:, :, :3].contiguous()
         B = pts.shape[0]
         nn_ops.begin_step(pts.device)
@@ -283,6 +283,10 @@ class PointCAE_transformer(nn.Module):
         G = self.num_group
         Tvis = vis_rows.numel() // B
         M = G - Tvis
+        out = dict(B=B, C=C, Tvis=Tvis, center=center, gt_nb=gt_nb, t_nb=t_nb, t_c=t_c, mask=mask,
+                   x_vis=x_vis.reshape(B, Tvis, C))
+        if encoder_only:
+            return out
         # decoder positions come from the UN-transformed centres (:695-696)
         ctr = center.reshape(B * G, 3)
         order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
@@ -295,11 +299,81 @@ class PointCAE_transformer(nn.Module):
         else:
             x_rec = self.MAE_decoder(x_full, pos_full, B, G, M)
             gt_rows, R = mask_rows, M
-        rebuild = nn_ops.conv1x1(x_rec, self.increase_dim[0]).reshape(B * R, self.group_size, 3)
-        gt_points = gt_nb.reshape(B * G, self.group_size, 3).index_select(0, gt_rows)
-        loss1 = self.loss_func(rebuild, gt_points)
+        out.update(x_rec=x_rec, R=R,
+                   gt_points=gt_nb.reshape(B * G, self.group_size, 3).index_select(0, gt_rows))
+        return out
+
+    def forward(self, corrupted_pts, pts, vis=False, mask=None, steps=None, capture=None, rows=None, **kwargs):
+        """`corrupted_pts` is ignored on this path, as in the reference (:676).
+        `mask` (B,G) bool and `steps` (nsteps,B,10) inject the random draws
+        (parity tests); by default they come from the host RNGs like the
+        reference's."""
+        t = self.trunk(pts, mask=mask, steps=steps, rows=rows)
+        B, R = t['B'], t['R']
+        rebuild = nn_ops.conv1x1(t['x_rec'], self.increase_dim[0]).reshape(B * R, self.group_size, 3)
+        loss1 = self.loss_func(rebuild, t['gt_points'])
         if capture is not None:
-            capture.update(center=center, neighborhood=gt_nb, t_nb=t_nb, t_c=t_c, mask=mask,
-                           x_vis=x_vis.reshape(B, Tvis, C), x_rec=x_rec.reshape(B, R, C),
-                           rebuild=rebuild, gt=gt_points)
+            capture.update(center=t['center'], neighborhood=t['gt_nb'], t_nb=t['t_nb'], t_c=t['t_c'], mask=t['mask'],
+                           x_vis=t['x_vis'], x_rec=t['x_rec'].reshape(B, R, t['C']), rebuild=rebuild,
+                           gt=t['gt_points'])
         return loss1, torch.zeros(1, device=loss1.device)
+
+
+@MODELS.register_module()
+class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
+    """The variant the released Transformer checkpoints were trained with
+    (models/PointCAE_transformer.py:919-1088, `--model_name` in rerun2.sh:38-41):
+    masked patches are rebuilt by two FoldingNet stages on a 6x6 grid (36 points
+    per patch, loss1 = CD(fold, patch)) and a global branch predicts the 64 patch
+    centres from max+mean pooled visible tokens (loss2 = CD(coarse, centres)).
+    `return_feat=True` returns the pooled global feature (:1025-1026).
+
+    The reference tiles each token 36x and concatenates the grid / first fold
+    before the 1x1 convs; here the first conv of each stage is split by column
+    block so the token part is multiplied once per patch, not once per point."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        del self.increase_dim
+        C = self.trans_dim
+        self.coarse_pred = nn.Sequential(nn.Linear(C, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1024),
+                                         nn.ReLU(inplace=True), nn.Linear(1024, 3 * 64))
+        self.folding1 = nn.Sequential(nn.Conv1d(C + 2, C, 1), nn.ReLU(), nn.Conv1d(C, C, 1), nn.ReLU(),
+                                      nn.Conv1d(C, 3, 1))
+        self.folding2 = nn.Sequential(nn.Conv1d(C + 3, C, 1), nn.ReLU(), nn.Conv1d(C, C, 1), nn.ReLU(),
+                                      nn.Conv1d(C, 3, 1))
+        x = np.linspace(-0.3, 0.3, 6)
+        import itertools
+        grid = torch.tensor(np.array(list(itertools.product(x, x)))).float()      # (36, 2), build_grid :990-996
+        self.register_buffer('fold_grid', grid, persistent=False)
+
+    @staticmethod
+    def _fold(stage, tok, extra_w_cols, extra):
+        """stage(cat([tok tiled, extra])) with the first conv split: tok (P, C) once per
+        patch, extra (P, 36, e) or (36, e) per point.  -> (P*36, 3)."""
+        C = tok.shape[1]
+        w = stage[0].weight.squeeze(-1)
+        a = F.linear(tok, w[:, :C], stage[0].bias).unsqueeze(1)                    # (P, 1, C)
+        h = F.relu(a + F.linear(extra, w[:, C:C + extra_w_cols]))                  # (P, 36, C)
+        h = F.relu(F.linear(h.reshape(-1, C), stage[2].weight.squeeze(-1), stage[2].bias))
+        return F.linear(h, stage[4].weight.squeeze(-1), stage[4].bias)
+
+    def forward(self, corrupted_pts, pts, vis=False, return_feat=False, mask=None, steps=None, capture=None,
+                rows=None, **kwargs):
+        t = self.trunk(pts, mask=mask, steps=steps, rows=rows, encoder_only=return_feat)
+        x_vis = t['x_vis']
+        global_feature = x_vis.max(dim=1)[0] + x_vis.mean(1)                       # (B, C), :1024
+        if return_feat:
+            return global_feature
+        B, R, C = t['B'], t['R'], t['C']
+        coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(global_feature, self.coarse_pred[0], 'relu'),
+                                             self.coarse_pred[2], 'relu'), self.coarse_pred[4]).reshape(B, -1, 3)
+        tok = t['x_rec']                                                           # (B*R, C)
+        f1 = self._fold(self.folding1, tok, 2, self.fold_grid).reshape(B * R, 36, 3)
+        f2 = self._fold(self.folding2, tok, 3, f1).reshape(B * R, 36, 3)
+        loss1 = self.loss_func(f2, t['gt_points'])
+        loss2 = self.loss_func(coarse, t['center'])
+        if capture is not None:
+            capture.update(center=t['center'], mask=t['mask'], x_vis=x_vis, x_rec=tok.reshape(B, R, C),
+                           coarse=coarse, fold=f2, global_feature=global_feature)
+        return loss1, loss2

@@ -28,7 +28,7 @@ def _sample(t, n=256):
     return flat[idx].numpy(), idx
 
 
-def transformer_fixture(name, B, seed, overrides):
+def transformer_fixture(name, B, seed, overrides, cls='PointCAE_transformer'):
     from easydict import EasyDict
     import yaml
     import models.PointCAE_transformer as M
@@ -46,7 +46,7 @@ def transformer_fixture(name, B, seed, overrides):
             node = node[p]
         node[parts[-1]] = v
     R.seed_all(seed)
-    ref = fill_state(M.PointCAE_transformer(cfg), seed)
+    ref = fill_state(getattr(M, cls)(cfg), seed)
     ref.train()
     pts = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed))
 
@@ -62,18 +62,18 @@ def transformer_fixture(name, B, seed, overrides):
     mask, _ = draw_mask(B, cfg.num_group, cfg.transformer_config.mask_ratio, cfg.transformer_config.rand_ratio)
     R.seed_all(seed + 1)
     loss, loss2 = ref(pts, pts)
-    loss.backward()
+    (loss + 0.005 * loss2.sum()).backward()          # runner :165-166, normal_weight 0.005
     assert torch.equal(cap['mask'], mask), 'mask draw does not reproduce the reference'
 
     # cross-check: the oracle model with the captured draws injected reproduces the reference bit for bit
-    orc = OM.PointCAE_transformer(cfg)
+    orc = getattr(OM, cls)(cfg)
     orc.load_state_dict(ref.state_dict())
     osteps = [('mul', s[:, 1:4]) if s[0, 0] == 0 else ('mat', s[:, 1:].reshape(B, 3, 3)) for s in steps]
-    oloss, _ = orc(pts, pts, mask=mask, steps=osteps)
-    assert oloss.item() == loss.item(), (oloss.item(), loss.item())
+    oloss, oloss2 = orc(pts, pts, mask=mask, steps=osteps)
+    assert oloss.item() == loss.item() and oloss2.sum().item() == loss2.sum().item(), (oloss.item(), loss.item())
 
     out = dict(seed=np.int64(seed), B=np.int64(B), pts=pts.numpy(), steps=steps.numpy(), mask=mask.numpy(),
-               loss=np.float32(loss.item()), loss2=loss2.detach().numpy(),
+               loss=np.float32(loss.item()), loss2=loss2.detach().numpy().reshape(-1), cls=np.array(cls),
                center=cap['center'].numpy(), tokens=cap['tokens'].detach().numpy(),
                t_nb=cap['t_nb'].detach().numpy()[:, ::8], x_vis=cap['x_vis'].detach().numpy(),
                x_rec=cap['x_rec'].detach().numpy(),
@@ -143,6 +143,9 @@ if __name__ == '__main__':
     R.setup()
     R.cpu_cuda_noop()
     pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
+    transformer_fixture('transformer_folding_b2.npz', 2, 13, {'transformer_config.drop_path_rate': 0.0,
+                        'transformer_config.depth': 4, 'transformer_config.decoder_depth': 2},
+                        cls='PointCAE_transformer_fc_global_folding_local')
     # cfg3 architecture at full size (384-d, 12+4 blocks), B=2, stochastic depth off
     transformer_fixture('transformer_cfg3_b2.npz', 2, 11, {'transformer_config.drop_path_rate': 0.0})
     # all_patch variant, cdl1 loss, smaller stack
