@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg2'])
     p.add_argument('--batch', type=int, default=128, help='clouds per GPU')
     p.add_argument('--npoints', type=int, default=1024)

@@ -225,11 +225,20 @@ int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,
                                     const float* scale, const float* shift,
                                     const float* W, const float* bias,
                                     float* gmax, unsigned char* garg,
+                                    const int32_t* groups /*nullable*/,
                                     pdae_stream_t stream);
 int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
                                        const float* X, const float* scale,
                                        const float* shift, float* dW,
+                                       const int32_t* groups /*nullable*/,
                                        pdae_stream_t stream);
+/* `groups` (embed_bnrelu_conv_groupmax, bnrelu_linear_backward_weight,
+ * bnrelu_backward): a list of group (patch) ids.  The last conv of the embedder
+ * comes after the last BatchNorm, and the tokens of masked patches are thrown
+ * away by MaskTransformer.forward (:449), so only the VISIBLE patches need that
+ * GEMM: with a list, the M = 32*len(groups) rows of the product are gathered
+ * from X group-wise (row m <- X[groups[m/32]*32 + m%32]) and the outputs are
+ * compact, in list order.  Same numbers as computing all patches and selecting. */
 /*   embed_bnrelu_conv_store_groupmax  (first_conv[1..3] + the max of :47)
  *       Y[M,N] = relu(X*scale + shift).W^T + bias, plus its group max / argmax. */
 int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,
@@ -259,7 +268,12 @@ int pdae_bnrelu_backward(int G, int C, float* dA, const float* X,
                          const float* scale, const float* shift,
                          const float* mean, const float* invstd,
                          const float* gamma, float* S, float* gsum /*nullable*/,
-                         pdae_stream_t stream);
+                         int n_listed, const int32_t* groups /*nullable*/,
+                         const int32_t* inv_group /*nullable*/,
+                         float* dX /*nullable*/, pdae_stream_t stream);
+/*   with groups / inv_group / dX: dA is compact (n_listed*32 rows, the listed
+ *   groups; every other group's dA is zero), inv_group[g] = position of g in the
+ *   list or -1, and the result for ALL G groups is written to dX.            */
 
 /* ------------------------------------------------------------------------
  * Transformer block, Block.forward (models/PointCAE_transformer.py:155-158 with

@@ -33,12 +33,12 @@ _SIGNATURES = {
     "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pdae_bnrelu_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_group_max_scatter": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_group_scatter_add": [_i, _i, _vp, _vp, _vp, _vp],
-    "pdae_bnrelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pdae_attention_forward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "pdae_attention_backward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_add_layernorm_forward": [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],

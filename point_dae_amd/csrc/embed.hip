@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
     int R, int C, const float* __restrict__ dA, const float* __restrict__ X,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ S,
-    int rows_per_block) {
+    int rows_per_block, const int* __restrict__ groups) {
   __shared__ float4 red[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c4 = (blockIdx.x * 32 + cl) * 4;
@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
     const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
     const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
     for (int r = r0 + rl; r < r1; r += 8) {
+      // with a group list, dA holds only the listed groups (compact); the others have dA = 0
+      const int xr = groups ? groups[r >> 5] * 32 + (r & 31) : r;
       const float4 d = *reinterpret_cast<const float4*>(dA + (size_t)r * C + c4);
-      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * C + c4);
+      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)xr * C + c4);
       const float tx = (x.x * sc.x + sh.x > 0.f) ? d.x : 0.f;
       const float ty = (x.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
       const float tz = (x.z * sc.z + sh.z > 0.f) ? d.z : 0.f;
@@ -104,10 +106,12 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ S, float inv_rows,
-    float* __restrict__ gsum) {
+    float* __restrict__ gsum, const int* __restrict__ inv_group, float* __restrict__ dX) {
   const int c4 = (blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
   const int g = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (c4 >= C || g >= G) return;
+  // inv_group[g] = position of group g in the compact dA, or -1 (its dA is zero)
+  const int cg = inv_group ? inv_group[g] : g;
   const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
   const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
   const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
@@ -121,14 +125,15 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_kernel(
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int r = 0; r < 32; ++r) {
     const size_t o = ((size_t)g * 32 + r) * C + c4;
-    const float4 d = *reinterpret_cast<const float4*>(dA + o);
+    const float4 d = cg >= 0 ? *reinterpret_cast<const float4*>(dA + ((size_t)cg * 32 + r) * C + c4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 x = *reinterpret_cast<const float4*>(X + o);
     float4 y;
     y.x = kx * (((x.x * sc.x + sh.x > 0.f) ? d.x : 0.f) - m1x - ((x.x - mu.x) * is.x) * m2x);
     y.y = ky * (((x.y * sc.y + sh.y > 0.f) ? d.y : 0.f) - m1y - ((x.y - mu.y) * is.y) * m2y);
     y.z = kz * (((x.z * sc.z + sh.z > 0.f) ? d.z : 0.f) - m1z - ((x.z - mu.z) * is.z) * m2z);
     y.w = kw * (((x.w * sc.w + sh.w > 0.f) ? d.w : 0.f) - m1w - ((x.w - mu.w) * is.w) * m2w);
-    *reinterpret_cast<float4*>(dA + o) = y;
+    *reinterpret_cast<float4*>(dX + o) = y;
     acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
   }
   if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)g * C + c4) = acc;
@@ -162,7 +167,8 @@ extern "C" int pdae_group_scatter_add(int G, int C, const float* grad, const uns
 
 extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, const float* scale,
                                     const float* shift, const float* mean, const float* invstd,
-                                    const float* gamma, float* S, float* gsum,
+                                    const float* gamma, float* S, float* gsum, int n_listed,
+                                    const int32_t* groups, const int32_t* inv_group, float* dX,
                                     pdae_stream_t stream) {
   if (G < 0 || C <= 0 || C % 4 != 0) return bad_arg("bnrelu_backward: C must be a positive multiple of 4");
   if (!S) return bad_arg("bnrelu_backward: null pointer");
@@ -171,16 +177,22 @@ extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, con
   if (G == 0) return check_launch("bnrelu_backward");
   if (!dA || !X || !scale || !shift || !mean || !invstd || !gamma)
     return bad_arg("bnrelu_backward: null pointer");
+  if ((groups == nullptr) != (inv_group == nullptr) || (groups && !dX))
+    return bad_arg("bnrelu_backward: groups, inv_group and dX go together");
+  if (!groups) dX = dA;                       // in place over all groups
   const int R = G * 32;
+  const int Rsum = groups ? n_listed * 32 : R;  // rows that carry a non-zero dA
   int rows = 512;
-  int by = (R + rows - 1) / rows;
+  int by = (Rsum + rows - 1) / rows;
   if (by > 16384) {
-    rows = (R + 16383) / 16384;
-    by = (R + rows - 1) / rows;
+    rows = (Rsum + 16383) / 16384;
+    by = (Rsum + rows - 1) / rows;
   }
-  hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, R, C,
-                     dA, X, scale, shift, mean, invstd, S, rows);
+  if (Rsum > 0)
+    hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, Rsum,
+                       C, dA, X, scale, shift, mean, invstd, S, rows, groups);
   hipLaunchKernelGGL(bnrelu_backward_apply_kernel, dim3((C / 4 + 31) / 32, (G + 7) / 8), dim3(256), 0, s,
-                     G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)R, gsum);
+                     G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)R, gsum, inv_group,
+                     dX);
   return check_launch("bnrelu_backward");
 }

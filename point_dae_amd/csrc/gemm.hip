@@ -72,6 +72,7 @@ struct NtArgs {
   float* stats;            // [8][2][N]  per-XCD-slot partial sum / sumsq
   float* gmax;             // [M/32][N]  EPI_*GROUPMAX
   unsigned char* garg;     // [M/32][N]
+  const int* a_groups;     // nullable: row m of A is source row a_groups[m/32]*32 + m%32
   int tiles_n, tiles;
 };
 
@@ -109,8 +110,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
   const float* arow[LA];
   const float* brow[LB];
 #pragma unroll
-  for (int i = 0; i < LA; ++i)
-    arow[i] = p.A + (size_t)min(m0 + ((tid + i * NT) >> 3), M - 1) * p.lda + scol;
+  for (int i = 0; i < LA; ++i) {
+    int m = min(m0 + ((tid + i * NT) >> 3), M - 1);
+    if (p.a_groups) m = p.a_groups[m >> 5] * 32 + (m & 31);   // gather whole 32-row groups
+    arow[i] = p.A + (size_t)m * p.lda + scol;
+  }
 #pragma unroll
   for (int i = 0; i < LB; ++i)
     brow[i] = p.B + (size_t)min(n0 + ((tid + i * NT) >> 3), N - 1) * p.ldb + scol;
@@ -303,6 +307,7 @@ struct TnArgs {
   int ldc;
   const float* pro_scale;  // [K]
   const float* pro_shift;
+  const int* b_groups;     // nullable: row m of B is source row b_groups[m/32]*32 + m%32
   int rows_per_split;
 };
 
@@ -351,7 +356,8 @@ __global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(co
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok[i] && gm < mend) {
         if (isb[i]) {
-          v = *reinterpret_cast<const float4*>(p.B + (size_t)gm * p.ldb + k0 + scol[i] - TM);
+          const int sm = p.b_groups ? p.b_groups[gm >> 5] * 32 + (gm & 31) : gm;
+          v = *reinterpret_cast<const float4*>(p.B + (size_t)sm * p.ldb + k0 + scol[i] - TM);
           if (PRO == PRO_BNRELU) {
             v.x = act_relu(v.x * sc[i].x + sh[i].x);
             v.y = act_relu(v.y * sc[i].y + sh[i].y);
@@ -598,7 +604,8 @@ extern "C" int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float*
 extern "C" int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,
                                                const float* scale, const float* shift,
                                                const float* W, const float* bias, float* gmax,
-                                               unsigned char* garg, pdae_stream_t stream) {
+                                               unsigned char* garg, const int32_t* groups,
+                                               pdae_stream_t stream) {
   int rc = check_nt("embed_bnrelu_conv_groupmax: bad size", M, N, K);
   if (rc) return rc;
   if (M % 32 != 0) return bad_arg("embed_bnrelu_conv_groupmax: M must be a multiple of 32");
@@ -607,14 +614,14 @@ extern "C" int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float*
     return bad_arg("embed_bnrelu_conv_groupmax: null pointer");
   NtArgs a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.bias = bias;
-  a.pro_scale = scale, a.pro_shift = shift, a.gmax = gmax, a.garg = garg;
+  a.pro_scale = scale, a.pro_shift = shift, a.gmax = gmax, a.garg = garg, a.a_groups = groups;
   return launch_nt<PRO_BNRELU, EPI_GROUPMAX>(a, as_stream(stream));
 }
 
 extern "C" int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
                                                   const float* X, const float* scale,
                                                   const float* shift, float* dW,
-                                                  pdae_stream_t stream) {
+                                                  const int32_t* groups, pdae_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return bad_arg("bnrelu_linear_backward_weight: bad size");
   if (!dW) return bad_arg("bnrelu_linear_backward_weight: null pointer");
   hipStream_t s = as_stream(stream);
@@ -624,7 +631,8 @@ extern "C" int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const flo
   if (N % 4 != 0 || K % 4 != 0) return unsupported("bnrelu_linear_backward_weight: N, K multiples of 4");
   TnArgs t = {};
   t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
-  t.pro_scale = scale, t.pro_shift = shift;
+  t.pro_scale = scale, t.pro_shift = shift, t.b_groups = groups;
+  if (groups && M % 32 != 0) return bad_arg("bnrelu_linear_backward_weight: M must be a multiple of 32 with a group list");
   return launch_tn(t, true, s);
 }
 

@@ -58,7 +58,8 @@ class PatchEmbedFunction(torch.autograd.Function):
     """points (R,3) + the 12 parameter tensors of Encoder -> tokens (R/32, C)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, first_conv, second_conv, training):
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, first_conv, second_conv, training,
+                groups):
         R = x.shape[0]
         BG = R // 32
         x = x.contiguous()
@@ -93,16 +94,26 @@ class PatchEmbedFunction(torch.autograd.Function):
         else:
             mean2 = var2 = None
         sc2, sh2, mean2, is2 = _bn_affine(second_conv[1], mean2, var2, R, training)
-        # conv4: BN2+ReLU producer, only the group max leaves the kernel
-        tok = _empty((BG, c4), x)
-        arg4 = _empty((BG, c4), x, torch.uint8)
+        # conv4: BN2+ReLU producer, only the group max leaves the kernel.  It comes after the
+        # last BatchNorm, so it is evaluated only for the groups whose tokens are used
+        # (`groups`: the visible patches; masked tokens are discarded by the caller).
+        if groups is not None:
+            Gv = groups.numel()
+            inv = torch.full((BG,), -1, dtype=torch.int32, device=x.device)
+            inv[groups.long()] = torch.arange(Gv, dtype=torch.int32, device=x.device)
+        else:
+            Gv, inv = BG, None
+        Rv = Gv * 32
+        tok = _empty((Gv, c4), x)
+        arg4 = _empty((Gv, c4), x, torch.uint8)
         # the largest GEMM of the step: bench.py's roofline kernel
-        probed('gemm_nt_kernel<128,384,BNRELU,GROUPMAX> patch_embed.second_conv fwd %dx%dx%d' % (R, c4, c3),
-               2.0 * R * c4 * c3,
-               lambda: _lib.call('pdae_embed_bnrelu_conv_groupmax', x, R, c4, c3, _lib.ptr(h3), _lib.ptr(sc2),
-                                 _lib.ptr(sh2), _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4)))
+        probed('gemm_nt_kernel<128,384,BNRELU,GROUPMAX> patch_embed.second_conv[3] fwd %dx%dx%d' % (Rv, c4, c3),
+               2.0 * Rv * c4 * c3,
+               lambda: _lib.call('pdae_embed_bnrelu_conv_groupmax', x, Rv, c4, c3, _lib.ptr(h3), _lib.ptr(sc2),
+                                 _lib.ptr(sh2), _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4),
+                                 _lib.ptr(groups)))
         ctx.save_for_backward(x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
-                              w1m, w2m, wg, wl, w4m, g1, g2)
+                              w1m, w2m, wg, wl, w4m, g1, g2, groups, inv)
         ctx.training = training
         return tok
 
@@ -111,24 +122,29 @@ class PatchEmbedFunction(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError('patch embedder backward is implemented for training-mode BatchNorm')
         (x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
-         w1m, w2m, wg, wl, w4m, g1, g2) = ctx.saved_tensors
+         w1m, w2m, wg, wl, w4m, g1, g2, groups, inv) = ctx.saved_tensors
         R, BG = x.shape[0], x.shape[0] // 32
         c1, c2, c3, c4 = w1m.shape[0], w2m.shape[0], wl.shape[0], w4m.shape[0]
         dtok = dtok.contiguous()
-        # ---- conv4 + max-pool
-        dy4 = _empty((R, c4), x)
-        _lib.call('pdae_group_max_scatter', x, BG, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
+        Gv = dtok.shape[0]                                        # groups that went through conv4
+        Rv = Gv * 32
+        # ---- conv4 + max-pool (compact: only the listed groups carry gradient)
+        dy4 = _empty((Rv, c4), x)
+        _lib.call('pdae_group_max_scatter', x, Gv, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
         db4 = dtok.sum(0)
         dw4 = _empty((c4, c3), x)
-        _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
-                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4))
-        d3 = torch.mm(dy4, w4m)                                   # (R, 512) grad of relu(bn2(h3))
+        _lib.call('pdae_bnrelu_linear_backward_weight', x, Rv, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
+                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), _lib.ptr(groups))
+        d3c = torch.mm(dy4, w4m)                                  # (Rv, 512) grad of relu(bn2(h3)) rows
         del dy4
-        # ---- ReLU + BN2 backward (in place) + per-group sums for the global half
+        # ---- ReLU + BN2 backward + per-group sums for the global half
         S2 = _empty((2, c3), x)
         dgb = _empty((BG, c3), x)
-        _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
-                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb))
+        d3 = _empty((R, c3), x) if groups is not None else d3c
+        _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), Gv,
+                  _lib.ptr(groups), _lib.ptr(inv), _lib.ptr(d3) if groups is not None else None)
+        del d3c
         dbe2, dg2 = S2[0], S2[1]
         # ---- conv3 (split weight)
         dwl = _empty((c3, c2), x)
@@ -143,23 +159,25 @@ class PatchEmbedFunction(torch.autograd.Function):
         # ---- conv2
         dw2 = _empty((c2, c1), x)
         _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c2, c1, _lib.ptr(df), _lib.ptr(y1),
-                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2))
+                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2), None)
         db2 = df.sum(0)
         d1 = torch.mm(df, w2m)                                    # (R, 128)
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)
         S1 = _empty((2, c1), x)
         _lib.call('pdae_bnrelu_backward', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
-                  _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None)
+                  _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None, BG, None, None, None)
         dbe1, dg1 = S1[0], S1[1]
         dw1 = torch.mm(d1.t(), x).unsqueeze(-1)
         db1 = d1.sum(0)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
-                dw4.unsqueeze(-1), db4, None, None, None)
+                dw4.unsqueeze(-1), db4, None, None, None, None)
 
 
-def patch_embed(points, first_conv, second_conv, training):
-    """points (BG, n=32, 3) -> (BG, C)."""
+def patch_embed(points, first_conv, second_conv, training, groups=None):
+    """points (BG, n=32, 3) -> tokens (BG, C), or -- with `groups`, an int32 device
+    tensor of group ids -- the tokens of just those groups (len(groups), C) in list
+    order; BatchNorm statistics always cover all BG groups."""
     BG, n, _ = points.shape
     if n != 32:
         raise NotImplementedError('the fused embedder is written for group_size 32')
@@ -167,4 +185,4 @@ def patch_embed(points, first_conv, second_conv, training):
         points.reshape(BG * n, 3), first_conv[0].weight, first_conv[0].bias, first_conv[1].weight,
         first_conv[1].bias, first_conv[3].weight, first_conv[3].bias, second_conv[0].weight,
         second_conv[0].bias, second_conv[1].weight, second_conv[1].bias, second_conv[3].weight,
-        second_conv[3].bias, first_conv, second_conv, training)
+        second_conv[3].bias, first_conv, second_conv, training, groups)

@@ -59,11 +59,13 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, encoder_channel, 1))
 
-    def forward(self, point_groups):
+    def forward(self, point_groups, groups=None):
+        """(B,G,n,3) -> tokens (B,G,C); with `groups` (int32 flat group ids) only their
+        tokens, as rows (len(groups), C)."""
         bs, g, n, _ = point_groups.shape
         tok = nn_ops.patch_embed(point_groups.reshape(bs * g, n, 3), self.first_conv, self.second_conv,
-                                 self.training)
-        return tok.reshape(bs, g, self.encoder_channel)
+                                 self.training, groups)
+        return tok if groups is not None else tok.reshape(bs, g, self.encoder_channel)
 
 
 class Mlp(nn.Module):
@@ -217,16 +219,18 @@ class MaskTransformer(nn.Module):
         """-> x_vis rows (B*Tvis, C), host bool mask (B,G), (vis_rows, mask_rows) on device.
         `rows` = (vis_rows, mask_rows) already on the device skips the host-side
         mask draw (hipGraph replay: nothing on this path may touch the host)."""
-        tokens = self.encoder(neighborhood)                    # every group is embedded (:437)
-        B, G, C = tokens.shape
+        B, G = center.shape[:2]
         if rows is not None:
             vis_rows, mask_rows = rows
         else:
             if mask is None:
                 mask = self._mask_center_rand(center, noaug=noaug)
-            vis_rows, mask_rows = (r.to(tokens.device) for r in mask_row_ids(mask.cpu()))
+            vis_rows, mask_rows = (r.to(center.device) for r in mask_row_ids(mask.cpu()))
         Tvis = vis_rows.numel() // B
-        x_vis = tokens.reshape(B * G, C).index_select(0, vis_rows)
+        # every group goes through the embedder up to its last BatchNorm (:437); the
+        # final conv + max-pool, whose output the reference computes for all groups and
+        # then drops for the masked ones (:449), runs for the visible groups only
+        x_vis = self.encoder(neighborhood, groups=vis_rows.to(torch.int32))
         pos = nn_ops.pos_embed(center.reshape(B * G, 3).index_select(0, vis_rows), self.pos_embed)
         x_vis = self.blocks(x_vis, pos, B, Tvis)
         return nn_ops.layer_norm(x_vis, self.norm), mask, (vis_rows, mask_rows)
