@@ -205,9 +205,9 @@ def main():
         if kern:
             ach = kern['flops'] / (kern['avg_ms'] * 1e-3) / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'pmc_r01.json')
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_r01.json')   # same kernel, same shape (B=128, G=64)
             if os.path.exists(pmc):            # bytes per launch from the committed rocprofv3 --pmc passes
-                rec = json.load(open(pmc)).get('gemm_nt_kernel<128,384,BNRELU,GROUPMAX>')
+                rec = json.load(open(pmc)).get('gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>')
                 if rec and args.batch == 128 and args.num_group == 64:
                     traffic = rec['hbm_bytes_per_launch']
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

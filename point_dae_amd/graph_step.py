@@ -12,6 +12,7 @@ All graphs share one memory pool (activations of one step, ~6 GB of the 288 GB).
 The gradient all-reduce (world > 1) and the optimiser run right after the
 replay, outside the graph.
 """
+import os
 import torch
 
 from .corrupt_util_tensor import draw_corruption
@@ -21,6 +22,7 @@ from .point_cae_transformer import draw_mask, mask_row_ids
 
 class GraphedTrainStep:
     MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
+    RING = int(os.environ.get("PDAE_RING", "4"))   # staging slots = how many steps the host may run ahead
 
     def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2):
         assert isinstance(model, FlatDataParallel)
@@ -30,11 +32,16 @@ class GraphedTrainStep:
         self.B, self.G = batch_size, self.net.num_group
         self.pts = torch.zeros(batch_size, npoints, 3, device=dev)
         self.steps = torch.zeros(self.MAX_STEPS, batch_size, 10, device=dev)
-        self.steps_host = torch.zeros(self.MAX_STEPS, batch_size, 10).pin_memory()
         self.vis = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
         self.msk = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
-        self.vis_host = torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory()
-        self.msk_host = torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory()
+        # The host runs several steps ahead of the GPU, so the pinned staging buffers of
+        # the draws form a ring; a slot is reused only after the event recorded behind its
+        # H2D copies has completed.
+        self.ring = [dict(steps=torch.zeros(self.MAX_STEPS, batch_size, 10).pin_memory(),
+                          vis=torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory(),
+                          msk=torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory(),
+                          done=None) for _ in range(self.RING)]
+        self.slot = 0
         self.graphs, self.outputs = {}, {}
         self.pool = None
         self.eager_left = warmup_eager
@@ -50,17 +57,23 @@ class GraphedTrainStep:
         mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
         enc.num_mask = int(enc.mask_ratio * self.G)
         n = steps.shape[0]
-        self.steps_host.zero_()
-        self.steps_host[:, :, 1:4] = 1.0                       # identity 'multiply' steps
+        slot = self.ring[self.slot]
+        self.slot = (self.slot + 1) % self.RING
+        if slot['done'] is not None:
+            slot['done'].synchronize()                         # its previous copies have been consumed
+        slot['steps'].zero_()
+        slot['steps'][:, :, 1:4] = 1.0                         # identity 'multiply' steps
         if n:
-            self.steps_host[:n].copy_(steps)
+            slot['steps'][:n].copy_(steps)
         vis_rows, mask_rows = mask_row_ids(mask)
         tvis = vis_rows.numel() // self.B
-        self.vis_host[:vis_rows.numel()].copy_(vis_rows)
-        self.msk_host[:mask_rows.numel()].copy_(mask_rows)
-        self.steps.copy_(self.steps_host, non_blocking=True)
-        self.vis.copy_(self.vis_host, non_blocking=True)
-        self.msk.copy_(self.msk_host, non_blocking=True)
+        slot['vis'][:vis_rows.numel()].copy_(vis_rows)
+        slot['msk'][:mask_rows.numel()].copy_(mask_rows)
+        self.steps.copy_(slot['steps'], non_blocking=True)
+        self.vis.copy_(slot['vis'], non_blocking=True)
+        self.msk.copy_(slot['msk'], non_blocking=True)
+        slot['done'] = torch.cuda.Event()
+        slot['done'].record()
         return tvis
 
     def _fwd_bwd(self, tvis):

@@ -160,19 +160,17 @@ def draw_mask(B, G, mask_ratio, rand_ratio):
         mask_ratio = torch.FloatTensor(1).uniform_(0.5, 0.8).item()
     num_mask = int(mask_ratio * G)
     overall = np.zeros([B, G])
+    overall[:, G - num_mask:] = 1.0
     for i in range(B):
-        m = np.hstack([np.zeros(G - num_mask), np.ones(num_mask)])
-        np.random.shuffle(m)
-        overall[i, :] = m
-    return torch.from_numpy(overall).to(torch.bool), mask_ratio
+        np.random.shuffle(overall[i])        # one global-generator shuffle per sample, as the reference
+    return torch.from_numpy(overall.astype(np.bool_)), mask_ratio
 
 
 def mask_row_ids(mask):
     """Flat row ids (into B*G) of the visible and of the masked groups, each in
     ascending group order per sample -- what tokens[~mask] / tokens[mask] select."""
-    B, G = mask.shape
-    rows = torch.arange(B * G).reshape(B, G)
-    return rows[~mask].reshape(-1), rows[mask].reshape(-1)
+    flat = mask.numpy().reshape(-1)          # numpy: no OpenMP fork/join on the per-step host path
+    return torch.from_numpy(np.flatnonzero(~flat)), torch.from_numpy(np.flatnonzero(flat))
 
 
 class MaskTransformer(nn.Module):
