@@ -81,9 +81,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);
 // dgamma += sum dy*xhat, dbeta += sum dy over this block's rows (LDS, then atomics)
-constexpr int LNB_ROWS = 32;  // rows per block (4 waves x 8)
+// `rows` rows per block (a multiple of 4: one per wave and pass), chosen by the launcher so
+// that the grid covers the chip about twice even at M = 3200 tokens
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
-    int M, int C, const float* __restrict__ dy, const float* __restrict__ x,
+    int M, int C, int rows, const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   float4 ag[LN_MAX4], ab[LN_MAX4];
 #pragma unroll
   for (int i = 0; i < LN_MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
-    const int row = blockIdx.x * LNB_ROWS + rr * 4 + w;
+  for (int rr = 0; rr < rows / 4; ++rr) {
+    const int row = blockIdx.x * rows + rr * 4 + w;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
     float4 gd[LN_MAX4], xh[LN_MAX4];
@@ -309,8 +310,10 @@ extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const floa
   }
   if (M == 0) return check_launch("layernorm_backward");
   if (!dy || !x || !mean || !rstd || !gamma || !dx) return bad_arg("layernorm_backward: null pointer");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256),
-                     2 * C * sizeof(float), s, M, C, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+  int rows = 4 * ((M + 4 * 512 - 1) / (4 * 512));   // ~512 blocks
+  if (rows > 32) rows = 32;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256),
+                     2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
   return check_launch("layernorm_backward");
 }
 
