@@ -248,6 +248,29 @@ int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,
                                           unsigned char* garg,
                                           pdae_stream_t stream);
 
+/*   embed_conv1_stats   first_conv[0] (:24, Conv1d(3, C, 1)) on rows (R,3):
+ *       y[R,C] = x.W^T + bias, evaluated as ((x0*w0 + x1*w1) + x2*w2) + b, and
+ *       stats[0][c] += sum y, stats[1][c] += sum y*y in fp64 (caller zeroes
+ *       stats before the first call; C/4 must divide 256).
+ *   bn_finalize         training-mode nn.BatchNorm1d bookkeeping (:25,:31) in one
+ *       launch: batch mean and biased variance from `stats64` ([2][C] fp64 sums)
+ *       or, when that is null, from `P` fp32 partial sets `partials` [P][2][C]
+ *       (what embed_conv_groupbias_stats leaves); running_mean / running_var
+ *       (unbiased, `momentum`; nullable) and num_batches_tracked (nullable)
+ *       are updated in place; scale = gamma*invstd, shift = beta - mean*scale,
+ *       mean and invstd (C each) are written.                               */
+int pdae_embed_conv1_stats(int R, int C, const float* x, const float* W,
+                           const float* bias /*nullable*/, float* y,
+                           double* stats, pdae_stream_t stream);
+int pdae_bn_finalize(int C, long long rows, const double* stats64 /*nullable*/,
+                     const float* partials /*nullable*/, int P,
+                     const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean /*nullable*/,
+                     float* running_var /*nullable*/,
+                     long long* num_batches_tracked /*nullable*/,
+                     float* scale, float* shift, float* mean, float* invstd,
+                     pdae_stream_t stream);
+
 /* Memory-bound backward passes of the embedder (autograd of torch.max over the
  * 32 points of a group, nn.ReLU and training-mode nn.BatchNorm1d, :26,:32,:47,:50),
  * each a single fused sweep.  G groups of 32 rows, C channels (C % 4 == 0).
@@ -324,6 +347,12 @@ int pdae_scale_residual(int M, int C, int T, const float* a,
                         pdae_stream_t stream);
 int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
                 pdae_stream_t stream);
+/*   scale_colsum        Y = keep[row/T] * X and out[c] (nullable) = column sums
+ *                       of Y: autograd of scale_residual w.r.t. its branch and
+ *                       bias in one pass (DropPath backward, timm drop.py).   */
+int pdae_scale_colsum(int M, int N, int T, const float* X, const float* keep,
+                      float* Y, float* out /*nullable*/, int accumulate,
+                      pdae_stream_t stream);
 /*   bias_gelu_forward   h = GELU(z + bias)            (fc1 epilogue, :104-106)
  *   bias_gelu_backward  dz = dh * GELU'(z + bias), dbias = column sums of dz
  * `accumulate` != 0 (layernorm_backward, colsum, bias_gelu_backward): the small

@@ -278,6 +278,37 @@ __global__ __launch_bounds__(256) void colsum2_kernel(int M, int N, const float*
   }
 }
 
+// Y[m][c] = keep[m/T] * X[m][c] and out[c] += column sums of Y: the backward of
+// scale_residual (DropPath scaling of the branch gradient + the Linear bias gradient) in
+// one pass over the gradient instead of a scaling pass and a column-sum pass.
+__global__ __launch_bounds__(256) void scale_colsum_kernel(int M, int N, int T, const float* __restrict__ X,
+                                                           const float* __restrict__ keep,
+                                                           float* __restrict__ Y, float* __restrict__ out,
+                                                           int rows_per_split) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N)
+    for (int m = mbeg + w; m < mend; m += 4) {
+      float4 v = *reinterpret_cast<const float4*>(X + (size_t)m * N + c);
+      const float k = keep[m / T];
+      v.x *= k, v.y *= k, v.z *= k, v.w *= k;
+      *reinterpret_cast<float4*>(Y + (size_t)m * N + c) = v;
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N && out) {
+    const float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
+    atomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
+    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
+    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
+    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
+  }
+}
+
 }  // namespace pdae
 
 using namespace pdae;
@@ -394,4 +425,19 @@ extern "C" int pdae_colsum(int M, int N, const float* X, float* out, int accumul
   const int rows = (M + bs - 1) / bs;
   hipLaunchKernelGGL(colsum2_kernel, dim3((N + 255) / 256, bs), dim3(256), 0, s, M, N, X, out, rows);
   return check_launch("colsum");
+}
+
+extern "C" int pdae_scale_colsum(int M, int N, int T, const float* X, const float* keep, float* Y,
+                                 float* out, int accumulate, pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || N % 4 != 0 || T <= 0) return bad_arg("scale_colsum: N must be a positive multiple of 4, T > 0");
+  hipStream_t s = as_stream(stream);
+  if (out && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+  if (M == 0) return check_launch("scale_colsum");
+  if (!X || !keep || !Y) return bad_arg("scale_colsum: null pointer");
+  int bs = (M + 31) / 32;
+  if (bs > 1024) bs = 1024;
+  const int rows = (M + bs - 1) / bs;
+  hipLaunchKernelGGL(scale_colsum_kernel, dim3((N + 255) / 256, bs), dim3(256), 0, s, M, N, T, X, keep, Y,
+                     out, rows);
+  return check_launch("scale_colsum");
 }

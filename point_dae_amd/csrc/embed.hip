@@ -139,6 +139,89 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_kernel(
   if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)g * C + c4) = acc;
 }
 
+// First conv of the embedder (K = 3, first_conv[0]) with BatchNorm's batch statistics:
+//   y[m][c] = ((x0*w[c][0] + x1*w[c][1]) + x2*w[c][2]) + b[c];  stats[0][c] += sum_m y,
+//   stats[1][c] += sum_m y*y  (fp32 per-thread partials over 64 rows, then fp64 atomics).
+// Thread = 4 adjacent channels of one row phase; weights stay in registers; the pass is
+// bound by the (R, C) store.
+constexpr int C1_ROWS = 512;   // rows per block
+__global__ __launch_bounds__(256) void conv1_stats_kernel(int R, int C, const float* __restrict__ x,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, double* __restrict__ stats) {
+  extern __shared__ float red[];             // [phases][2][C]
+  const int q = C >> 2;                      // channel quads
+  const int phases = 256 / q;                // row phases per block
+  const int cq = threadIdx.x % q, ph = threadIdx.x / q;
+  const int c = cq * 4;
+  float w[4][3], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w[j][0] = W[(c + j) * 3 + 0], w[j][1] = W[(c + j) * 3 + 1], w[j][2] = W[(c + j) * 3 + 2];
+    b[j] = bias ? bias[c + j] : 0.f;
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int mbeg = blockIdx.x * C1_ROWS, mend = min(R, mbeg + C1_ROWS);
+  if (ph < phases)
+    for (int m = mbeg + ph; m < mend; m += phases) {
+      const float x0 = x[(size_t)m * 3], x1 = x[(size_t)m * 3 + 1], x2 = x[(size_t)m * 3 + 2];
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = ((x0 * w[j][0] + x1 * w[j][1]) + x2 * w[j][2]) + b[j];
+        s1[j] += v[j];
+        s2[j] += v[j] * v[j];
+      }
+      *reinterpret_cast<float4*>(y + (size_t)m * C + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  if (ph < phases) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[(ph * 2 + 0) * C + c + j] = s1[j];
+      red[(ph * 2 + 1) * C + c + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    double t = 0.0;
+    for (int p = 0; p < phases; ++p) t += (double)red[p * 2 * C + i];
+    atomicAdd(stats + i, t);
+  }
+}
+
+// Training-mode nn.BatchNorm1d bookkeeping in one launch: batch mean / biased variance
+// from the accumulated sums (fp64 sums, or P fp32 partial sets), running estimates
+// (unbiased variance, momentum), the update counter, and the affine y = x*scale + shift.
+__global__ void bn_finalize_kernel(int C, double rows, const double* __restrict__ st64,
+                                   const float* __restrict__ part, int P,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, long long* __restrict__ counter,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && counter) *counter += 1;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  if (st64) {
+    s1 = st64[c], s2 = st64[C + c];
+  } else {
+    for (int p = 0; p < P; ++p) s1 += (double)part[(p * 2 + 0) * C + c], s2 += (double)part[(p * 2 + 1) * C + c];
+  }
+  const double mu = s1 / rows;
+  double var = s2 / rows - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float m = (float)mu, v = (float)var;
+  const float is = 1.0f / sqrtf(v + eps);
+  if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * m;
+  if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(var * (rows / (rows > 1.0 ? rows - 1.0 : 1.0)));
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - m * sc;
+  mean[c] = m;
+  invstd[c] = is;
+}
+
 }  // namespace pdae
 
 using namespace pdae;
@@ -195,4 +278,30 @@ extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, con
                      G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)R, gsum, inv_group,
                      dX);
   return check_launch("bnrelu_backward");
+}
+
+extern "C" int pdae_embed_conv1_stats(int R, int C, const float* x, const float* W, const float* bias,
+                                      float* y, double* stats, pdae_stream_t stream) {
+  if (R < 0 || C <= 0 || C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0)
+    return bad_arg("embed_conv1_stats: C/4 must divide 256");
+  if (R == 0) return PDAE_OK;
+  if (!x || !W || !y || !stats) return bad_arg("embed_conv1_stats: null pointer");
+  const int phases = 256 / (C / 4);
+  hipLaunchKernelGGL(conv1_stats_kernel, dim3((R + C1_ROWS - 1) / C1_ROWS), dim3(256),
+                     sizeof(float) * phases * 2 * C, as_stream(stream), R, C, x, W, bias, y, stats);
+  return check_launch("embed_conv1_stats");
+}
+
+extern "C" int pdae_bn_finalize(int C, long long rows, const double* stats64, const float* partials, int P,
+                                const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                float* scale, float* shift, float* mean, float* invstd,
+                                pdae_stream_t stream) {
+  if (C <= 0 || rows <= 0) return bad_arg("bn_finalize: C and rows must be positive");
+  if ((!stats64 && (!partials || P <= 0)) || !gamma || !beta || !scale || !shift || !mean || !invstd)
+    return bad_arg("bn_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C,
+                     (double)rows, stats64, partials, P, gamma, beta, eps, momentum, running_mean,
+                     running_var, num_batches_tracked, scale, shift, mean, invstd);
+  return check_launch("bn_finalize");
 }

@@ -13,46 +13,13 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from .arena import ZeroArena, arena, begin_step  # noqa: F401
 from .patch_embed import patch_embed  # noqa: F401  (fused gfx950 embedder)
 from .probe import Probe, set_probe  # noqa: F401
 
 
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
-
-
-class ZeroArena:
-    """One pre-zeroed device buffer per step for the small reduction outputs of
-    the backward (LayerNorm dgamma/dbeta, bias gradients): `reset()` is ONE
-    memset at the start of a step, kernels then accumulate into `take()`n slices
-    (accumulate=1) instead of each issuing its own memset node (~110 per step)."""
-
-    def __init__(self, numel=1 << 20):
-        self.numel, self.buf, self.used = numel, None, 0
-
-    def reset(self, device):
-        if self.buf is None or self.buf.device != device:
-            self.buf = torch.zeros(self.numel, device=device)
-        else:
-            self.buf.zero_()
-        self.used = 0
-
-    def take(self, n, like):
-        """-> (zeroed float tensor of n elements, came_from_arena)"""
-        n_pad = (n + 63) & ~63
-        if self.buf is None or self.buf.device != like.device or self.used + n_pad > self.numel:
-            return torch.zeros(n, device=like.device), True
-        t = self.buf[self.used:self.used + n]
-        self.used += n_pad
-        return t, True
-
-
-arena = ZeroArena()
-
-
-def begin_step(device):
-    """Call once at the start of a forward pass (the models do)."""
-    arena.reset(device)
 
 
 def _colsum(x):
@@ -203,11 +170,12 @@ class _ScaleResidual(torch.autograd.Function):
         M, C = dy.shape
         if keep is not None:
             da = torch.empty_like(dy)
-            _lib.call('pdae_scale_residual', dy, M, C, ctx.T, _lib.ptr(dy), None, _lib.ptr(keep), None,
-                      _lib.ptr(da))
+            dbias = arena.take(C, dy)[0] if ctx.has_bias else None
+            _lib.call('pdae_scale_colsum', dy, M, C, ctx.T, _lib.ptr(dy), _lib.ptr(keep), _lib.ptr(da),
+                      _lib.ptr(dbias), 1)
         else:
             da = dy
-        dbias = _colsum(da) if ctx.has_bias else None
+            dbias = _colsum(da) if ctx.has_bias else None
         return da, dbias, None, dy, None
 
 

@@ -29,11 +29,28 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from .arena import arena
 from .probe import probed
 
 
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _bn_finalize(bn, rows, like, stats64=None, partials=None):
+    """Training-mode BatchNorm bookkeeping in one launch (csrc/embed.hip bn_finalize):
+    -> scale, shift, mean, invstd; updates the running estimates and the counter."""
+    C = bn.weight.numel()
+    scale, shift, mean, invstd = (_empty((C,), like) for _ in range(4))
+    m = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats and bn.running_mean is not None
+    _lib.call('pdae_bn_finalize', like, C, rows, _lib.ptr(stats64), _lib.ptr(partials),
+              partials.shape[0] if partials is not None else 0, _lib.ptr(bn.weight), _lib.ptr(bn.bias),
+              float(bn.eps), float(m), _lib.ptr(bn.running_mean) if track else None,
+              _lib.ptr(bn.running_var) if track else None,
+              _lib.ptr(bn.num_batches_tracked) if track else None,
+              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd))
+    return scale, shift, mean, invstd
 
 
 def _bn_affine(bn, mean, var_biased, rows, training):
@@ -67,12 +84,15 @@ class PatchEmbedFunction(torch.autograd.Function):
         w3m, w4m = w3.squeeze(-1), w4.squeeze(-1).contiguous()
         c1, c2, c3, c4 = w1m.shape[0], w2m.shape[0], w3m.shape[0], w4m.shape[0]
         # conv1 (K = 3) + BN1 statistics
-        y1 = F.linear(x, w1m, b1)
         if training:
-            var1, mean1 = torch.var_mean(y1, dim=0, unbiased=False)
+            y1 = _empty((R, c1), x)
+            st1 = arena.take(4 * c1, x)[0].view(torch.float64)      # [2][c1] fp64 sums, pre-zeroed
+            _lib.call('pdae_embed_conv1_stats', x, R, c1, _lib.ptr(x), _lib.ptr(w1m.contiguous()), _lib.ptr(b1),
+                      _lib.ptr(y1), _lib.ptr(st1))
+            sc1, sh1, mean1, is1 = _bn_finalize(first_conv[1], R, x, stats64=st1)
         else:
-            var1 = mean1 = None
-        sc1, sh1, mean1, is1 = _bn_affine(first_conv[1], mean1, var1, R, training)
+            y1 = F.linear(x, w1m, b1)
+            sc1, sh1, mean1, is1 = _bn_affine(first_conv[1], None, None, R, False)
         # conv2: BN1+ReLU producer, store f, group max
         f = _empty((R, c2), x)
         g = _empty((BG, c2), x)
@@ -91,12 +111,9 @@ class PatchEmbedFunction(torch.autograd.Function):
                lambda: _lib.call('pdae_embed_conv_groupbias_stats', x, R, c3, c2, _lib.ptr(f), _lib.ptr(wl),
                                  _lib.ptr(gb), _lib.ptr(h3), _lib.ptr(stats)))
         if training:
-            s = stats.sum(0)
-            mean2 = s[0] / R
-            var2 = (s[1] / R - mean2 * mean2).clamp_min_(0.)
+            sc2, sh2, mean2, is2 = _bn_finalize(second_conv[1], R, x, partials=stats)
         else:
-            mean2 = var2 = None
-        sc2, sh2, mean2, is2 = _bn_affine(second_conv[1], mean2, var2, R, training)
+            sc2, sh2, mean2, is2 = _bn_affine(second_conv[1], None, None, R, False)
         # conv4: BN2+ReLU producer, only the group max leaves the kernel.  It comes after the
         # last BatchNorm, so it is evaluated only for the groups whose tokens are used
         # (`groups`: the visible patches; masked tokens are discarded by the caller).
