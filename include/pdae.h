@@ -230,6 +230,7 @@ int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,
 int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
                                        const float* X, const float* scale,
                                        const float* shift, float* dW,
+                                       float* dbias /*nullable: column sums of dY*/,
                                        const int32_t* groups /*nullable*/,
                                        pdae_stream_t stream);
 /* `groups` (embed_bnrelu_conv_groupmax, bnrelu_linear_backward_weight,

@@ -34,7 +34,7 @@ _SIGNATURES = {
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pdae_bnrelu_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_group_max_scatter": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_group_scatter_add": [_i, _i, _vp, _vp, _vp, _vp],

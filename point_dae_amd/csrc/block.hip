@@ -80,75 +80,98 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) (+ dres);
-// dgamma += sum dy*xhat, dbeta += sum dy over this block's rows (LDS, then atomics)
-// `rows` rows per block (a multiple of 4: one per wave and pass), chosen by the launcher so
-// that the grid covers the chip about twice even at M = 3200 tokens
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+// dgamma += sum dy*xhat, dbeta += sum dy over this block's rows (LDS, then atomics).
+// One wave per row, NS float4 slots per lane (C <= 256*NS), NW waves per block, `rows`
+// rows per block (a multiple of NW).  The pass is latency-bound, not bandwidth-bound
+// (12-50 MB per launch): every load of a row -- dy, x, the skip gradient -- is issued
+// before the first reduction and gamma stays in registers across rows.  The 2*C global
+// atomics per BLOCK are what the launch pays for (device-scope float atomics run at
+// ~28 G/s on 24 cache lines: 2048 blocks cost 55 us, 128 blocks 3 us), hence 16-wave
+// blocks: few blocks, many rows in flight per CU.
+template <int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     int M, int C, int rows, const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  extern __shared__ float red[];  // [2][C]
-  for (int c = threadIdx.x; c < 2 * C; c += 256) red[c] = 0.f;
-  __syncthreads();
+  extern __shared__ float red[];  // [NW][2][C]: one plain-store slot per wave (LDS float
+                                  // atomics serialise: 256 of them cost 12 us per block)
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const int n4 = C >> 2;
-  float4 ag[LN_MAX4], ab[LN_MAX4];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ag[NS], ab[NS], g[NS];
 #pragma unroll
-  for (int i = 0; i < LN_MAX4; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int rr = 0; rr < rows / 4; ++rr) {
-    const int row = blockIdx.x * rows + rr * 4 + w;
-    if (row >= M) break;
-    const float mu = mean[row], rs = rstd[row];
-    float4 gd[LN_MAX4], xh[LN_MAX4];
-    float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < NS; ++i) {
+    ag[i] = ab[i] = zero4;
+    const int c4 = lane + i * kWave;
+    g[i] = c4 < n4 ? *reinterpret_cast<const float4*>(gamma + c4 * 4) : zero4;
+  }
+  float4 d[NS], xv[NS], e[NS];
+  float mu = 0.f, rs = 0.f;
+  auto load_row = [&](int row) {
 #pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) {
+    for (int i = 0; i < NS; ++i) {
       const int c4 = lane + i * kWave;
-      if (c4 < n4) {
-        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * C + c4 * 4);
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * C + c4 * 4);
-        const float4 g = *reinterpret_cast<const float4*>(gamma + c4 * 4);
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
-        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
-        ag[i].x += d.x * xh[i].x, ag[i].y += d.y * xh[i].y, ag[i].z += d.z * xh[i].z, ag[i].w += d.w * xh[i].w;
-        ab[i].x += d.x, ab[i].y += d.y, ab[i].z += d.z, ab[i].w += d.w;
-      }
+      const bool on = c4 < n4 && row < M;
+      const size_t off = (size_t)row * C + c4 * 4;
+      d[i] = on ? *reinterpret_cast<const float4*>(dy + off) : zero4;
+      xv[i] = on ? *reinterpret_cast<const float4*>(x + off) : zero4;
+      e[i] = (on && dres) ? *reinterpret_cast<const float4*>(dres + off) : zero4;
     }
+    mu = row < M ? mean[row] : 0.f;
+    rs = row < M ? rstd[row] : 0.f;
+  };
+  const int row0 = blockIdx.x * rows + w;
+  load_row(row0);
+  for (int rr = 0; rr < rows / NW; ++rr) {
+    const int row = row0 + rr * NW;
+    if (row >= M) break;
+    float4 gd[NS], xh[NS];
+    float s1 = 0.f, s2 = 0.f;
+    const float rs_ = rs;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      // (slots past the row hold zeros: xh = -mu*rs there, but d = gd = 0 keeps every sum exact)
+      xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+      gd[i] = make_float4(d[i].x * g[i].x, d[i].y * g[i].y, d[i].z * g[i].z, d[i].w * g[i].w);
+      s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+      s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+      ag[i].x += d[i].x * xh[i].x, ag[i].y += d[i].y * xh[i].y, ag[i].z += d[i].z * xh[i].z, ag[i].w += d[i].w * xh[i].w;
+      ab[i].x += d[i].x, ab[i].y += d[i].y, ab[i].z += d[i].z, ab[i].w += d[i].w;
+    }
+    float4 sk[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) sk[i] = e[i];
+    if (rr + 1 < rows / NW) load_row(row + NW);      // next row's loads fly during the reductions
     const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) {
+    for (int i = 0; i < NS; ++i) {
       const int c4 = lane + i * kWave;
       if (c4 < n4) {
         float4 o;
-        o.x = rs * (gd[i].x - m1 - xh[i].x * m2);
-        o.y = rs * (gd[i].y - m1 - xh[i].y * m2);
-        o.z = rs * (gd[i].z - m1 - xh[i].z * m2);
-        o.w = rs * (gd[i].w - m1 - xh[i].w * m2);
-        if (dres) {
-          const float4 e = *reinterpret_cast<const float4*>(dres + (size_t)row * C + c4 * 4);
-          o.x += e.x, o.y += e.y, o.z += e.z, o.w += e.w;
-        }
+        o.x = rs_ * (gd[i].x - m1 - xh[i].x * m2) + sk[i].x;
+        o.y = rs_ * (gd[i].y - m1 - xh[i].y * m2) + sk[i].y;
+        o.z = rs_ * (gd[i].z - m1 - xh[i].z * m2) + sk[i].z;
+        o.w = rs_ * (gd[i].w - m1 - xh[i].w * m2) + sk[i].w;
         *reinterpret_cast<float4*>(dx + (size_t)row * C + c4 * 4) = o;
       }
     }
   }
+  float* mine = red + (size_t)w * 2 * C;
 #pragma unroll
-  for (int i = 0; i < LN_MAX4; ++i) {
+  for (int i = 0; i < NS; ++i) {
     const int c4 = lane + i * kWave;
     if (c4 < n4) {
-      atomicAdd(&red[c4 * 4 + 0], ag[i].x), atomicAdd(&red[c4 * 4 + 1], ag[i].y);
-      atomicAdd(&red[c4 * 4 + 2], ag[i].z), atomicAdd(&red[c4 * 4 + 3], ag[i].w);
-      atomicAdd(&red[C + c4 * 4 + 0], ab[i].x), atomicAdd(&red[C + c4 * 4 + 1], ab[i].y);
-      atomicAdd(&red[C + c4 * 4 + 2], ab[i].z), atomicAdd(&red[C + c4 * 4 + 3], ab[i].w);
+      *reinterpret_cast<float4*>(mine + c4 * 4) = ag[i];
+      *reinterpret_cast<float4*>(mine + C + c4 * 4) = ab[i];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, red[c]);
-    atomicAdd(dbeta + c, red[C + c]);
+  for (int c = threadIdx.x; c < 2 * C; c += NW * 64) {
+    float t = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < NW; ++k) t += red[(size_t)k * 2 * C + c];
+    atomicAdd((c < C ? dgamma : dbeta - C) + c, t);
   }
 }
 
@@ -341,10 +364,19 @@ extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const floa
   }
   if (M == 0) return check_launch("layernorm_backward");
   if (!dy || !x || !mean || !rstd || !gamma || !dx) return bad_arg("layernorm_backward: null pointer");
-  int rows = 4 * ((M + 4 * 512 - 1) / (4 * 512));   // ~512 blocks
-  if (rows > 32) rows = 32;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256),
-                     2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+  if (C <= 512) {
+    // 16-wave blocks, one row per wave (two from 6144 rows on: fewer blocks = fewer atomics);
+    // measured 13 us at M = 2944 and 20 us at M = 8192 (was 24 / 29 us with LDS atomics)
+    const int per_wave = M >= 6144 ? 2 : 1;
+    const int rows = 16 * per_wave;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
+                       16 * 2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+  } else {
+    int rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
+    if (rows > 32) rows = 32;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3((M + rows - 1) / rows), dim3(256),
+                       4 * 2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+  }
   return check_launch("layernorm_backward");
 }
 

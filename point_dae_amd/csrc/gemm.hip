@@ -308,13 +308,15 @@ struct TnArgs {
   const float* pro_scale;  // [K]
   const float* pro_shift;
   const int* b_groups;     // nullable: row m of B is source row b_groups[m/32]*32 + m%32
+  float* colsum_a;         // nullable: [N] += column sums of A (the bias gradient), from the k-tile-0 blocks
   int rows_per_split;
 };
 
 // Block tile TM (columns n of A) x TN_ (columns k of B); every wave 64x64.  Bigger
 // tiles = fewer bytes staged per MAC (the 128x128 version ran at 69 TFLOP/s).
 template <int TM, int TN_, int PRO>
-__global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(const TnArgs p) {
+__global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void gemm_tn_kernel(const TnArgs p) {
   constexpr int WN = TN_ / 64;
   constexpr int NT = (TM / 64) * (TN_ / 64) * 64;
   constexpr int ROW4 = (TM + TN_) / 4;              // float4 per staged row
@@ -346,6 +348,8 @@ __global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(co
   const int ld = isb ? p.ldb : p.lda;
   const int* grp = isb ? p.b_groups : nullptr;
   float4 rg[SLOTS];
+  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of this thread's A elements
+  const bool sum_a = p.colsum_a != nullptr && blockIdx.x == 0 && !isb;
   auto gload = [&](int mt) {
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
@@ -362,6 +366,7 @@ __global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(co
         }
       }
       rg[i] = v;
+      if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
     }
   };
   auto lstore = [&](int buf) {
@@ -415,6 +420,10 @@ __global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(co
     __syncthreads();
     buf ^= 1;
   }
+  if (sum_a && ok) {
+    atomicAdd(p.colsum_a + gcol + 0, asum.x), atomicAdd(p.colsum_a + gcol + 1, asum.y);
+    atomicAdd(p.colsum_a + gcol + 2, asum.z), atomicAdd(p.colsum_a + gcol + 3, asum.w);
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = k0 + wn * 64 + j * 32 + r;
@@ -428,24 +437,6 @@ __global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) void gemm_tn_kernel(co
       }
     }
   }
-}
-
-// out[c] += sum_m X[m, c]  (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ X,
-                                                     int ldx, float* __restrict__ out,
-                                                     int rows_per_split) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
-  float s = 0.f;
-  if (c < N)
-    for (int m = mbeg + w; m < mend; m += 4) s += X[(size_t)m * ldx + c];
-  part[w][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (w == 0 && c < N)
-    atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
-                           part[3][threadIdx.x]);
 }
 
 template <int BM, int BN, int PRO, int EPI>
@@ -517,8 +508,10 @@ template <int TM, int TN_>
 static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
   const int tn = (t.N + TM - 1) / TM, tk = (t.K + TN_ - 1) / TN_;
   constexpr int NTH = (TM / 64) * (TN_ / 64) * 64;
-  // enough M-splits to cover the chip about four times, each at least 256 rows
-  int splits = (4 * 256 + tn * tk - 1) / (tn * tk);
+  // M-splits so that the grid is ONE full residency of the chip (256 CUs x 3 blocks):
+  // 768 blocks ran dW4 in 576 us, 1024 blocks (1.33 rounds) in 663 us; each split >= 256 rows
+  int splits = (3 * 256 + tn * tk / 2) / (tn * tk);
+  if (splits < 1) splits = 1;
   int rows = (t.M + splits - 1) / splits;
   rows = ((rows + TBK - 1) / TBK) * TBK;
   if (rows < 256) rows = 256;
@@ -549,16 +542,8 @@ extern "C" int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
   if (N % 4 != 0 || K % 4 != 0) return unsupported("linear_backward_weight: N, K multiples of 4");
   TnArgs t = {};
   t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
-  int rc = launch_tn(t, false, s);
-  if (rc) return rc;
-  if (dbias) {
-    int bs = (M + 4095) / 4096;
-    if (bs > 1024) bs = 1024;
-    const int brows = (M + bs - 1) / bs;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, bs), dim3(256), 0, s, M, N, dY, N, dbias,
-                       brows);
-  }
-  return check_launch("linear_backward_weight");
+  t.colsum_a = dbias;      // the bias gradient rides on the A tiles the k-tile-0 blocks stage anyway
+  return launch_tn(t, false, s);
 }
 
 // ---- fused patch-embedder layers (models/PointCAE_transformer.py:37-51) ------
@@ -612,18 +597,19 @@ extern "C" int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float*
 
 extern "C" int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const float* dY,
                                                   const float* X, const float* scale,
-                                                  const float* shift, float* dW,
+                                                  const float* shift, float* dW, float* dbias,
                                                   const int32_t* groups, pdae_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return bad_arg("bnrelu_linear_backward_weight: bad size");
   if (!dW) return bad_arg("bnrelu_linear_backward_weight: null pointer");
   hipStream_t s = as_stream(stream);
   (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+  if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("bnrelu_linear_backward_weight");
   if (!dY || !X || !scale || !shift) return bad_arg("bnrelu_linear_backward_weight: null pointer");
   if (N % 4 != 0 || K % 4 != 0) return unsupported("bnrelu_linear_backward_weight: N, K multiples of 4");
   TnArgs t = {};
   t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
-  t.pro_scale = scale, t.pro_shift = shift, t.b_groups = groups;
+  t.pro_scale = scale, t.pro_shift = shift, t.b_groups = groups, t.colsum_a = dbias;
   if (groups && M % 32 != 0) return bad_arg("bnrelu_linear_backward_weight: M must be a multiple of 32 with a group list");
   return launch_tn(t, true, s);
 }

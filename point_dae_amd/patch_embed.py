@@ -151,7 +151,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         db4 = dtok.sum(0)
         dw4 = _empty((c4, c3), x)
         _lib.call('pdae_bnrelu_linear_backward_weight', x, Rv, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
-                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), _lib.ptr(groups))
+                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), None, _lib.ptr(groups))
         d3c = torch.mm(dy4, w4m)                                  # (Rv, 512) grad of relu(bn2(h3)) rows
         del dy4
         # ---- ReLU + BN2 backward + per-group sums for the global half
@@ -175,9 +175,9 @@ class PatchEmbedFunction(torch.autograd.Function):
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
         dw2 = _empty((c2, c1), x)
+        db2 = _empty((c2,), x)                                    # column sums of df, from the same kernel
         _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c2, c1, _lib.ptr(df), _lib.ptr(y1),
-                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2), None)
-        db2 = df.sum(0)
+                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2), _lib.ptr(db2), None)
         d1 = torch.mm(df, w2m)                                    # (R, 128)
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)

@@ -126,9 +126,11 @@ def test_embed_bnrelu_conv_groupmax(G, N, K):
     # weight gradient with the activation recomputed in the producer
     dy = torch.randn(M, N, device='cuda', generator=g)
     dw = torch.empty(N, K, device='cuda')
+    db = torch.empty(N, device='cuda')
     L.call('pdae_bnrelu_linear_backward_weight', x, M, N, K, dy.data_ptr(), x.data_ptr(), sc.data_ptr(),
-           sh.data_ptr(), dw.data_ptr(), None)
+           sh.data_ptr(), dw.data_ptr(), db.data_ptr(), None)
     _close(dw, (dy.double().t() @ a.double()).float(), 5e-5)
+    _close(db, dy.double().sum(0).float(), 5e-5)       # bias gradient from the same kernel
     # group list: only some groups go through the layer, outputs compact in list order
     sel = torch.randperm(G, device='cuda', generator=g)[:max(1, G // 3)].sort()[0].to(torch.int32)
     Gs = sel.numel()
@@ -139,7 +141,7 @@ def test_embed_bnrelu_conv_groupmax(G, N, K):
     assert torch.equal(gm2, gm[sel.long()]) and torch.equal(ga2, ga[sel.long()])
     dyc = torch.randn(Gs * 32, N, device='cuda', generator=g)
     L.call('pdae_bnrelu_linear_backward_weight', x, Gs * 32, N, K, dyc.data_ptr(), x.data_ptr(), sc.data_ptr(),
-           sh.data_ptr(), dw.data_ptr(), sel.data_ptr())
+           sh.data_ptr(), dw.data_ptr(), None, sel.data_ptr())
     a_sel = a.reshape(G, 32, K)[sel.long()].reshape(Gs * 32, K)
     _close(dw, (dyc.double().t() @ a_sel.double()).float(), 5e-5)
 
@@ -191,9 +193,14 @@ def test_fused_patch_embed_matches_pytorch(BG):
             continue
         e_mine = (a.grad.double() - c.grad).abs().max().item() / scale
         e_t32 = (b.grad.double() - c.grad).abs().max().item() / scale
-        # (an arg-max that flips between fp32 and fp64 reroutes one element's gradient: then
-        #  PyTorch's own fp32 path shows the same percent-level distance and bounds ours)
-        assert (e_mine <= 1e-2 or e_mine <= 1.5 * e_t32) and e_mine <= 5 * e_t32 + 3e-3, (tuple(a.shape), e_mine, e_t32)
+        l2_mine = ((a.grad.double() - c.grad).norm() / c.grad.norm()).item()
+        # An arg-max that flips between an fp32 path and fp64 (near-tied rows of a patch) reroutes
+        # one element's gradient: a percent-level spike in the max norm of either fp32 path, nothing
+        # in the L2 norm.  Max norm as tight as PyTorch's own fp32 path, or L2-tight with a bounded spike.
+        ok_max = e_mine <= 1e-2 and e_mine <= 5 * e_t32 + 3e-3
+        ok_l2 = l2_mine <= 2e-3 and e_mine <= 5e-2
+        ok_like_torch = e_mine <= 1.5 * e_t32 and e_mine <= 5e-2      # PyTorch's fp32 path has the same flip
+        assert ok_max or ok_l2 or ok_like_torch, (tuple(a.shape), e_mine, e_t32, l2_mine)
     for a, b in zip(list(first.buffers()) + list(second.buffers()), list(first_d.buffers()) + list(second_d.buffers())):
         assert torch.allclose(a.double(), b.double(), rtol=1e-4, atol=1e-5)
     # visible-groups path == all groups + selection, forward and backward
