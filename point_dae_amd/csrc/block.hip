@@ -196,21 +196,43 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(long long n4, int C4
   h[i] = make_float4(gelu_f(v.x + b.x), gelu_f(v.y + b.y), gelu_f(v.z + b.z), gelu_f(v.w + b.w));
 }
 
-// one block = 64 column-quads x 4 row phases over a slab of rows
-__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(int M, int C, const float* __restrict__ z,
+// Column-reducing sweeps (bias_gelu_bwd, scale_colsum, colsum2): one block = 64 column
+// quads x CS_NW row phases over a slab of CS_ROWS rows.  16 waves with 4 independent rows
+// each keep enough loads in flight (these passes are latency-bound at M = 3-8 k rows) while
+// the block count -- the number of global atomics -- stays small.
+constexpr int CS_NW = 16, CS_ROWS = 4 * CS_NW;
+__device__ __forceinline__ void colsum_finish(float4 s, float4 (*part)[64], float* __restrict__ out, int c,
+                                              int N) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < N && out) {
+    float4 t = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < CS_NW; ++k) {
+      const float4 u = part[k][lane];
+      t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+    }
+    atomicAdd(out + c + 0, t.x), atomicAdd(out + c + 1, t.y);
+    atomicAdd(out + c + 2, t.z), atomicAdd(out + c + 3, t.w);
+  }
+}
+
+__global__ __launch_bounds__(CS_NW * 64) void bias_gelu_bwd_kernel(int M, int C, const float* __restrict__ z,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ dh,
                                                             float* __restrict__ dz,
                                                             float* __restrict__ dbias,
                                                             int rows_per_split) {
-  __shared__ float4 part[4][64];
+  __shared__ float4 part[CS_NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
     const float4 b = *reinterpret_cast<const float4*>(bias + c);
-    for (int m = mbeg + w; m < mend; m += 4) {
+#pragma unroll 4
+    for (int m = mbeg + w; m < mend; m += CS_NW) {
       const float4 v = *reinterpret_cast<const float4*>(z + (size_t)m * C + c);
       const float4 d = *reinterpret_cast<const float4*>(dh + (size_t)m * C + c);
       float4 o;
@@ -222,15 +244,7 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(int M, int C, const 
       s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
     }
   }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < C) {
-    const float4 a = part[0][lane], b2 = part[1][lane], d2 = part[2][lane], e = part[3][lane];
-    atomicAdd(dbias + c + 0, (a.x + b2.x) + (d2.x + e.x));
-    atomicAdd(dbias + c + 1, (a.y + b2.y) + (d2.y + e.y));
-    atomicAdd(dbias + c + 2, (a.z + b2.z) + (d2.z + e.z));
-    atomicAdd(dbias + c + 3, (a.w + b2.w) + (d2.w + e.w));
-  }
+  colsum_finish(s, part, dbias, c, C);
 }
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(long long n4, const float4* __restrict__ z,
@@ -277,64 +291,60 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(long long n4, int C
   y[i] = v;
 }
 
-// out[c] += sum over a slab of rows; lane owns 4 adjacent columns, 4 waves stride the rows
-__global__ __launch_bounds__(256) void colsum2_kernel(int M, int N, const float* __restrict__ X,
-                                                      float* __restrict__ out, int rows_per_split) {
-  __shared__ float4 part[4][64];
+// out[c] += sum over a slab of rows; lane owns 4 adjacent columns, the waves stride the rows
+__global__ __launch_bounds__(CS_NW * 64) void colsum2_kernel(int M, int N, const float* __restrict__ X,
+                                                             float* __restrict__ out, int rows_per_split) {
+  __shared__ float4 part[CS_NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < N)
-    for (int m = mbeg + w; m < mend; m += 4) {
+  if (c < N) {
+#pragma unroll 4
+    for (int m = mbeg + w; m < mend; m += CS_NW) {
       const float4 v = *reinterpret_cast<const float4*>(X + (size_t)m * N + c);
       s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < N) {
-    const float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
-    atomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
-    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
-    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
-    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
   }
+  colsum_finish(s, part, out, c, N);
 }
 
 // Y[m][c] = keep[m/T] * X[m][c] and out[c] += column sums of Y: the backward of
 // scale_residual (DropPath scaling of the branch gradient + the Linear bias gradient) in
 // one pass over the gradient instead of a scaling pass and a column-sum pass.
-__global__ __launch_bounds__(256) void scale_colsum_kernel(int M, int N, int T, const float* __restrict__ X,
-                                                           const float* __restrict__ keep,
-                                                           float* __restrict__ Y, float* __restrict__ out,
-                                                           int rows_per_split) {
-  __shared__ float4 part[4][64];
+__global__ __launch_bounds__(CS_NW * 64) void scale_colsum_kernel(int M, int N, int T,
+                                                                  const float* __restrict__ X,
+                                                                  const float* __restrict__ keep,
+                                                                  float* __restrict__ Y, float* __restrict__ out,
+                                                                  int rows_per_split) {
+  __shared__ float4 part[CS_NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
   const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < N)
-    for (int m = mbeg + w; m < mend; m += 4) {
+  if (c < N) {
+#pragma unroll 4
+    for (int m = mbeg + w; m < mend; m += CS_NW) {
       float4 v = *reinterpret_cast<const float4*>(X + (size_t)m * N + c);
       const float k = keep[m / T];
       v.x *= k, v.y *= k, v.z *= k, v.w *= k;
       *reinterpret_cast<float4*>(Y + (size_t)m * N + c) = v;
       s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < N && out) {
-    const float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
-    atomicAdd(out + c + 0, (a.x + b.x) + (d.x + e.x));
-    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
-    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
-    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
   }
+  colsum_finish(s, part, out, c, N);
 }
 
 }  // namespace pdae
 
 using namespace pdae;
+
+// rows per block of the column-reducing sweeps: CS_ROWS, more once that would exceed 2048 row slabs
+static int cs_rows(int M) {
+  int rows = CS_ROWS;
+  if ((M + rows - 1) / rows > 2048) rows = CS_NW * ((M + 2048 * CS_NW - 1) / (2048 * CS_NW));
+  return rows;
+}
 
 extern "C" int pdae_add_layernorm_forward(int M, int C, const float* x, const float* pos,
                                           const float* gamma, const float* beta, float eps,
@@ -422,11 +432,9 @@ extern "C" int pdae_bias_gelu_backward(int M, int C, const float* z, const float
   if (!accumulate) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s);
   if (M == 0) return check_launch("bias_gelu_backward");
   if (!z || !bias || !dh || !dz) return bad_arg("bias_gelu_backward: null pointer");
-  int bs = (M + 63) / 64;
-  if (bs > 1024) bs = 1024;
-  const int rows = (M + bs - 1) / bs;
-  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((C + 255) / 256, bs), dim3(256), 0, s, M, C, z, bias, dh,
-                     dz, dbias, rows);
+  const int rows = cs_rows(M);
+  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((C + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64),
+                     0, s, M, C, z, bias, dh, dz, dbias, rows);
   return check_launch("bias_gelu_backward");
 }
 
@@ -452,10 +460,9 @@ extern "C" int pdae_colsum(int M, int N, const float* X, float* out, int accumul
   if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("colsum");
   if (!X) return bad_arg("colsum: null pointer");
-  int bs = (M + 63) / 64;
-  if (bs > 1024) bs = 1024;
-  const int rows = (M + bs - 1) / bs;
-  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 255) / 256, bs), dim3(256), 0, s, M, N, X, out, rows);
+  const int rows = cs_rows(M);
+  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N,
+                     X, out, rows);
   return check_launch("colsum");
 }
 
@@ -466,10 +473,8 @@ extern "C" int pdae_scale_colsum(int M, int N, int T, const float* X, const floa
   if (out && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("scale_colsum");
   if (!X || !keep || !Y) return bad_arg("scale_colsum: null pointer");
-  int bs = (M + 31) / 32;
-  if (bs > 1024) bs = 1024;
-  const int rows = (M + bs - 1) / bs;
-  hipLaunchKernelGGL(scale_colsum_kernel, dim3((N + 255) / 256, bs), dim3(256), 0, s, M, N, T, X, keep, Y,
-                     out, rows);
+  const int rows = cs_rows(M);
+  hipLaunchKernelGGL(scale_colsum_kernel, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64),
+                     0, s, M, N, T, X, keep, Y, out, rows);
   return check_launch("scale_colsum");
 }

@@ -48,12 +48,15 @@ class _AddLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.has_pos = pos is not None
         ctx.mark_non_differentiable(mean, rstd)
+        ctx.set_materialize_grads(False)      # an unused `s` must not cost a zero-fill + a read of zeros
         return s, y
 
     @staticmethod
     def backward(ctx, ds, dy):
         s, mean, rstd, gamma = ctx.saved_tensors
         M, C = s.shape
+        if dy is None:                        # only the pass-through sum was used
+            return ds, (ds if ctx.has_pos else None), None, None, None
         dx = torch.empty_like(s)
         gb, _ = arena.take(2 * C, s)
         dg, db = gb[:C], gb[C:]
@@ -227,6 +230,8 @@ def transformer_block(x, pos, B, T, blk, keeps):
     o = attention_core(qkv, B, T, attn.num_heads, attn.scale)
     keep1, keep2 = keeps
     x2 = _ScaleResidual.apply(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T)
-    n2 = layer_norm(x2, blk.norm2)
+    # (the pass-through output carries the skip connection, so that its gradient reaches
+    #  layernorm_backward as `dres` instead of through a separate autograd add)
+    x2, n2 = add_layer_norm(x2, None, blk.norm2)
     h = bias_gelu(torch.mm(n2, blk.mlp.fc1.weight.t()), blk.mlp.fc1.bias)
     return _ScaleResidual.apply(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)

@@ -29,6 +29,14 @@ def short(n):
     return re.sub(r'[<(].*', '', n).replace('void ', '')[:80]
 
 
+if filt == 'SEQ':      # the kernel sequence of the last step, non-library non-pdae kernels named in full
+    one = rows[ad[-3] + 1:ad[-1] + 1]
+    for n, s, e, gx, gy, gz in one:
+        k = short(n)
+        if not (k.startswith('library') or k.startswith('pdae::')):
+            k = re.sub(r'void at::native::|\(anonymous namespace\)::|at::native::', '', n)[:150]
+        print('%8.1f us  grid %9d  %s' % ((e - s) / 1e3, gx * gy * gz, k))
+    sys.exit(0)
 agg = {}
 for n, s, e, gx, gy, gz in sel:
     k = short(n)
