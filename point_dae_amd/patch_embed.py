@@ -37,6 +37,13 @@ def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
+def _colsum(t):
+    """Column sums (bias gradients) into a pre-zeroed arena slice."""
+    out = arena.take(t.shape[1], t)[0]
+    _lib.call('pdae_colsum', t, t.shape[0], t.shape[1], _lib.ptr(t), _lib.ptr(out), 1)
+    return out
+
+
 def _bn_finalize(bn, rows, like, stats64=None, partials=None):
     """Training-mode BatchNorm bookkeeping in one launch (csrc/embed.hip bn_finalize):
     -> scale, shift, mean, invstd; updates the running estimates and the counter."""
@@ -148,7 +155,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         # ---- conv4 + max-pool (compact: only the listed groups carry gradient)
         dy4 = _empty((Rv, c4), x)
         _lib.call('pdae_group_max_scatter', x, Gv, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
-        db4 = dtok.sum(0)
+        db4 = _colsum(dtok)
         dw4 = _empty((c4, c3), x)
         _lib.call('pdae_bnrelu_linear_backward_weight', x, Rv, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
                   _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), None, _lib.ptr(groups))
@@ -167,7 +174,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         dwl = _empty((c3, c2), x)
         _lib.call('pdae_linear_backward_weight', x, R, c3, c2, _lib.ptr(d3), _lib.ptr(f), _lib.ptr(dwl), None)
         dwg = torch.mm(dgb.t(), g)
-        db3 = dgb.sum(0)
+        db3 = _colsum(dgb)
         dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
         df = torch.mm(d3, wl)                                     # (R, 256)
         del d3
@@ -186,7 +193,7 @@ class PatchEmbedFunction(torch.autograd.Function):
                   _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None, BG, None, None, None)
         dbe1, dg1 = S1[0], S1[1]
         dw1 = torch.mm(d1.t(), x).unsqueeze(-1)
-        db1 = d1.sum(0)
+        db1 = _colsum(d1)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
                 dw4.unsqueeze(-1), db4, None, None, None, None)
 
