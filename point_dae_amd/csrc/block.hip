@@ -291,22 +291,33 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(long long n4, int C
   y[i] = v;
 }
 
-// out[c] += sum over a slab of rows; lane owns 4 adjacent columns, the waves stride the rows
+// out[c] += sum over a slab of rows; lane owns 4 adjacent columns, the waves stride the rows.
+// Narrow matrices (N <= 128): LPR = N/4 lanes span a row and a wave reads 64/LPR rows at once.
+template <int LPR>
 __global__ __launch_bounds__(CS_NW * 64) void colsum2_kernel(int M, int N, const float* __restrict__ X,
                                                              float* __restrict__ out, int rows_per_split) {
   __shared__ float4 part[CS_NW][64];
+  constexpr int RPW = 64 / LPR;                       // rows per wave and pass
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int c = (blockIdx.x * 64 + (lane % LPR)) * 4;
   const int mbeg = blockIdx.y * rows_per_split, mend = min(M, mbeg + rows_per_split);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < N) {
 #pragma unroll 4
-    for (int m = mbeg + w; m < mend; m += CS_NW) {
+    for (int m = mbeg + w * RPW + lane / LPR; m < mend; m += CS_NW * RPW) {
       const float4 v = *reinterpret_cast<const float4*>(X + (size_t)m * N + c);
       s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
   }
-  colsum_finish(s, part, out, c, N);
+  if (LPR < 64) {                                     // fold the lanes that share a column
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) {
+      s.x += __shfl_xor(s.x, o, kWave), s.y += __shfl_xor(s.y, o, kWave);
+      s.z += __shfl_xor(s.z, o, kWave), s.w += __shfl_xor(s.w, o, kWave);
+    }
+    if (lane >= LPR) s = make_float4(0.f, 0.f, 0.f, 0.f), part[w][lane] = s;
+  }
+  colsum_finish(s, part, (LPR < 64 && lane >= LPR) ? nullptr : out, c, N);
 }
 
 // Y[m][c] = keep[m/T] * X[m][c] and out[c] += column sums of Y: the backward of
@@ -339,10 +350,12 @@ __global__ __launch_bounds__(CS_NW * 64) void scale_colsum_kernel(int M, int N, 
 
 using namespace pdae;
 
-// rows per block of the column-reducing sweeps: CS_ROWS, more once that would exceed 2048 row slabs
+// rows per block of the column-reducing sweeps: CS_ROWS, more once that would exceed 256 row
+// slabs -- every slab ends in atomics on the same few cache lines (2048 slabs of a 128-column
+// matrix: 200 us of atomics for a 30 us read)
 static int cs_rows(int M) {
   int rows = CS_ROWS;
-  if ((M + rows - 1) / rows > 2048) rows = CS_NW * ((M + 2048 * CS_NW - 1) / (2048 * CS_NW));
+  if ((M + rows - 1) / rows > 256) rows = CS_NW * ((M + 256 * CS_NW - 1) / (256 * CS_NW));
   return rows;
 }
 
@@ -461,8 +474,13 @@ extern "C" int pdae_colsum(int M, int N, const float* X, float* out, int accumul
   if (M == 0) return check_launch("colsum");
   if (!X) return bad_arg("colsum: null pointer");
   const int rows = cs_rows(M);
-  hipLaunchKernelGGL(colsum2_kernel, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N,
-                     X, out, rows);
+  if (N == 128)
+    hipLaunchKernelGGL(colsum2_kernel<32>, dim3(1, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N, X, out, rows);
+  else if (N == 64)
+    hipLaunchKernelGGL(colsum2_kernel<16>, dim3(1, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N, X, out, rows);
+  else
+    hipLaunchKernelGGL(colsum2_kernel<64>, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M,
+                       N, X, out, rows);
   return check_launch("colsum");
 }
 

@@ -150,3 +150,14 @@ def test_flat_adamw_matches_torch():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
     sd = opt.state_dict()
     assert sd['state']['step'] == 5 and len(sd['param_groups']) == 2
+
+
+@pytest.mark.parametrize('M,N', [(262144, 128), (8192, 64), (2944, 384), (100, 1536), (5, 4), (8192, 512)])
+def test_colsum(M, N):
+    from point_dae_amd import _lib
+    x = torch.randn(M, N, device='cuda')
+    out = torch.empty(N, device='cuda')
+    _lib.call('pdae_colsum', x, M, N, x.data_ptr(), out.data_ptr(), 0)
+    _close(out, x.double().sum(0), 1e-5)
+    _lib.call('pdae_colsum', x, M, N, x.data_ptr(), out.data_ptr(), 1)       # accumulate
+    _close(out, 2 * x.double().sum(0), 1e-5)
