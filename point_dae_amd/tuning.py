@@ -16,7 +16,7 @@ import shutil
 import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-MASTER = os.path.join(_HERE, 'tunableop_gfx950.csv')
+MASTER = os.environ.get('PDAE_TUNABLEOP_CSV') or os.path.join(_HERE, 'tunableop_gfx950.csv')
 
 
 def enable_tuned_gemms(retune=False, out=None):
@@ -37,10 +37,10 @@ def enable_tuned_gemms(retune=False, out=None):
     os.makedirs(d, exist_ok=True)
     ordinal = int(os.environ.get('LOCAL_RANK', '0'))
     for o in {0, ordinal}:
-        dst = os.path.join(d, 'tunableop_gfx950_%d.csv' % o)
+        dst = os.path.join(d, '%s_%d.csv' % (os.path.basename(MASTER)[:-4], o))
         if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(MASTER):
             tmp = dst + '.%d.tmp' % os.getpid()
             shutil.copyfile(MASTER, tmp)
             os.replace(tmp, dst)
-    os.environ['PYTORCH_TUNABLEOP_FILENAME'] = os.path.join(d, 'tunableop_gfx950_%d.csv')
+    os.environ['PYTORCH_TUNABLEOP_FILENAME'] = os.path.join(d, os.path.basename(MASTER)[:-4] + '_%d.csv')
     return True
