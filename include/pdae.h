@@ -337,6 +337,28 @@ int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
                             const float* gamma, const float* dres /*nullable*/,
                             float* dx, float* dgamma, float* dbeta,
                             int accumulate, pdae_stream_t stream);
+/*   residual_layernorm_forward / _backward: the previous sub-layer's tail folded in
+ *       (Block.forward :155-158: x = x + drop_path(branch(...)) followed by the next
+ *       norm):  s = res + keep[row/T] * (a + bias) (+ pos);  y = LayerNorm(s);
+ *       xsum receives s.  bias / keep / pos nullable.  Backward:
+ *       dx = LayerNorm'(dy) + dres (the gradient w.r.t. s = w.r.t. res and pos);
+ *       da = keep[row/T] * dx (written only when keep is given; otherwise da == dx);
+ *       dbias = column sums of da; dgamma / dbeta as layernorm_backward.        */
+int pdae_residual_layernorm_forward(int M, int C, int T, const float* a,
+                                    const float* bias /*nullable*/,
+                                    const float* keep /*nullable*/,
+                                    const float* res, const float* pos /*nullable*/,
+                                    const float* gamma, const float* beta,
+                                    float eps, float* xsum, float* y, float* mean,
+                                    float* rstd, pdae_stream_t stream);
+int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy,
+                                     const float* x, const float* mean,
+                                     const float* rstd, const float* gamma,
+                                     const float* dres /*nullable*/,
+                                     const float* keep /*nullable*/, float* dx,
+                                     float* da /*nullable unless keep*/,
+                                     float* dgamma, float* dbeta, float* dbias,
+                                     int accumulate, pdae_stream_t stream);
 int pdae_gelu_forward(long long n, const float* z, float* h,
                       pdae_stream_t stream);
 int pdae_gelu_backward(long long n, const float* z, const float* dh, float* dz,

@@ -23,15 +23,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int LN_MAX4 = 8;  // float4 per lane: C <= 2048
 
+// s = x (+ keep[row/T] * (br + bias): the previous sub-layer's branch, i.e. scale_residual)
+//       (+ pos);  y = LN(s).  s is written to xsum whenever it differs from x.
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
     int M, int C, const float* __restrict__ x, const float* __restrict__ pos,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ xsum, float* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd) {
+    float* __restrict__ rstd, const float* __restrict__ br, const float* __restrict__ bias,
+    const float* __restrict__ keep, int T) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = lane_id();
   const int n4 = C >> 2;
+  const float k = keep ? keep[row / T] : 1.f;
   float4 v[LN_MAX4];
   float s = 0.f;
 #pragma unroll
@@ -39,11 +43,20 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
     const int c4 = lane + i * kWave;
     if (c4 < n4) {
       float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * C + c4 * 4);
+      if (br) {      // same operation order as scale_residual: res + keep * (a + bias)
+        float4 t = *reinterpret_cast<const float4*>(br + (size_t)row * C + c4 * 4);
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+          t.x += b.x, t.y += b.y, t.z += b.z, t.w += b.w;
+        }
+        if (keep) t.x *= k, t.y *= k, t.z *= k, t.w *= k;
+        a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+      }
       if (pos) {
         const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)row * C + c4 * 4);
         a.x += p.x, a.y += p.y, a.z += p.z, a.w += p.w;
-        *reinterpret_cast<float4*>(xsum + (size_t)row * C + c4 * 4) = a;
       }
+      if (pos || br) *reinterpret_cast<float4*>(xsum + (size_t)row * C + c4 * 4) = a;
       v[i] = a;
       s += (a.x + a.y) + (a.z + a.w);
     }
@@ -93,21 +106,24 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     int M, int C, int rows, const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  extern __shared__ float red[];  // [NW][2][C]: one plain-store slot per wave (LDS float
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ keep, int T,
+    float* __restrict__ da, float* __restrict__ dbias) {
+  // (keep / da / dbias: the backward of the branch folded into the forward -- da =
+  //  keep[row/T] * dx, dbias += column sums of da; see residual_layernorm_backward)
+  extern __shared__ float red[];  // [NW][3][C]: one plain-store slot per wave (LDS float
                                   // atomics serialise: 256 of them cost 12 us per block)
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const int n4 = C >> 2;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ag[NS], ab[NS], g[NS];
+  float4 ag[NS], ab[NS], g[NS], ac[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    ag[i] = ab[i] = zero4;
+    ag[i] = ab[i] = ac[i] = zero4;
     const int c4 = lane + i * kWave;
     g[i] = c4 < n4 ? *reinterpret_cast<const float4*>(gamma + c4 * 4) : zero4;
   }
   float4 d[NS], xv[NS], e[NS];
-  float mu = 0.f, rs = 0.f;
+  float mu = 0.f, rs = 0.f, kp = 1.f;
   auto load_row = [&](int row) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -120,6 +136,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     }
     mu = row < M ? mean[row] : 0.f;
     rs = row < M ? rstd[row] : 0.f;
+    kp = (keep && row < M) ? keep[row / T] : 1.f;
   };
   const int row0 = blockIdx.x * rows + w;
   load_row(row0);
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     if (row >= M) break;
     float4 gd[NS], xh[NS];
     float s1 = 0.f, s2 = 0.f;
-    const float rs_ = rs;
+    const float rs_ = rs, kp_ = kp;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       // (slots past the row hold zeros: xh = -mu*rs there, but d = gd = 0 keeps every sum exact)
@@ -154,24 +171,31 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
         o.z = rs_ * (gd[i].z - m1 - xh[i].z * m2) + sk[i].z;
         o.w = rs_ * (gd[i].w - m1 - xh[i].w * m2) + sk[i].w;
         *reinterpret_cast<float4*>(dx + (size_t)row * C + c4 * 4) = o;
+        if (dbias) {
+          if (keep) o.x *= kp_, o.y *= kp_, o.z *= kp_, o.w *= kp_;
+          if (da) *reinterpret_cast<float4*>(da + (size_t)row * C + c4 * 4) = o;
+          ac[i].x += o.x, ac[i].y += o.y, ac[i].z += o.z, ac[i].w += o.w;
+        }
       }
     }
   }
-  float* mine = red + (size_t)w * 2 * C;
+  const int nred = dbias ? 3 : 2;
+  float* mine = red + (size_t)w * nred * C;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int c4 = lane + i * kWave;
     if (c4 < n4) {
       *reinterpret_cast<float4*>(mine + c4 * 4) = ag[i];
       *reinterpret_cast<float4*>(mine + C + c4 * 4) = ab[i];
+      if (dbias) *reinterpret_cast<float4*>(mine + 2 * C + c4 * 4) = ac[i];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += NW * 64) {
+  for (int c = threadIdx.x; c < nred * C; c += NW * 64) {
     float t = 0.f;
 #pragma unroll 4
-    for (int k = 0; k < NW; ++k) t += red[(size_t)k * 2 * C + c];
-    atomicAdd((c < C ? dgamma : dbeta - C) + c, t);
+    for (int k = 0; k < NW; ++k) t += red[(size_t)k * nred * C + c];
+    atomicAdd(c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : dbias + (c - 2 * C)), t);
   }
 }
 
@@ -359,48 +383,90 @@ static int cs_rows(int M) {
   return rows;
 }
 
+static int ln_forward(const char* what, int M, int C, int T, const float* x, const float* br,
+                      const float* bias, const float* keep, const float* pos, const float* gamma,
+                      const float* beta, float eps, float* xsum, float* y, float* mean, float* rstd,
+                      pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0)
+    return bad_arg("layernorm forward: C must be a multiple of 4, at most 2048; T > 0");
+  if (M == 0) return PDAE_OK;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || ((pos || br) && !xsum) || ((bias || keep) && !br))
+    return bad_arg("layernorm forward: null pointer");
+  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), M,
+                     C, x, pos, gamma, beta, eps, xsum, y, mean, rstd, br, bias, keep, T);
+  return check_launch(what);
+}
+
 extern "C" int pdae_add_layernorm_forward(int M, int C, const float* x, const float* pos,
                                           const float* gamma, const float* beta, float eps,
                                           float* xsum, float* y, float* mean, float* rstd,
                                           pdae_stream_t stream) {
-  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4)
-    return bad_arg("add_layernorm_forward: C must be a multiple of 4, at most 2048");
-  if (M == 0) return PDAE_OK;
-  if (!x || !gamma || !beta || !y || !mean || !rstd || (pos && !xsum))
-    return bad_arg("add_layernorm_forward: null pointer");
-  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), M,
-                     C, x, pos, gamma, beta, eps, xsum, y, mean, rstd);
-  return check_launch("add_layernorm_forward");
+  return ln_forward("add_layernorm_forward", M, C, 1, x, nullptr, nullptr, nullptr, pos, gamma, beta, eps,
+                    xsum, y, mean, rstd, stream);
 }
 
-extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
-                                       const float* mean, const float* rstd, const float* gamma,
-                                       const float* dres, float* dx, float* dgamma, float* dbeta,
-                                       int accumulate, pdae_stream_t stream) {
-  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4)
-    return bad_arg("layernorm_backward: C must be a multiple of 4, at most 2048");
-  if (!dgamma || !dbeta) return bad_arg("layernorm_backward: null pointer");
+extern "C" int pdae_residual_layernorm_forward(int M, int C, int T, const float* a, const float* bias,
+                                               const float* keep, const float* res, const float* pos,
+                                               const float* gamma, const float* beta, float eps,
+                                               float* xsum, float* y, float* mean, float* rstd,
+                                               pdae_stream_t stream) {
+  if (!a) return bad_arg("residual_layernorm_forward: null pointer");
+  return ln_forward("residual_layernorm_forward", M, C, T, res, a, bias, keep, pos, gamma, beta, eps, xsum,
+                    y, mean, rstd, stream);
+}
+
+static int ln_backward(const char* what, int M, int C, int T, const float* dy, const float* x,
+                       const float* mean, const float* rstd, const float* gamma, const float* dres,
+                       const float* keep, float* dx, float* da, float* dgamma, float* dbeta, float* dbias,
+                       int accumulate, pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0)
+    return bad_arg("layernorm backward: C must be a multiple of 4, at most 2048; T > 0");
+  if (!dgamma || !dbeta) return bad_arg("layernorm backward: null pointer");
   hipStream_t s = as_stream(stream);
   if (!accumulate) {
     (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, s);
     (void)hipMemsetAsync(dbeta, 0, sizeof(float) * C, s);
+    if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, s);
   }
-  if (M == 0) return check_launch("layernorm_backward");
-  if (!dy || !x || !mean || !rstd || !gamma || !dx) return bad_arg("layernorm_backward: null pointer");
+  if (M == 0) return check_launch(what);
+  if (!dy || !x || !mean || !rstd || !gamma || !dx || ((keep || da) && !dbias) || (keep && !da))
+    return bad_arg("layernorm backward: null pointer");
+  const int nred = dbias ? 3 : 2;
   if (C <= 512) {
     // 16-wave blocks, one row per wave (two from 6144 rows on: fewer blocks = fewer atomics);
     // measured 13 us at M = 2944 and 20 us at M = 8192 (was 24 / 29 us with LDS atomics)
     const int per_wave = M >= 6144 ? 2 : 1;
     const int rows = 16 * per_wave;
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
-                       16 * 2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+                       16 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
+                       dbeta, keep, T, da, dbias);
   } else {
     int rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
     if (rows > 32) rows = 32;
     hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3((M + rows - 1) / rows), dim3(256),
-                       4 * 2 * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta);
+                       4 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
+                       dbeta, keep, T, da, dbias);
   }
-  return check_launch("layernorm_backward");
+  return check_launch(what);
+}
+
+extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
+                                       const float* mean, const float* rstd, const float* gamma,
+                                       const float* dres, float* dx, float* dgamma, float* dbeta,
+                                       int accumulate, pdae_stream_t stream) {
+  return ln_backward("layernorm_backward", M, C, 1, dy, x, mean, rstd, gamma, dres, nullptr, dx, nullptr,
+                     dgamma, dbeta, nullptr, accumulate, stream);
+}
+
+extern "C" int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, const float* x,
+                                                const float* mean, const float* rstd,
+                                                const float* gamma, const float* dres,
+                                                const float* keep, float* dx, float* da, float* dgamma,
+                                                float* dbeta, float* dbias, int accumulate,
+                                                pdae_stream_t stream) {
+  if (!dbias) return bad_arg("residual_layernorm_backward: null pointer");
+  return ln_backward("residual_layernorm_backward", M, C, T, dy, x, mean, rstd, gamma, dres, keep, dx, da,
+                     dgamma, dbeta, dbias, accumulate, stream);
 }
 
 extern "C" int pdae_gelu_forward(long long n, const float* z, float* h, pdae_stream_t stream) {

@@ -66,13 +66,79 @@ class _AddLayerNorm(torch.autograd.Function):
         return dx, (dx if ctx.has_pos else None), dg, db, None
 
 
+class _ResidualLayerNorm(torch.autograd.Function):
+    """(s, y) with s = res + keep[b] * (a + bias) (+ pos), y = LayerNorm(s): the tail of the
+    previous sub-layer (Linear bias, DropPath, residual add) folded into the norm that
+    consumes it, forward and backward (one launch each instead of two)."""
+
+    @staticmethod
+    def forward(ctx, a, bias, keep, res, pos, gamma, beta, eps, T):
+        a, res = a.contiguous(), res.contiguous()
+        M, C = a.shape
+        s, y = torch.empty_like(a), torch.empty_like(a)
+        mean, rstd = _empty((M,), a), _empty((M,), a)
+        if pos is not None:
+            pos = pos.contiguous()
+        _lib.call('pdae_residual_layernorm_forward', a, M, C, T, _lib.ptr(a), _lib.ptr(bias), _lib.ptr(keep),
+                  _lib.ptr(res), _lib.ptr(pos), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(s),
+                  _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd))
+        ctx.save_for_backward(s, mean, rstd, gamma, keep)
+        ctx.T, ctx.has_pos, ctx.has_bias = T, pos is not None, bias is not None
+        ctx.mark_non_differentiable(mean, rstd)
+        ctx.set_materialize_grads(False)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, mean, rstd, gamma, keep = ctx.saved_tensors
+        M, C = s.shape
+        if dy is None:                        # only the sum was used: plain scale_residual backward
+            ds = ds.contiguous()
+            if keep is not None:
+                da = torch.empty_like(ds)
+                dbias = arena.take(C, ds)[0] if ctx.has_bias else None
+                _lib.call('pdae_scale_colsum', ds, M, C, ctx.T, _lib.ptr(ds), _lib.ptr(keep), _lib.ptr(da),
+                          _lib.ptr(dbias), 1)
+            else:
+                da, dbias = ds, (_colsum(ds) if ctx.has_bias else None)
+            return da, dbias, None, ds, (ds if ctx.has_pos else None), None, None, None, None
+        dx = torch.empty_like(s)
+        buf, _ = arena.take(3 * C, s)
+        dg, db, dbias = buf[:C], buf[C:2 * C], buf[2 * C:]
+        da = torch.empty_like(s) if keep is not None else dx
+        dres = ds.contiguous() if ds is not None else None
+        _lib.call('pdae_residual_layernorm_backward', s, M, C, ctx.T, _lib.ptr(dy.contiguous()), _lib.ptr(s),
+                  _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(keep), _lib.ptr(dx),
+                  _lib.ptr(da) if keep is not None else None, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), 1)
+        return da, (dbias if ctx.has_bias else None), None, dx, (dx if ctx.has_pos else None), dg, db, None, None
+
+
+class Pending:
+    """A sub-layer's output that has not been added to the residual stream yet:
+    stream = res + keep * (a + bias).  The norm that consumes it does the add."""
+    __slots__ = ('a', 'bias', 'keep', 'res', 'T')
+
+    def __init__(self, a, bias, keep, res, T):
+        self.a, self.bias, self.keep, self.res, self.T = a, bias, keep, res, T
+
+    def resolve(self):
+        return _ScaleResidual.apply(self.a, self.bias, self.keep, self.res, self.T)
+
+
+def residual_layer_norm(x, pos, ln):
+    """x: rows or a Pending -> (stream (+ pos), LN of it)."""
+    if isinstance(x, Pending):
+        return _ResidualLayerNorm.apply(x.a, x.bias, x.keep, x.res, pos, ln.weight, ln.bias, ln.eps, x.T)
+    return _AddLayerNorm.apply(x, pos, ln.weight, ln.bias, ln.eps)
+
+
 def add_layer_norm(x, pos, ln):
     """-> (x + pos, LN(x + pos)); the sum feeds the residual stream."""
     return _AddLayerNorm.apply(x, pos, ln.weight, ln.bias, ln.eps)
 
 
 def layer_norm(x, ln):
-    return _AddLayerNorm.apply(x, None, ln.weight, ln.bias, ln.eps)[1]
+    return residual_layer_norm(x, None, ln)[1]
 
 
 class _Attention(torch.autograd.Function):
@@ -250,18 +316,19 @@ def pos_embed(xyz_rows, seq):
     return linear(linear(xyz_rows, seq[0], 'gelu'), seq[2])
 
 
-def transformer_block(x, pos, B, T, blk, keeps):
+def transformer_block(x, pos, B, T, blk, keeps, pending=False):
     """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
-    (PointCAE_transformer.py:155-158, :174-177) in 11 launches.  `keeps` =
-    (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path."""
+    (PointCAE_transformer.py:155-158, :174-177) in 9 launches.  `keeps` =
+    (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path.
+    x may be a Pending (the previous block's MLP branch, added here by norm1's
+    kernel); with pending=True the result is one too (for the next norm)."""
     attn = blk.attn
-    x1, n1 = add_layer_norm(x, pos, blk.norm1)
+    x1, n1 = residual_layer_norm(x, pos, blk.norm1)
     qkv = F.linear(n1, attn.qkv.weight, attn.qkv.bias)
     o = attention_core(qkv, B, T, attn.num_heads, attn.scale)
     keep1, keep2 = keeps
-    x2 = _ScaleResidual.apply(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T)
-    # (the pass-through output carries the skip connection, so that its gradient reaches
-    #  layernorm_backward as `dres` instead of through a separate autograd add)
-    x2, n2 = add_layer_norm(x2, None, blk.norm2)
+    x2, n2 = residual_layer_norm(Pending(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T), None,
+                                 blk.norm2)
     h = bias_gelu(torch.mm(n2, blk.mlp.fc1.weight.t()), blk.mlp.fc1.bias)
-    return _ScaleResidual.apply(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)
+    out = Pending(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)
+    return out if pending else out.resolve()

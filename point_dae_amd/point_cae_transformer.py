@@ -96,9 +96,11 @@ class Block(nn.Module):
         self.attn = Attention(dim, num_heads)
         self.drop_prob = float(drop_path)
 
-    def forward(self, x, pos, B, T, keeps=(None, None)):
-        """x, pos: (B*T, C) rows; computes block(x + pos)."""
-        return nn_ops.transformer_block(x, pos, B, T, self, keeps)
+    def forward(self, x, pos, B, T, keeps=(None, None), pending=False):
+        """x, pos: (B*T, C) rows; computes block(x + pos).  x may be, and with
+        pending=True the result is, an nn_ops.Pending (a branch not yet added to the
+        residual stream: the next norm's kernel adds it)."""
+        return nn_ops.transformer_block(x, pos, B, T, self, keeps, pending)
 
 
 def _stack_keeps(stack, B):
@@ -114,8 +116,8 @@ class TransformerEncoder(nn.Module):
     def forward(self, x, pos, B, T):
         keeps = _stack_keeps(self, B)
         for blk, k in zip(self.blocks, keeps):   # position re-added before EVERY block (:174-177)
-            x = blk(x, pos, B, T, k)
-        return x
+            x = blk(x, pos, B, T, k, pending=True)
+        return x                                 # nn_ops.Pending: the caller's norm adds the last branch
 
 
 class TransformerDecoder(nn.Module):
@@ -140,11 +142,14 @@ class TransformerDecoder(nn.Module):
     def forward(self, x, pos, B, T, return_token_num=-1):
         keeps = _stack_keeps(self, B)
         for blk, k in zip(self.blocks, keeps):
-            x = blk(x, pos, B, T, k)
-        C = x.shape[-1]
-        if return_token_num != -1:     # the masked tokens sit last in every sample (:229-231)
-            x = x.reshape(B, T, C)[:, -return_token_num:].reshape(-1, C)
-        return nn_ops.layer_norm(x, self.norm)
+            x = blk(x, pos, B, T, k, pending=True)
+        # LayerNorm is row-wise: norm(x[:, -n:]) (:229-231) == norm(x)[:, -n:]; normalising every row
+        # lets the norm's kernel also do the last block's bias + DropPath + residual add
+        y = nn_ops.layer_norm(x, self.norm)
+        if return_token_num != -1:     # the masked tokens sit last in every sample
+            C = y.shape[-1]
+            y = y.reshape(B, T, C)[:, -return_token_num:].reshape(-1, C)
+        return y
 
 
 def _pos_embed(dim):

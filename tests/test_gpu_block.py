@@ -161,3 +161,40 @@ def test_colsum(M, N):
     _close(out, x.double().sum(0), 1e-5)
     _lib.call('pdae_colsum', x, M, N, x.data_ptr(), out.data_ptr(), 1)       # accumulate
     _close(out, 2 * x.double().sum(0), 1e-5)
+
+
+@pytest.mark.parametrize('B,T,C', [(16, 23, 384), (128, 64, 384), (3, 5, 128), (2, 7, 2048)])
+@pytest.mark.parametrize('with_keep,with_pos', [(True, True), (True, False), (False, True), (False, False)])
+def test_residual_layernorm_equals_unfused(B, T, C, with_keep, with_pos):
+    """The fused tail (bias + DropPath + residual (+ pos) + LayerNorm, one launch each way) against
+    the unfused pair scale_residual -> add_layer_norm: identical forward bits, same gradients."""
+    from point_dae_amd import nn_ops
+    torch.manual_seed(B * 100 + T)
+    M = B * T
+    ln = torch.nn.LayerNorm(C).cuda()
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.normal_()
+    a0, res0 = torch.randn(M, C, device='cuda'), torch.randn(M, C, device='cuda')
+    bias0 = torch.randn(C, device='cuda')
+    pos0 = torch.randn(M, C, device='cuda') if with_pos else None
+    keep = (torch.rand(B, device='cuda') > 0.3).float() / 0.7 if with_keep else None
+    gs, gy = torch.randn(M, C, device='cuda'), torch.randn(M, C, device='cuda')
+    outs = []
+    for fused in (True, False):
+        a, res, bias = (t.clone().requires_grad_(True) for t in (a0, res0, bias0))
+        pos = pos0.clone().requires_grad_(True) if with_pos else None
+        ln.zero_grad()
+        nn_ops.begin_step(a.device)
+        if fused:
+            s, y = nn_ops.residual_layer_norm(nn_ops.Pending(a, bias, keep, res, T), pos, ln)
+        else:
+            s, y = nn_ops.add_layer_norm(nn_ops._ScaleResidual.apply(a, bias, keep, res, T), pos, ln)
+        (s * gs).sum().backward(retain_graph=True)
+        (y * gy).sum().backward()
+        outs.append([s.detach(), y.detach(), a.grad, res.grad, bias.grad, pos.grad if with_pos else None,
+                     ln.weight.grad.clone(), ln.bias.grad.clone()])
+    f, u = outs
+    assert torch.equal(f[0], u[0]) and torch.equal(f[1], u[1])
+    for x, y_ in zip(f[2:], u[2:]):
+        if x is not None:
+            _close(x, y_, 2e-5)
