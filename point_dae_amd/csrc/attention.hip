@@ -74,6 +74,29 @@ __device__ __forceinline__ void stage_head(float* dst, const float* src, int T, 
   }
 }
 
+// The same staging with every global load of the thread issued BEFORE the first LDS store
+// (NJ float4 per tensor and thread, Tpad * 16 == NJ * nthreads): the loop above waits out a
+// full memory latency per float4 -- 24 of them in a row made up most of the forward's time.
+template <int NJ>
+__device__ __forceinline__ void load_head(float4 (&buf)[NJ], const float* src, int T, size_t row_stride,
+                                          int tid, int nthreads) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = tid + j * nthreads;
+    const int row = i >> 4, c4 = (i & 15) * 4;
+    buf[j] = row < T ? *reinterpret_cast<const float4*>(src + (size_t)row * row_stride + c4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void store_head(float* dst, const float4 (&buf)[NJ], int tid, int nthreads) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = tid + j * nthreads;
+    *reinterpret_cast<float4*>(dst + (i >> 4) * ALD + (i & 15) * 4) = buf[j];
+  }
+}
+
 // ---------------------------------------------------------------- forward
 // grid (H, B), block = 64 * ceil(T/32) threads.  qkv (B*T, 3*H*64); o (B*T, H*64);
 // lse (B, H, T).
@@ -90,9 +113,15 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int T, int H, float 
   const int hd = blockIdx.x, b = blockIdx.y;
   const size_t rs = (size_t)3 * H * AD;
   const float* base = qkv + (size_t)b * T * rs + hd * AD;
-  stage_head(Qs, base, T, Tpad, rs, threadIdx.x, blockDim.x);
-  stage_head(Ks, base + (size_t)H * AD, T, Tpad, rs, threadIdx.x, blockDim.x);
-  stage_head(Vs, base + (size_t)2 * H * AD, T, Tpad, rs, threadIdx.x, blockDim.x);
+  {   // blockDim = 2 * Tpad threads: 8 float4 per tensor and thread, 24 loads in flight
+    float4 bq[8], bk[8], bv[8];
+    load_head(bq, base, T, rs, threadIdx.x, blockDim.x);
+    load_head(bk, base + (size_t)H * AD, T, rs, threadIdx.x, blockDim.x);
+    load_head(bv, base + (size_t)2 * H * AD, T, rs, threadIdx.x, blockDim.x);
+    store_head(Qs, bq, threadIdx.x, blockDim.x);
+    store_head(Ks, bk, threadIdx.x, blockDim.x);
+    store_head(Vs, bv, threadIdx.x, blockDim.x);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -174,20 +203,28 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(int T, int H, float 
   const int hd = blockIdx.x, b = blockIdx.y;
   const size_t rs = (size_t)3 * H * AD, os = (size_t)H * AD;
   const float* base = qkv + (size_t)b * T * rs + hd * AD;
-  stage_head(Qs, base, T, Tpad, rs, threadIdx.x, blockDim.x);
-  stage_head(Ks, base + (size_t)H * AD, T, Tpad, rs, threadIdx.x, blockDim.x);
-  stage_head(Vs, base + (size_t)2 * H * AD, T, Tpad, rs, threadIdx.x, blockDim.x);
-  stage_head(dOs, d_o + (size_t)b * T * os + hd * AD, T, Tpad, os, threadIdx.x, blockDim.x);
-  for (int q = threadIdx.x; q < Tpad; q += blockDim.x) {
-    float dl = 0.f, ls = 0.f;
-    if (q < T) {
-      const float* op = o + ((size_t)b * T + q) * os + hd * AD;
-      const float* dp = d_o + ((size_t)b * T + q) * os + hd * AD;
-      for (int d = 0; d < AD; ++d) dl += op[d] * dp[d];
-      ls = lse[((size_t)b * H + hd) * T + q];
+  {   // blockDim = 4 * Tpad threads: 4 float4 per tensor and thread, 20 loads in flight
+    float4 bq[4], bk[4], bv[4], bd[4], bo[4];
+    load_head(bq, base, T, rs, threadIdx.x, blockDim.x);
+    load_head(bk, base + (size_t)H * AD, T, rs, threadIdx.x, blockDim.x);
+    load_head(bv, base + (size_t)2 * H * AD, T, rs, threadIdx.x, blockDim.x);
+    load_head(bd, d_o + (size_t)b * T * os + hd * AD, T, os, threadIdx.x, blockDim.x);
+    load_head(bo, o + (size_t)b * T * os + hd * AD, T, os, threadIdx.x, blockDim.x);
+    const float ls = (int)threadIdx.x < T ? lse[((size_t)b * H + hd) * T + threadIdx.x] : 0.f;
+    store_head(Qs, bq, threadIdx.x, blockDim.x);
+    store_head(Ks, bk, threadIdx.x, blockDim.x);
+    store_head(Vs, bv, threadIdx.x, blockDim.x);
+    store_head(dOs, bd, threadIdx.x, blockDim.x);
+    if ((int)threadIdx.x < Tpad) Ls[threadIdx.x] = ls;
+    // delta[q] = sum_d dO[q][d] * O[q][d]: the 16 consecutive lanes that staged row q hold it
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float dl = (bd[j].x * bo[j].x + bd[j].y * bo[j].y) + (bd[j].z * bo[j].z + bd[j].w * bo[j].w);
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) dl += __shfl_xor(dl, m, kWave);
+      const int i = threadIdx.x + j * blockDim.x;
+      if ((i & 15) == 0) Ds[i >> 4] = dl;
     }
-    Ls[q] = ls;
-    Ds[q] = dl;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;

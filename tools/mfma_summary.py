@@ -1,0 +1,38 @@
+"""MFMA utilisation per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass
+(--output-format csv).  util = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * 1024 SIMDs), the
+formula of rocprofv3's derived MfmaUtil counter.  usage: mfma_summary.py <dir> -> JSON on stdout."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+SIMDS = 256 * 4
+acc = {}
+for path in glob.glob(os.path.join(sys.argv[1], '**', '*counter_collection.csv'), recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            n = r['Kernel_Name']
+            if n.startswith('Cijk_'):
+                key = 'library GEMMs (hipBLASLt/rocBLAS, all shapes)'
+            elif 'pdae::' in n:
+                key = re.sub(r'\(.*', '', n).replace('void ', '')
+            else:
+                continue
+            a = acc.setdefault(key, {})
+            d = a.setdefault(r['Dispatch_Id'], {})
+            v = float(r['Counter_Value'])
+            if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':      # one row per XCD: reduce(max), as MfmaUtil does
+                d['GRBM_GUI_ACTIVE'] = max(d.get('GRBM_GUI_ACTIVE', 0.0), v)
+            else:                                           # reduce(sum)
+                d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + v
+out = {}
+for key, disp in acc.items():
+    busy = sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for d in disp.values())
+    act = sum(d.get('GRBM_GUI_ACTIVE', 0.0) for d in disp.values())
+    if busy <= 0 or act <= 0:
+        continue
+    out[key] = {'dispatches': len(disp), 'SQ_VALU_MFMA_BUSY_CYCLES_avg': busy / len(disp),
+                'GRBM_GUI_ACTIVE_avg': act / len(disp), 'mfma_util': busy / (act * SIMDS)}
+print(json.dumps(dict(sorted(out.items(), key=lambda kv: -kv[1]['mfma_util'])), indent=1))
