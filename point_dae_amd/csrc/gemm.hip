@@ -39,6 +39,7 @@
 //     EPI_STORE_GROUPMAX     both C = acc + bias and the group max / argmax
 // Kernel "TN":  C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; reduction over
 //     the slow index M, split over blockIdx.z, fp32 atomics into C).
+#include <type_traits>
 #include "common.h"
 
 namespace pdae {
@@ -196,8 +197,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
         b[nxt][0] = *reinterpret_cast<const float4*>(Bs + (s + 1) * 8);
         b[nxt][1] = *reinterpret_cast<const float4*>(Bs + 32 * GLD + (s + 1) * 8);
       }
+#ifdef PDAE_NT_NO_SGB
       // keep the compiler from sinking those reads back to their first use
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -207,8 +210,22 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].z, b[cur][j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].w, b[cur][j].w, acc[i][j], 0, 0, 0);
         }
+#ifndef PDAE_NT_NO_SGB
+      // issue order: one fragment read of the next k-group behind every four MFMAs (the reads
+      // then never queue up in front of an MFMA that needs them; measured 99 -> 104 TFLOP/s in
+      // tools/lab/gemm_lab2.hip), the next slab's global loads behind the first MFMAs
+      if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, LA + LB, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (s + 1 < GBK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x200, (LA + LB + 3) / 4, 0);   // the LDS stores of the next slab
+      }
+#endif
+      // the next slab goes to the other LDS buffer (free since the last barrier) while this
+      // slab's last MFMAs run, not after them
+      if (s == GBK / 8 - 2 && kt + 1 < KT) lstore(buf ^ 1);
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -216,54 +233,67 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
   // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
   // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
   float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+  // FULL = the whole tile lies inside the matrix (the only case on the step's shapes): no
+  // per-element guards, one 64-bit base pointer per MFMA tile and 32-bit row offsets (the
+  // guarded form spent ~6 us of VALU address arithmetic and 64 branches per tile)
+  auto epilogue = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const unsigned ldc = (unsigned)p.ldc;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + r;
-    const bool colok = col < N;
-    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + r;
+      const bool colok = FULL || col < N;
+      const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rbase = m0 + wm * 64 + i * 32;  // one 32-row group per MFMA tile
-      float add = bv;
-      if (EPI == EPI_GROUPBIAS_STATS)
-        add = (colok && rbase < M) ? p.gbias[(size_t)(rbase >> 5) * N + col] : 0.f;
-      float vmax = -__builtin_huge_valf();
-      int amax = 0;
+      for (int i = 0; i < 2; ++i) {
+        const int rbase = m0 + wm * 64 + i * 32;  // one 32-row group per MFMA tile
+        float add = bv;
+        if (EPI == EPI_GROUPBIAS_STATS)
+          add = (colok && (FULL || rbase < M)) ? p.gbias[(size_t)(rbase >> 5) * N + col] : 0.f;
+        float vmax = -__builtin_huge_valf();
+        int amax = 0;
+        float* cbase = (EPI != EPI_GROUPMAX) ? p.C + (size_t)(rbase + 4 * h) * ldc + col : nullptr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int row = rbase + lr;
-        float v = acc[i][j][e] + add;
-        if (EPI == EPI_BIAS_RELU) v = act_relu(v);
-        if (EPI == EPI_BIAS_GELU) v = act_gelu(v);
-        if (EPI == EPI_GROUPBIAS_STATS && row < M) {
-          csum[j] += v;
-          csq[j] += v * v;
+        for (int e = 0; e < 16; ++e) {
+          const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int row = rbase + lr;
+          float v = acc[i][j][e] + add;
+          if (EPI == EPI_BIAS_RELU) v = act_relu(v);
+          if (EPI == EPI_BIAS_GELU) v = act_gelu(v);
+          if (EPI == EPI_GROUPBIAS_STATS && (FULL || row < M)) {
+            csum[j] += v;
+            csq[j] += v * v;
+          }
+          if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+            if (v > vmax) {  // e ascending => lr ascending within this half
+              vmax = v;
+              amax = lr;
+            }
+          }
+          if (EPI != EPI_GROUPMAX && (FULL || (colok && row < M)))
+            cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
         }
         if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
-          if (v > vmax) {  // e ascending => lr ascending within this half
-            vmax = v;
-            amax = lr;
+          // the other 16 rows of the group live in lane ^ 32
+          const float ov = __shfl_xor(vmax, 32, kWave);
+          const int oa = __shfl_xor(amax, 32, kWave);
+          const bool take = (ov > vmax) || (ov == vmax && oa < amax);
+          if (take) {
+            vmax = ov;
+            amax = oa;
           }
-        }
-        if (EPI != EPI_GROUPMAX && colok && row < M) p.C[(size_t)row * p.ldc + col] = v;
-      }
-      if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
-        // the other 16 rows of the group live in lane ^ 32
-        const float ov = __shfl_xor(vmax, 32, kWave);
-        const int oa = __shfl_xor(amax, 32, kWave);
-        const bool take = (ov > vmax) || (ov == vmax && oa < amax);
-        if (take) {
-          vmax = ov;
-          amax = oa;
-        }
-        if (h == 0 && colok && rbase < M) {
-          p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
-          p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
+          if (h == 0 && colok && (FULL || rbase < M)) {
+            p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
+            p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
+          }
         }
       }
     }
-  }
+  };
+  if (m0 + BM <= M && n0 + BN <= N)
+    epilogue(std::true_type{});
+  else
+    epilogue(std::false_type{});
   if (EPI == EPI_GROUPBIAS_STATS) {
     // per-block column sums through LDS, then one atomic per column per block
     // into the partial buffer of this block's XCD slot
@@ -426,7 +456,6 @@ void gemm_tn_kernel(const TnArgs p) {
         fread(nxt, 2 * tt + 2);
         fread(nxt, 2 * tt + 3);
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][0], fb[cur][u][0], acc[0][0], 0, 0, 0);
@@ -434,8 +463,17 @@ void gemm_tn_kernel(const TnArgs p) {
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][1], fb[cur][u][0], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u][1], fb[cur][u][1], acc[1][1], 0, 0, 0);
       }
+      // issue order (see gemm_nt_kernel): the next slab's global loads behind the first MFMAs,
+      // one fragment read behind every MFMA, the LDS stores of the next slab behind the last ones
+      if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x020, SLOTS, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (tt + 1 < TBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (g < SLOTS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      if (tt == TBK / 4 - 2 && mt + TBK < mend) lstore(buf ^ 1);
     }
-    if (mt + TBK < mend) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
