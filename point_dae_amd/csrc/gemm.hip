@@ -360,7 +360,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 // "down the columns": lane (r,h) of MFMA step t takes A[m = 2t + h][n = i0 + r].
 // Optional producer on B (PRO_BNRELU over B's columns k) recomputes the
 // activation that was never stored.
-constexpr int TBK = 16;
+#ifndef PDAE_TBK
+#define PDAE_TBK 16
+#endif
+constexpr int TBK = PDAE_TBK;
+constexpr int TN_RES = TBK == 16 ? 3 : 2;   // TN blocks resident per CU (LDS: 32 KB / 64 KB each)
 struct TnArgs {
   int M, N, K;
   const float* A;
@@ -380,7 +384,7 @@ struct TnArgs {
 // Block tile TM (columns n of A) x TN_ (columns k of B); every wave 64x64.  Bigger
 // tiles = fewer bytes staged per MAC (the 128x128 version ran at 69 TFLOP/s).
 template <int TM, int TN_, int PRO>
-__global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__((TM / 64) * (TN_ / 64) * 64) __attribute__((amdgpu_waves_per_eu(TN_RES, TN_RES)))
 void gemm_tn_kernel(const TnArgs p) {
   constexpr int WN = TN_ / 64;
   constexpr int NT = (TM / 64) * (TN_ / 64) * 64;
@@ -608,7 +612,7 @@ static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
   constexpr int NTH = (TM / 64) * (TN_ / 64) * 64;
   // M-splits so that the grid is ONE full residency of the chip (256 CUs x 3 blocks):
   // 768 blocks ran dW4 in 576 us, 1024 blocks (1.33 rounds) in 663 us; each split >= 256 rows
-  int splits = (3 * 256 + tn * tk / 2) / (tn * tk);
+  int splits = (TN_RES * 256 + tn * tk / 2) / (tn * tk);
   if (splits < 1) splits = 1;
   int rows = (t.M + splits - 1) / splits;
   rows = ((rows + TBK - 1) / TBK) * TBK;
