@@ -1,6 +1,9 @@
 """MFMA utilisation per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass
-(--output-format csv).  util = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * 1024 SIMDs), the
-formula of rocprofv3's derived MfmaUtil counter.  usage: mfma_summary.py <dir> -> JSON on stdout."""
+(--output-format csv).  util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): the
+formula of rocprofv3's derived MfmaUtil counter, with GRBM_GUI_ACTIVE divided by the 8 XCDs it is
+reported summed over on this part (19.8 G counts per second of kernel time = 8 x 2.4 GHz; check: a
+kernel of 16.8 M v_mfma_f32_32x32x2_f32 at 64 cycles each reports 1.07e9 busy cycles).
+usage: mfma_summary.py <dir> -> JSON on stdout."""
 import csv
 import glob
 import json
@@ -9,6 +12,7 @@ import re
 import sys
 
 SIMDS = 256 * 4
+XCDS = 8
 acc = {}
 for path in glob.glob(os.path.join(sys.argv[1], '**', '*counter_collection.csv'), recursive=True):
     with open(path) as f:
@@ -34,5 +38,5 @@ for key, disp in acc.items():
     if busy <= 0 or act <= 0:
         continue
     out[key] = {'dispatches': len(disp), 'SQ_VALU_MFMA_BUSY_CYCLES_avg': busy / len(disp),
-                'GRBM_GUI_ACTIVE_avg': act / len(disp), 'mfma_util': busy / (act * SIMDS)}
+                'GRBM_GUI_ACTIVE_avg': act / len(disp), 'mfma_util': busy / (act / XCDS * SIMDS)}
 print(json.dumps(dict(sorted(out.items(), key=lambda kv: -kv[1]['mfma_util'])), indent=1))

@@ -18,3 +18,4 @@ done
 python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc.json
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT
+bash tools/prof_mfma.sh
