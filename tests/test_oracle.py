@@ -261,3 +261,21 @@ def test_emd_match_is_a_transport_plan(oracle_ops):
     # identical clouds -> near-zero cost
     m2 = oracle_ops.emd_approxmatch(a, a)
     assert (oracle_ops.emd_matchcost(a, a, m2) / 64 < 2e-3).all()
+
+
+def test_oracle_reproduces_committed_op_vectors(oracle_ops):
+    """tests/golden/ops_oracle.npz (made by tests/golden/make_op_fixtures.py): the oracle's answers on
+    the SURVEY §8c cases -- FPS incl. the origin-skip and duplicate clouds, kNN, ball query with an
+    empty ball, Chamfer at the three cfg sizes, EMD incl. the reference's known answer."""
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, here)
+    import make_op_fixtures
+    want = np.load(os.path.join(here, 'ops_oracle.npz'))
+    got = make_op_fixtures.cases(oracle_ops)
+    assert sorted(got) == sorted(want.files)
+    for k in want.files:
+        np.testing.assert_array_equal(np.asarray(got[k]), want[k], err_msg=k)
+    assert abs(float(want['emd_two_point_cost']) - 0.355) < 1e-4     # extensions/emd/test_emd_loss.py
+    assert (want['ball_512_32_idx'][0, 0] == 0).all()                  # empty ball: all slots stay 0 (ball_query_gpu.cu)
