@@ -228,3 +228,52 @@ def test_fused_patch_embed_matches_pytorch(BG):
     first.eval(), second.eval(), first_d.eval(), second_d.eval()
     with torch.no_grad():
         _close(patch_embed(pts, first, second, False), _embed_reference(pts.double(), first_d, second_d).float(), 2e-5)
+
+
+@pytest.mark.parametrize('R,C', [(262144, 128), (4096, 64), (1000, 128), (37, 256)])
+def test_conv1_stats_and_bn_finalize(R, C):
+    """embed_conv1_stats + bn_finalize against nn.Conv1d(3, C, 1) -> nn.BatchNorm1d(C) in training mode
+    (values, batch statistics, running estimates, counter, the scale/shift the next kernel consumes)."""
+    import torch.nn as nn
+    L = _lib()
+    torch.manual_seed(R + C)
+    x = torch.randn(R, 3, device='cuda') * 0.3
+    conv = nn.Conv1d(3, C, 1).cuda()
+    bn = nn.BatchNorm1d(C).cuda()
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    bn.running_mean.normal_(0, 0.1)
+    bn.running_var.uniform_(0.5, 2.0)
+    ref_bn = nn.BatchNorm1d(C).cuda().double()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    w = conv.weight.detach().squeeze(-1).contiguous()
+    y = torch.empty(R, C, device='cuda')
+    st = torch.zeros(2, C, device='cuda', dtype=torch.float64)
+    L.call('pdae_embed_conv1_stats', x, R, C, x.data_ptr(), w.data_ptr(), conv.bias.data_ptr(), y.data_ptr(),
+           st.data_ptr())
+    y64 = x.double() @ w.double().t() + conv.bias.detach().double()
+    _close(y, y64.float(), 1e-6)
+    _close(st[0], y64.sum(0), 1e-6)
+    _close(st[1], (y64 * y64).sum(0), 1e-6)
+    scale, shift, mean, invstd = (torch.empty(C, device='cuda') for _ in range(4))
+    L.call('pdae_bn_finalize', x, C, R, st.data_ptr(), None, 0, bn.weight.data_ptr(), bn.bias.data_ptr(),
+           float(bn.eps), 0.1, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+           bn.num_batches_tracked.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+           invstd.data_ptr())
+    ref_bn.train()
+    out64 = ref_bn(y64)
+    _close(y * scale + shift, out64.float(), 2e-5)
+    _close(mean, y64.mean(0).float(), 1e-5)
+    _close(invstd, (y64.var(0, unbiased=False) + bn.eps).rsqrt().float(), 1e-5)
+    assert torch.allclose(bn.running_mean.double(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    # the fp32 partial-set form (what embed_conv_groupbias_stats leaves)
+    parts = torch.zeros(8, 2, C, device='cuda')
+    parts[3, 0], parts[3, 1] = st[0].float(), st[1].float()
+    parts[5, 0] += 1.0
+    parts[6, 0] -= 1.0
+    L.call('pdae_bn_finalize', x, C, R, None, parts.data_ptr(), 8, bn.weight.data_ptr(), bn.bias.data_ptr(),
+           float(bn.eps), 0.1, None, None, None, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+           invstd.data_ptr())
+    _close(mean, y64.mean(0).float(), 1e-5)
