@@ -216,7 +216,7 @@ def main():
                     'flops_per_launch': kern['flops'], 'timing': probe_mode,
                     'peak_note': 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
         line = {
-            'metric': 'pretrain point-clouds/sec (N=1024,G=64)', 'value': clouds_per_s, 'unit': 'clouds/s',
+            'metric': 'pretrain point-clouds/sec (N=%d,G=%d)' % (args.npoints, args.num_group), 'value': clouds_per_s, 'unit': 'clouds/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
