@@ -20,6 +20,17 @@ from .data_parallel import FlatDataParallel
 from .point_cae_transformer import draw_mask, mask_row_ids
 
 
+def _average_gradients(model):
+    """One all-reduce of the flat gradient buffer (116 MB for the Transformer DAE).  RCCL averages
+    in the collective (ReduceOp.AVG); other backends (gloo in the CPU-side tests) sum, then divide."""
+    dist = torch.distributed
+    if dist.get_backend(model.process_group) == 'nccl':
+        dist.all_reduce(model.flat_grad, op=dist.ReduceOp.AVG, group=model.process_group)
+    else:
+        dist.all_reduce(model.flat_grad, group=model.process_group)
+        model.flat_grad.div_(model.world_size)
+
+
 class GraphedTrainStep:
     MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
     RING = int(os.environ.get("PDAE_RING", "4"))   # staging slots = how many steps the host may run ahead
@@ -129,8 +140,7 @@ class GraphedTrainStep:
             g.replay()
             out = self.outputs[tvis]
         if self.model.world_size > 1:
-            torch.distributed.all_reduce(self.model.flat_grad, group=self.model.process_group)
-            self.model.flat_grad.div_(self.model.world_size)
+            _average_gradients(self.model)
         self.optimizer.step()
         return out
 
@@ -185,7 +195,6 @@ class GraphedStaticStep:
             out = self.out
         self.model.require_sync = sync
         if self.model.world_size > 1:
-            torch.distributed.all_reduce(self.model.flat_grad, group=self.model.process_group)
-            self.model.flat_grad.div_(self.model.world_size)
+            _average_gradients(self.model)
         self.optimizer.step()
         return out
