@@ -20,15 +20,24 @@ from .data_parallel import FlatDataParallel
 from .point_cae_transformer import draw_mask, mask_row_ids
 
 
+_AVG_OK = {}
+
+
 def _average_gradients(model):
     """One all-reduce of the flat gradient buffer (116 MB for the Transformer DAE).  RCCL averages
-    in the collective (ReduceOp.AVG); other backends (gloo in the CPU-side tests) sum, then divide."""
+    in the collective (ReduceOp.AVG) when the build supports it; otherwise (and with gloo in the
+    CPU-side tests) sum, then divide."""
     dist = torch.distributed
-    if dist.get_backend(model.process_group) == 'nccl':
-        dist.all_reduce(model.flat_grad, op=dist.ReduceOp.AVG, group=model.process_group)
-    else:
-        dist.all_reduce(model.flat_grad, group=model.process_group)
-        model.flat_grad.div_(model.world_size)
+    backend = dist.get_backend(model.process_group)
+    if backend == 'nccl' and _AVG_OK.get(backend, True):
+        try:
+            dist.all_reduce(model.flat_grad, op=dist.ReduceOp.AVG, group=model.process_group)
+            _AVG_OK[backend] = True
+            return
+        except (RuntimeError, ValueError, NotImplementedError):     # rejected before anything ran
+            _AVG_OK[backend] = False
+    dist.all_reduce(model.flat_grad, group=model.process_group)
+    model.flat_grad.div_(model.world_size)
 
 
 class GraphedTrainStep:
