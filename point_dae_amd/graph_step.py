@@ -127,7 +127,9 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self.pool):
+        # thread_local: only this thread's calls are checked against the capture (the RCCL
+        # watchdog thread of torch.distributed queries events while we capture)
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local'):
             out = self._fwd_bwd(tvis)
         self.model.require_sync = sync
         self.graphs[tvis], self.outputs[tvis] = g, out
@@ -198,7 +200,7 @@ class GraphedStaticStep:
                     self._fwd_bwd()
                 torch.cuda.current_stream().wait_stream(side)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                     self.out = self._fwd_bwd()
             self.graph.replay()
             out = self.out
