@@ -113,6 +113,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl')       # RCCL over xGMI
     device = torch.device('cuda', torch.cuda.current_device())
+    from point_dae_amd.graph_step import use_created_stream
+    use_created_stream(device)      # one created stream for everything: NULL-stream work breaks hipGraph replays here
 
     from point_dae_amd import builder, nn_ops
     from point_dae_amd.tuning import enable_tuned_gemms

@@ -20,6 +20,29 @@ from .data_parallel import FlatDataParallel
 from .point_cae_transformer import draw_mask, mask_row_ids
 
 
+def use_created_stream(device=None):
+    """Make a created (non-NULL) stream the current stream of this thread and return it.
+
+    Call once before building a graphed step.  On this platform work issued into the legacy NULL
+    stream while captured step graphs exist -- a checkpoint's device-to-host copies, a clone -- makes
+    every later replay at B = 128 return garbage (tools/soak.py, tools/dbg_graph_poke.py: losses of
+    ~700 instead of 0.1 from the next replay on), whether the replays themselves run on the NULL
+    stream or not; with ONE created stream for everything the same sequences are fine.  Eager
+    launches are not affected."""
+    s = torch.cuda.Stream(device)
+    s.wait_stream(torch.cuda.current_stream(device))
+    torch.cuda.set_stream(s)
+    return s
+
+
+def _warn_if_null_stream():
+    if torch.cuda.current_stream() == torch.cuda.default_stream():
+        import warnings
+        warnings.warn('graphed step built on the legacy NULL stream: call '
+                      'point_dae_amd.graph_step.use_created_stream() first (NULL-stream work between '
+                      'replays corrupts hipGraph replays on this platform)', RuntimeWarning, stacklevel=3)
+
+
 _AVG_OK = {}
 
 
@@ -63,6 +86,7 @@ class GraphedTrainStep:
                           done=None) for _ in range(self.RING)]
         self.slot = 0
         self.graphs, self.outputs = {}, {}
+        _warn_if_null_stream()
         self.pool = None
         self.eager_left = warmup_eager
         self.normal_weight = float(config.normal_weight)
@@ -138,6 +162,7 @@ class GraphedTrainStep:
     def __call__(self, points, gt=None):
         self.pts.copy_(points[:, :, :3], non_blocking=True)
         tvis = self._draw()
+        self.last_tvis = tvis
         if self.eager_left > 0:                                # first steps eager: library init, autotuning
             self.eager_left -= 1
             sync = self.model.require_sync
@@ -168,6 +193,7 @@ class GraphedStaticStep:
         self.corrupted = torch.zeros(batch_size, npoints, 3, device=dev)
         self.clean = torch.zeros(batch_size, npoints, 3, device=dev)
         self.graph, self.out = None, None
+        _warn_if_null_stream()
         self.eager_left = warmup_eager
 
     def _fwd_bwd(self):

@@ -6,6 +6,7 @@ epoch-granular scheduler -- without its per-step host syncs: the reference
 calls .item() twice and cuda.synchronize() every step (:201-217); here losses
 accumulate on the device and are read back every `log_every` steps.
 """
+import os
 import time
 
 import torch
@@ -54,6 +55,10 @@ def train_step(model, optimizer, config, points, gt, gradual_weight=0.):
 def run_net(args, config, train_writer=None, val_writer=None, log=print, log_every=50):
     rank, world = dist_utils.get_dist_info()
     device = torch.device('cuda', torch.cuda.current_device())
+    # Everything this process does on the GPU -- steps, logging reads, checkpoint copies -- goes to
+    # ONE created stream (graph_step.use_created_stream explains why).
+    from .graph_step import use_created_stream
+    use_created_stream(device)
     ds_cfg = dict(config.dataset.train.others)
     ds_cfg.update(NAME=config.dataset.train._base_.NAME, seed=args.seed + rank, device=device,
                   steps_per_epoch=getattr(args, 'steps_per_epoch', 50))

@@ -46,3 +46,14 @@ def make_clouds(seed, B, N, kind="uniform"):
         from point_dae_amd.synthetic import shapenet_like_clouds
         return shapenet_like_clouds(B, N, seed=seed)
     raise ValueError(kind)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _one_created_stream():
+    """GPU tests run on one created stream (point_dae_amd.graph_step.use_created_stream: NULL-stream
+    work between hipGraph replays corrupts the replays on this platform)."""
+    import torch
+    if torch.cuda.is_available():
+        from point_dae_amd.graph_step import use_created_stream
+        use_created_stream()
+    yield

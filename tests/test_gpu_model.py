@@ -246,3 +246,39 @@ def test_main_cli_trains_and_resumes(tmp_path):
     assert 'MAE_encoder.encoder.first_conv.0.weight' in sd['base_model']          # reference key layout
     r = subprocess.run(base + ['--resume'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_graphed_training_survives_host_copies():
+    """Regression for the NULL-stream failure (graph_step.use_created_stream): at the benchmarked batch
+    size, a checkpoint-sized device-to-host copy between hipGraph replays used to turn every later loss
+    into garbage (~700 instead of ~0.015).  On the created stream of the test session the losses of a
+    60-step run with such copies at steps 20 and 40 stay where the first 20 steps left them."""
+    import os
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.misc import set_random_seed
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    assert torch.cuda.current_stream() != torch.cuda.default_stream()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(
+        root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    set_random_seed(0)
+    model = FlatDataParallel(builder.model_builder(config.model).cuda())
+    opt, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+    B = 128
+    pool = torch.from_numpy(shapenet_like_clouds(B * 4, 1024, seed=7)).cuda().split(B)
+    step = GraphedTrainStep(model, opt, config, B, 1024)
+    losses = []
+    for i in range(60):
+        if i in (20, 40):
+            host = opt.state_dict()['state']['exp_avg'].cpu()        # 116 MB device-to-host, as a checkpoint does
+            assert torch.isfinite(host).all()
+        losses.append(step(pool[i % 4])[0].clone())      # the graph's output buffer is reused by the next replay
+    losses = torch.stack(losses).cpu()
+    assert torch.isfinite(losses).all()
+    assert losses[20:].max().item() < 2 * losses[10:20].mean().item(), losses.tolist()
+    assert losses[50:].mean().item() < losses[10:20].mean().item()     # and it keeps training
