@@ -39,7 +39,6 @@
 //     EPI_STORE_GROUPMAX     both C = acc + bias and the group max / argmax
 // Kernel "TN":  C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; reduction over
 //     the slow index M, split over blockIdx.z, fp32 atomics into C).
-#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -562,7 +561,7 @@ template <int PRO, int EPI>
 static int launch_nt(NtArgs& a, hipStream_t s) {
   const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (big_tiles >= 512 && a.N % 256 != 0 && a.N % 384 == 0) launch_nt_cfg<128, 384, PRO, EPI>(a, s);
-  else if (big_tiles >= 512 && !getenv("PDAE_LAB_NO256")) launch_nt_cfg<256, 256, PRO, EPI>(a, s);  // LAB
+  else if (big_tiles >= 512) launch_nt_cfg<256, 256, PRO, EPI>(a, s);
   else launch_nt_cfg<128, 128, PRO, EPI>(a, s);
   return check_launch("gemm_nt");
 }
