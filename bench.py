@@ -175,8 +175,12 @@ def main():
     if args.eager:
         nn_ops.set_probe(probe)
     t0 = time.perf_counter()
+    loss_first = loss_last = None
     for i in range(args.steps):
-        step(batches[i % pool])
+        out = step(batches[i % pool])
+        if i == 0:
+            loss_first = out[0].detach().clone()      # (a replayed graph's output buffer is reused by later replays)
+    loss_last = out[0].detach().clone()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,6 +236,8 @@ def main():
                        'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay',
                        'library_gemm_selection': 'TunableOp lookup of point_dae_amd/tunableop_gfx950.csv' if tuned else 'default heuristic'},
             'roofline': roof,
+            # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
+            'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
