@@ -33,7 +33,8 @@ def _worker(rank, world, port, out):
     from point_dae_amd import builder
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
-    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.graph_step import GraphedTrainStep, use_created_stream
+    use_created_stream()
     from point_dae_amd.misc import set_random_seed
     from point_dae_amd.synthetic import shapenet_like_clouds
     config = cfg_from_yaml_file(os.path.join(
