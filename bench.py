@@ -111,7 +111,7 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')       # RCCL over xGMI
+        dist.init_process_group(os.environ.get('PDAE_BENCH_BACKEND', 'nccl'))       # RCCL over xGMI (gloo: code-path test on one GPU)
     device = torch.device('cuda', torch.cuda.current_device())
     from point_dae_amd.graph_step import use_created_stream
     use_created_stream(device)      # one created stream for everything: NULL-stream work breaks hipGraph replays here
@@ -195,8 +195,10 @@ def main():
         # profiles/ holds the rocprofv3 --kernel-trace average of the same
         # kernel inside the graph replays for comparison.
         nn_ops.set_probe(probe)
+        model.require_sync = False            # rank-0-only steps: no collective (the other ranks are not in them)
         for i in range(args.probe_steps):
             train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+        model.require_sync = True
         torch.cuda.synchronize()
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
                       'timed hipGraph region' % args.probe_steps)

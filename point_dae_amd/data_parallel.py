@@ -110,6 +110,9 @@ class FlatDataParallel(nn.Module):
         Call after backward(), before optimizer.step()."""
         if self.world_size == 1:
             return
+        if not self.require_sync:          # local step (no_sync): nothing was sent, nothing to wait for
+            self._pending = [len(m) for _, _, m in self.buckets]
+            return
         if any(p != 0 for p in self._pending):
             # a parameter received no gradient this step: reduce whatever was not sent
             for b, (s, e, _) in enumerate(self.buckets):
