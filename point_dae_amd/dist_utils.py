@@ -11,8 +11,7 @@ def init_dist(launcher, backend='nccl', **kwargs):
     if launcher != 'pytorch':
         raise ValueError(f'Invalid launcher type: {launcher}')
     local_rank = int(os.environ['LOCAL_RANK'])
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, **kwargs)
 

@@ -20,7 +20,8 @@ def main(argv=None):
         torch.cuda.set_device(args.local_rank)
     else:
         args.distributed = True
-        dist_utils.init_dist(args.launcher)
+        import os
+        dist_utils.init_dist(args.launcher, backend=os.environ.get('PDAE_DIST_BACKEND', 'nccl'))
         _, args.world_size = dist_utils.get_dist_info()
     enable_tuned_gemms()
     config = get_config(args)
