@@ -205,6 +205,10 @@ def patch_embed(points, first_conv, second_conv, training, groups=None):
     BG, n, _ = points.shape
     if n != 32:
         raise NotImplementedError('the fused embedder is written for group_size 32')
+    if isinstance(first_conv[1], torch.nn.SyncBatchNorm) or isinstance(second_conv[1], torch.nn.SyncBatchNorm):
+        # --sync_bn (runner_pretrain.py:81-83, off in every shipped config): the fused embedder computes
+        # per-replica batch statistics; refusing is better than silently ignoring the flag
+        raise NotImplementedError('SyncBatchNorm in the fused patch embedder (batch statistics are per replica)')
     return PatchEmbedFunction.apply(
         points.reshape(BG * n, 3), first_conv[0].weight, first_conv[0].bias, first_conv[1].weight,
         first_conv[1].bias, first_conv[3].weight, first_conv[3].bias, second_conv[0].weight,
