@@ -73,6 +73,10 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         builder.load_model(base_model, args.start_ckpts)
     if args.sync_bn and world > 1:
         base_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(base_model)
+    if config.get('step_per_update', 1) != 1:
+        # runner_pretrain.py:188-197 accumulates gradients over step_per_update batches; every shipped
+        # config uses 1 and the steps here apply the optimiser on every batch
+        raise NotImplementedError('step_per_update != 1')
     model = FlatDataParallel(base_model)
     optimizer, scheduler = builder.build_opti_sche(model, config)
     model.zero_grad()
