@@ -10,21 +10,24 @@
 // same arithmetic class is kept -- no TF32/bf16.
 //
 // Kernel "NT":  C[M,N] = epi( pro(A)[M,K] . B[N,K]^T )          (both K-contiguous)
-//   - block tile BM x BN (256x256 with 16 waves, or 128x128 with 4), BK = 32;
-//     every wave owns 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulators/lane).
-//     Measured on MI355X: the 128x128 tile is bound by the global->LDS load path
-//     (8 B/clk/CU of L2 traffic; 97 TFLOP/s), 256x256 halves the bytes per MAC
-//     and reaches ~126 TFLOP/s on the embedder's shapes.
+//   - block tile BM x BN (256x256 with 16 waves, 128x384 with 12, or 128x128 with 4),
+//     BK = 32; every wave owns 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulators/lane).
+//     Measured on MI355X (B=128 shapes): 256x256 tiles 112-126
+//     TFLOP/s (0.70 MFMA-busy), hipBLASLt 129-139 on the same shapes.
 //   - The k index inside an 8-deep slab is permuted so that one ds_read_b128 per
 //     operand row feeds four MFMAs: lane (r = l&31, h = l>>5) supplies
 //     k = 8s + 4h + t to MFMA t (same permutation on A and B).  LDS rows are
 //     padded to 36 floats: the four 16-lane groups of a ds_read_b128 then hit 64
-//     distinct banks.  Fragment reads run one slab ahead of the MFMAs.
+//     distinct banks.
 //   - global -> registers -> LDS staging, two LDS buffers, ONE barrier per
-//     k-tile: the loads of tile t+1 are issued before the MFMAs of tile t and
-//     written to the other buffer after them.
-//   - blockIdx -> tile mapping is XCD-aware: blocks b, b+8, ... share an L2, so
-//     each XCD walks a contiguous range of tiles, n fastest.
+//     k-tile.  The issue order inside a k-tile is pinned with sched_group_barrier:
+//     the loads of tile t+1 behind the first MFMAs of tile t, one fragment read of
+//     the next 8-deep group behind every four MFMAs, the LDS stores of tile t+1
+//     behind the last ones.
+//   - persistent blocks: one residency of the chip; a block walks the tiles
+//     slot, slot + nslots, ... of its XCD's contiguous chunk (blocks b, b+8, ...
+//     share an L2; n fastest), and the slabs of consecutive tiles form one stream
+//     through the LDS double buffer, so a tile boundary costs only the epilogue.
 //   producers (applied to A while it is staged):
 //     PRO_BNRELU   a := max(0, a * scale[k] + shift[k])   -- BatchNorm + ReLU of
 //                  the previous layer never materialised
@@ -38,7 +41,9 @@
 //                            it; C itself is never written (max-pool fused)
 //     EPI_STORE_GROUPMAX     both C = acc + bias and the group max / argmax
 // Kernel "TN":  C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; reduction over
-//     the slow index M, split over blockIdx.z, fp32 atomics into C).
+//     the slow index M, split across blocks -- exactly one residency of the chip,
+//     all tiles of a split on one XCD -- fp32 atomics into C; optional producer on
+//     B, group-list row gather, fused column sums of A = the bias gradient).
 #include <type_traits>
 #include "common.h"
 
