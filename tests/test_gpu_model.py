@@ -297,6 +297,7 @@ def test_graphed_static_step_equals_eager_step():
     from point_dae_amd.synthetic import shapenet_like_clouds
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     config = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'))
+    config.optimizer.kwargs.lr = 1e-4          # small steps: the comparison is about the launches, not about chaos
     torch.manual_seed(0)
     net_a = builder.model_builder(config.model).cuda().train()
     net_b = copy.deepcopy(net_a)
@@ -328,6 +329,6 @@ def test_graphed_static_step_equals_eager_step():
     assert step.graph is not None
     # the first steps see (almost) identical parameters; AdamW then amplifies the fp32 atomics-order noise
     for i, ((a0, a1), (b0, b1)) in enumerate(zip(eager, graphed)):
-        tol = 1e-4 if i < 2 else 3e-2
+        tol = 1e-4 if i < 2 else 1e-2
         assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (i, eager, graphed)
     assert (model_a.flat_param - model_b.flat_param).abs().max().item() < 2e-2
