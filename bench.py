@@ -1,8 +1,12 @@
 """bench.py -- pretraining throughput of the Point-DAE hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...        # N > 1 without a launcher: starts the N ranks itself (child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`--gpus N` is binding: the run refuses (exit != 0) when fewer than N GPUs are visible or when a
+launcher's WORLD_SIZE differs from N, instead of reporting an N-GPU number from fewer ranks.
 
 A "step" is one full optimisation step (FPS -> kNN grouping -> in-forward
 corruption -> patch embedder -> masked Transformer encoder/decoder -> Chamfer
@@ -101,17 +105,61 @@ def cpu_baseline(config, args):
                           args.cpu_steps, args.cpu_batch, args.npoints, args.num_group, dt)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a
+    CHILD process (`python -m torch.distributed.run`, one rank per GPU over RCCL), relay rank 0's
+    JSON line and return the child's exit code.  Nothing in this (parent) process touches the GPU:
+    torch.cuda.device_count() does not initialise it on this image, and the child is a new process,
+    never an exec of this one.  The reference's launcher is `torch.distributed.launch` around
+    main.py (utils/dist_utils.py:9-29, main.py:57-59)."""
+    import socket
+    import subprocess
+    backend = os.environ.get('PDAE_BENCH_BACKEND', 'nccl')
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and have < args.gpus:      # RCCL needs one device per rank
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report a '
+                         '%d-GPU number from fewer devices\n' % (args.gpus, have, args.gpus))
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for ln in child.stdout:
+        if ln.startswith('{"metric"'):
+            lines += 1
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write('bench.py: the ranks exited 0 but printed %d result lines\n' % lines)
+        return 3
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d does not match WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path in point_dae_amd)')
+    backend = os.environ.get('PDAE_BENCH_BACKEND', 'nccl')      # nccl = RCCL over xGMI (gloo: code-path test on one GPU)
+    if world > 1 and backend == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: %d ranks but %d GPU(s): RCCL needs one device per rank' % (
+            world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(os.environ.get('PDAE_BENCH_BACKEND', 'nccl'))       # RCCL over xGMI (gloo: code-path test on one GPU)
+        dist.init_process_group(backend)
     device = torch.device('cuda', torch.cuda.current_device())
     from point_dae_amd.graph_step import use_created_stream
     use_created_stream(device)      # one created stream for everything: NULL-stream work breaks hipGraph replays here
@@ -227,7 +275,8 @@ def main():
                     'peak_note': 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
         line = {
             'metric': 'pretrain point-clouds/sec (N=%d,G=%d)' % (args.npoints, args.num_group), 'value': clouds_per_s, 'unit': 'clouds/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if world > 1 and backend == 'nccl' else (1 if world == 1 else 0)),
+            'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': ('cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '

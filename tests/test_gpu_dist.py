@@ -68,21 +68,42 @@ def test_two_ranks_graphed_step_stay_in_sync(tmp_path):
     assert r['losses'][-1] < r['losses'][0], r['losses']
 
 
-def test_bench_two_ranks_code_path():
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_two_ranks_code_path(launcher):
     """bench.py's N > 1 path end to end (launcher env, broadcast, graphed steps with the gradient
     all-reduce, rank-0-only roofline probe, max-over-ranks timing) with two gloo ranks sharing the GPU --
-    RCCL needs one device per rank, so this checks the code path, not the collective's speed."""
+    RCCL needs one device per rank, so this checks the code path, not the collective's speed.
+    'self': `python bench.py --gpus 2` with NO launcher must start the two ranks itself."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PDAE_BENCH_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
-           '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '8', '--probe-steps', '2']
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '8',
+            '--probe-steps', '2']
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 16 and d['scaling'] == 'weak'
     assert d['value'] > 0 and d['roofline'] is not None and 'cpu_baseline' not in d
+    assert d['rccl_ranks'] == 0          # gloo ranks: not an RCCL measurement, and the line says so
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus 8` on a 1-GPU box must fail, not print an n_gpus=1 line (RCCL: one device per rank)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PDAE_BENCH_BACKEND')}
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(want), '--steps', '1',
+                        '--warmup', '0'], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '{"metric"' not in r.stdout, (r.returncode, r.stdout[-500:])
