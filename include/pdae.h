@@ -191,6 +191,51 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
                                 float* dbias /*nullable*/, pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Dense layers of the Transformer blocks (csrc/rows_gemm.hip): Attention.qkv /
+ * proj (models/PointCAE_transformer.py:113-137), Mlp.fc1 / act / fc2 (:94-110),
+ * pos_embed (:329-333), increase_dim (:653-658), and their backward.  Small-M
+ * GEMMs (M = B * T tokens): a family of tile shapes, a per-shape plan, optional
+ * split-K into slabs, no atomics (results are bit-identical run to run).
+ *
+ *   rows_gemm:  Y[M,N] = epi(X[M,K] . op(W))
+ *       w_kn = 0: W is [N,K] (torch's (out,in) layout: a Linear's forward)
+ *       w_kn = 1: W is [K,N] (the same (out,in) weight as the data-gradient
+ *                 operand: dX[M,in] = dY[M,out] . W[out,in]; no transposed copy)
+ *       epi  = 0: Y = acc (+ bias, nullable)
+ *              1: Y = ReLU(acc + bias)                              (w_kn = 0)
+ *              2: z = acc + bias, Y = GELU(z), Z = GELU'(z)   fc1 + nn.GELU in
+ *                 one pass; Z is the factor the backward needs     (w_kn = 0)
+ *              3: Y = acc * Z                   backward of 2: X = the gradient
+ *                 of fc2's output, W = fc2's weight, Z from the forward: Y is
+ *                 the gradient of fc1's output                     (w_kn = 1)
+ *       cfg    : tile shape 0..7, or -1 = planned per shape
+ *       splits : 1, or S in 2..8 = split the reduction: Y is then S slabs
+ *                [S][M][N] of partial products (epi 0, no bias) which the
+ *                consumer adds up (residual_layernorm_forward / layernorm_backward
+ *                take a slab count); -1 = 1.
+ *   rows_gemm_plan: the (cfg, splits) rows_gemm would pick; may_split = 0 keeps
+ *       splits = 1.
+ *   rows_wgrad: weight gradients of a GROUP of nprob <= 8 Linear layers that
+ *       share M in one launch: dW_p[N_p,K_p] = dY_p[M,N_p]^T . X_p[M,K_p],
+ *       db_p[N_p] = column sums of dY_p (db or db[p] nullable).  Pointer arrays
+ *       are HOST arrays of device pointers.  (tile, 32-row chunk) work units are
+ *       dealt in equal contiguous ranges to one residency of the chip; the
+ *       partial tiles go to `workspace` and are added in block order by a second
+ *       launch; rows_wgrad_workspace returns the workspace size in floats.
+ */
+int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn,
+                   const float* bias /*nullable*/, int epi, float* Z /*epi 2,3*/,
+                   float* Y, int cfg, int splits, pdae_stream_t stream);
+int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg,
+                        int* splits);
+int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks,
+                              long long* floats);
+int pdae_rows_wgrad(int M, int nprob, const float* const* dY,
+                    const float* const* X, float* const* dW,
+                    float* const* db /*nullable*/, const int* Ns, const int* Ks,
+                    float* workspace, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Fused layers of the patch embedder, Encoder.forward
  * (models/PointCAE_transformer.py:37-51).  Rows are points, 32 consecutive rows
  * form one group (patch); M % 32 == 0.  The reference runs each of these as a
@@ -332,7 +377,7 @@ int pdae_add_layernorm_forward(int M, int C, const float* x,
                                const float* beta, float eps,
                                float* xsum /*nullable*/, float* y, float* mean,
                                float* rstd, pdae_stream_t stream);
-int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
+int pdae_layernorm_backward(int M, int C, const float* dy, int dy_slabs, const float* x,
                             const float* mean, const float* rstd,
                             const float* gamma, const float* dres /*nullable*/,
                             float* dx, float* dgamma, float* dbeta,
@@ -343,15 +388,18 @@ int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
  *       xsum receives s.  bias / keep / pos nullable.  Backward:
  *       dx = LayerNorm'(dy) + dres (the gradient w.r.t. s = w.r.t. res and pos);
  *       da = keep[row/T] * dx (written only when keep is given; otherwise da == dx);
- *       dbias = column sums of da; dgamma / dbeta as layernorm_backward.        */
-int pdae_residual_layernorm_forward(int M, int C, int T, const float* a,
+ *       dbias = column sums of da; dgamma / dbeta as layernorm_backward.
+ *       a_slabs / dy_slabs (1..8): `a` / `dy` arrive as that many split-K slabs
+ *       [slabs][M][C] of partial products (pdae_rows_gemm with splits > 1) and are
+ *       added up in slab order while they are read; 1 = a plain [M][C] matrix.     */
+int pdae_residual_layernorm_forward(int M, int C, int T, const float* a, int a_slabs,
                                     const float* bias /*nullable*/,
                                     const float* keep /*nullable*/,
                                     const float* res, const float* pos /*nullable*/,
                                     const float* gamma, const float* beta,
                                     float eps, float* xsum, float* y, float* mean,
                                     float* rstd, pdae_stream_t stream);
-int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy,
+int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, int dy_slabs,
                                      const float* x, const float* mean,
                                      const float* rstd, const float* gamma,
                                      const float* dres /*nullable*/,

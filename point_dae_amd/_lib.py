@@ -31,6 +31,8 @@ _SIGNATURES = {
     "pdae_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "pdae_linear_backward_data": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_rows_gemm": [_i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "pdae_rows_wgrad": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -42,15 +44,15 @@ _SIGNATURES = {
     "pdae_attention_forward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "pdae_attention_backward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_add_layernorm_forward": [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
-    "pdae_layernorm_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_layernorm_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_bias_gelu_forward": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_bias_gelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_gelu_forward": [ctypes.c_longlong, _vp, _vp, _vp],
     "pdae_gelu_backward": [ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_colsum": [_i, _i, _vp, _vp, _i, _vp],
-    "pdae_residual_layernorm_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
-    "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_residual_layernorm_forward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_scale_colsum": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_embed_conv1_stats": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bn_finalize": [_i, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -58,6 +60,11 @@ _SIGNATURES = {
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+# host-side queries (no stream argument)
+_HOST = {
+    "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp],
+    "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
 }
 _STR = ("pdae_version", "pdae_last_error")
 
@@ -70,7 +77,7 @@ class NativeLibraryMissing(RuntimeError):
 
 def exported_symbols():
     """Every symbol include/pdae.h declares (used by the CPU-side ABI test)."""
-    return list(_SIGNATURES) + list(_STR)
+    return list(_SIGNATURES) + list(_HOST) + list(_STR)
 
 
 def lib():
@@ -83,6 +90,10 @@ def lib():
                 "g.build()'` (hipcc --offload-arch=gfx950). point_dae_amd has no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        for name, argtypes in _HOST.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
@@ -130,3 +141,51 @@ def call(name, on, *args):
     if rc != 0:
         msg = handle.pdae_last_error().decode()
         raise RuntimeError(f"{name} failed with status {rc}: {msg}")
+
+
+def _check(handle, name, rc):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}: {handle.pdae_last_error().decode()}")
+
+
+_plan_cache = {}
+
+
+def rows_gemm_plan(M, N, K, w_kn, may_split):
+    """(cfg, splits) of pdae_rows_gemm for a shape (host-side query, cached)."""
+    key = (M, N, K, w_kn, may_split)
+    hit = _plan_cache.get(key)
+    if hit is None:
+        handle = lib()
+        cfg, splits = ctypes.c_int(0), ctypes.c_int(0)
+        _check(handle, 'pdae_rows_gemm_plan',
+               handle.pdae_rows_gemm_plan(M, N, K, int(w_kn), int(may_split), ctypes.byref(cfg), ctypes.byref(splits)))
+        hit = _plan_cache[key] = (cfg.value, splits.value)
+    return hit
+
+
+_wg_cache = {}
+
+
+def rows_wgrad_workspace(M, Ns, Ks):
+    """workspace floats of pdae_rows_wgrad for a group of layers (cached)."""
+    key = (M, tuple(Ns), tuple(Ks))
+    hit = _wg_cache.get(key)
+    if hit is None:
+        handle = lib()
+        n = len(Ns)
+        arr = ctypes.c_int * n
+        floats = ctypes.c_longlong(0)
+        _check(handle, 'pdae_rows_wgrad_workspace',
+               handle.pdae_rows_wgrad_workspace(M, n, arr(*Ns), arr(*Ks), ctypes.byref(floats)))
+        hit = _wg_cache[key] = floats.value
+    return hit
+
+
+def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace):
+    """pdae_rows_wgrad over lists of tensors (dbs entries may be None)."""
+    n = len(dYs)
+    parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
+    call('pdae_rows_wgrad', on, M, n, parr(*[ptr(t) for t in dYs]), parr(*[ptr(t) for t in Xs]),
+         parr(*[ptr(t) for t in dWs]), parr(*[ptr(t) for t in dbs]),
+         iarr(*[t.shape[1] for t in dYs]), iarr(*[t.shape[1] for t in Xs]), ptr(workspace))

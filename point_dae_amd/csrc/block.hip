@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ xsum, float* __restrict__ y, float* __restrict__ mean,
     float* __restrict__ rstd, const float* __restrict__ br, const float* __restrict__ bias,
-    const float* __restrict__ keep, int T) {
+    const float* __restrict__ keep, int T, int br_slabs) {
+  // br_slabs > 1: the branch arrives as split-K slabs [br_slabs][M][C] of partial products
+  // (rows_gemm.hip), added up here in slab order
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = lane_id();
@@ -45,6 +47,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
       float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * C + c4 * 4);
       if (br) {      // same operation order as scale_residual: res + keep * (a + bias)
         float4 t = *reinterpret_cast<const float4*>(br + (size_t)row * C + c4 * 4);
+        for (int q = 1; q < br_slabs; ++q) {
+          const float4 u = *reinterpret_cast<const float4*>(br + ((size_t)q * M + row) * C + c4 * 4);
+          t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+        }
         if (bias) {
           const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
           t.x += b.x, t.y += b.y, t.z += b.z, t.w += b.w;
@@ -107,7 +113,8 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ keep, int T,
-    float* __restrict__ da, float* __restrict__ dbias) {
+    float* __restrict__ da, float* __restrict__ dbias, int dy_slabs) {
+  // (dy_slabs > 1: dy arrives as split-K slabs [dy_slabs][M][C], added up in slab order)
   // (keep / da / dbias: the backward of the branch folded into the forward -- da =
   //  keep[row/T] * dx, dbias += column sums of da; see residual_layernorm_backward)
   extern __shared__ float red[];  // [NW][3][C]: one plain-store slot per wave (LDS float
@@ -131,6 +138,10 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
       const bool on = c4 < n4 && row < M;
       const size_t off = (size_t)row * C + c4 * 4;
       d[i] = on ? *reinterpret_cast<const float4*>(dy + off) : zero4;
+      for (int q = 1; q < dy_slabs; ++q) {
+        const float4 u = on ? *reinterpret_cast<const float4*>(dy + (size_t)q * M * C + off) : zero4;
+        d[i].x += u.x, d[i].y += u.y, d[i].z += u.z, d[i].w += u.w;
+      }
       xv[i] = on ? *reinterpret_cast<const float4*>(x + off) : zero4;
       e[i] = (on && dres) ? *reinterpret_cast<const float4*>(dres + off) : zero4;
     }
@@ -197,16 +208,6 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     for (int k = 0; k < NW; ++k) t += red[(size_t)k * nred * C + c];
     atomicAdd(c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : dbias + (c - 2 * C)), t);
   }
-}
-
-__device__ __forceinline__ float gelu_f(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float gelu_grad_f(float v) {
-  // d/dv [v Phi(v)] = Phi(v) + v phi(v)
-  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-  return cdf + v * pdf;
 }
 
 // h = gelu(z + bias[col]); backward: dz = dh * gelu'(z + bias), dbias += colsum(dz)
@@ -386,14 +387,14 @@ static int cs_rows(int M) {
 static int ln_forward(const char* what, int M, int C, int T, const float* x, const float* br,
                       const float* bias, const float* keep, const float* pos, const float* gamma,
                       const float* beta, float eps, float* xsum, float* y, float* mean, float* rstd,
-                      pdae_stream_t stream) {
-  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0)
-    return bad_arg("layernorm forward: C must be a multiple of 4, at most 2048; T > 0");
+                      int br_slabs, pdae_stream_t stream) {
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0 || br_slabs < 1 || br_slabs > 8)
+    return bad_arg("layernorm forward: C must be a multiple of 4, at most 2048; T > 0; 1..8 slabs");
   if (M == 0) return PDAE_OK;
   if (!x || !gamma || !beta || !y || !mean || !rstd || ((pos || br) && !xsum) || ((bias || keep) && !br))
     return bad_arg("layernorm forward: null pointer");
   hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), M,
-                     C, x, pos, gamma, beta, eps, xsum, y, mean, rstd, br, bias, keep, T);
+                     C, x, pos, gamma, beta, eps, xsum, y, mean, rstd, br, bias, keep, T, br_slabs);
   return check_launch(what);
 }
 
@@ -402,25 +403,25 @@ extern "C" int pdae_add_layernorm_forward(int M, int C, const float* x, const fl
                                           float* xsum, float* y, float* mean, float* rstd,
                                           pdae_stream_t stream) {
   return ln_forward("add_layernorm_forward", M, C, 1, x, nullptr, nullptr, nullptr, pos, gamma, beta, eps,
-                    xsum, y, mean, rstd, stream);
+                    xsum, y, mean, rstd, 1, stream);
 }
 
-extern "C" int pdae_residual_layernorm_forward(int M, int C, int T, const float* a, const float* bias,
+extern "C" int pdae_residual_layernorm_forward(int M, int C, int T, const float* a, int a_slabs, const float* bias,
                                                const float* keep, const float* res, const float* pos,
                                                const float* gamma, const float* beta, float eps,
                                                float* xsum, float* y, float* mean, float* rstd,
                                                pdae_stream_t stream) {
   if (!a) return bad_arg("residual_layernorm_forward: null pointer");
   return ln_forward("residual_layernorm_forward", M, C, T, res, a, bias, keep, pos, gamma, beta, eps, xsum,
-                    y, mean, rstd, stream);
+                    y, mean, rstd, a_slabs, stream);
 }
 
-static int ln_backward(const char* what, int M, int C, int T, const float* dy, const float* x,
+static int ln_backward(const char* what, int M, int C, int T, const float* dy, int dy_slabs, const float* x,
                        const float* mean, const float* rstd, const float* gamma, const float* dres,
                        const float* keep, float* dx, float* da, float* dgamma, float* dbeta, float* dbias,
                        int accumulate, pdae_stream_t stream) {
-  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0)
-    return bad_arg("layernorm backward: C must be a multiple of 4, at most 2048; T > 0");
+  if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0 || dy_slabs < 1 || dy_slabs > 8)
+    return bad_arg("layernorm backward: C must be a multiple of 4, at most 2048; T > 0; 1..8 slabs");
   if (!dgamma || !dbeta) return bad_arg("layernorm backward: null pointer");
   hipStream_t s = as_stream(stream);
   if (!accumulate) {
@@ -439,33 +440,33 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, c
     const int rows = 16 * per_wave;
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
                        16 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias);
+                       dbeta, keep, T, da, dbias, dy_slabs);
   } else {
     int rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
     if (rows > 32) rows = 32;
     hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3((M + rows - 1) / rows), dim3(256),
                        4 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias);
+                       dbeta, keep, T, da, dbias, dy_slabs);
   }
   return check_launch(what);
 }
 
-extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, const float* x,
+extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, int dy_slabs, const float* x,
                                        const float* mean, const float* rstd, const float* gamma,
                                        const float* dres, float* dx, float* dgamma, float* dbeta,
                                        int accumulate, pdae_stream_t stream) {
-  return ln_backward("layernorm_backward", M, C, 1, dy, x, mean, rstd, gamma, dres, nullptr, dx, nullptr,
+  return ln_backward("layernorm_backward", M, C, 1, dy, dy_slabs, x, mean, rstd, gamma, dres, nullptr, dx, nullptr,
                      dgamma, dbeta, nullptr, accumulate, stream);
 }
 
-extern "C" int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, const float* x,
+extern "C" int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, int dy_slabs, const float* x,
                                                 const float* mean, const float* rstd,
                                                 const float* gamma, const float* dres,
                                                 const float* keep, float* dx, float* da, float* dgamma,
                                                 float* dbeta, float* dbias, int accumulate,
                                                 pdae_stream_t stream) {
   if (!dbias) return bad_arg("residual_layernorm_backward: null pointer");
-  return ln_backward("residual_layernorm_backward", M, C, T, dy, x, mean, rstd, gamma, dres, keep, dx, da,
+  return ln_backward("residual_layernorm_backward", M, C, T, dy, dy_slabs, x, mean, rstd, gamma, dres, keep, dx, da,
                      dgamma, dbeta, dbias, accumulate, stream);
 }
 

@@ -45,6 +45,17 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// exact (erf) GELU of nn.GELU (models/PointCAE_transformer.py:94-110) and its derivative
+__device__ __forceinline__ float gelu_f(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  // d/dv [v Phi(v)] = Phi(v) + v phi(v)
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
 // ---- 64-lane shuffles on 64-bit keys (two ds_bpermute each) ----------------
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src_lane) {
   const unsigned lo = (unsigned)__shfl((int)(unsigned)(v & 0xffffffffull), src_lane, kWave);

@@ -1,0 +1,790 @@
+// rows_gemm.hip -- the dense layers of the Transformer blocks on the gfx950 matrix cores.
+//
+// The reference runs qkv / proj (models/PointCAE_transformer.py:113-137), fc1 / fc2 (:94-110),
+// pos_embed (:329-333) and increase_dim (:653-658) through cuBLAS, with bias, GELU and their
+// backward twins as separate passes.  The shapes are SMALL for a 256-CU chip: M = B * T rows
+// with T = 13..32 visible tokens (M = 1664..4096) in the encoder and M = 8192 in the decoder,
+// N, K in {384, 1152, 1536}: 5-25 us of MFMA time per GEMM, where a tile grid that does not
+// divide the chip and the fixed cost of a block's first load / last store decide the result.
+// Hence a family of tile shapes (64x64 .. 128x192, always 4 waves so the four SIMDs of a CU
+// carry equal work), several independent blocks resident per CU (one block's prologue and
+// epilogue under another's MFMAs), optional split-K into slabs that the consuming LayerNorm
+// kernel adds up, and a per-shape plan (plan_rows) that picks tile and split by the number of
+// MFMA rounds the grid costs.  fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32, the same
+// arithmetic class as the reference's.
+//
+//   rows_gemm_kernel   C[M,N] = epi(A[M,K] . op(B));  op(B) = B[N,K]^T (a Linear's forward) or
+//                      B[K,N] (the same weight as the data-gradient operand, no transposed copy)
+//     epilogues: store (+bias) | bias+ReLU | z = acc+bias: GELU(z) -> C and GELU'(z) -> Z (fc1 +
+//                act: the activation and the factor its backward needs, one erf for both) |
+//                C = acc * Z (backward of the former: dz comes out of the dh GEMM as a multiply;
+//                evaluating GELU' there cost 27 us per decoder block)
+//   wgrad_kernel       dW_p[N_p,K_p] = dY_p[M,N_p]^T . X_p[M,K_p] for a GROUP of layers in one
+//                      launch (a block's qkv, proj, fc1, fc2: 108 tiles instead of four grids of
+//                      9-36), reduction over M split into slabs, + column sums of dY (bias grad)
+//   wgrad_reduce       slabs -> gradients in fixed split order: no atomics anywhere, results are
+//                      bit-identical run to run
+#include <type_traits>
+#include <utility>
+#include "common.h"
+
+namespace pdae {
+namespace rows {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32, LD = BK + 4;   // LDS rows of 36 floats: ds_read_b128 of 16 lanes hits 64 banks
+
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_GELU2 = 2, EPI_MUL_GELUGRAD = 3 };
+
+struct Args {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* B;
+  int ldb;
+  float* C;
+  int ldc;
+  float* Z;           // EPI_BIAS_GELU2: GELU'(z) written;  EPI_MUL_GELUGRAD: read   (leading dimension ldc)
+  const float* bias;  // [N] or null
+  int tiles_n, tiles;
+  int kchunk;         // reduction range of one split (blockIdx.y), a multiple of BK
+  long long slab;     // elements between the C slabs of consecutive splits
+#ifdef PDAE_ROWS_STAMPS
+  long long* stamps;  // diagnostic build (tools/lab): [block][8] s_memrealtime / s_memtime marks
+#endif
+};
+
+#ifdef PDAE_ROWS_STAMPS
+#define PDAE_STAMP(i)                                                                                   \
+  if (p.stamps && threadIdx.x == 0) {                                                                   \
+    p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();  \
+  }
+#else
+#define PDAE_STAMP(i)
+#endif
+
+// Block tile (32 TI WM) x (32 TJ WN), WM x WN waves, every wave TI x TJ MFMA tiles of 32x32.
+// k permutation inside an 8-deep slab as in gemm.hip: lane (r = l & 31, h = l >> 5) supplies
+// k = 8s + 4h + t to MFMA t, so one ds_read_b128 of a K-contiguous operand row feeds four MFMAs.
+// BKN: B is stored [K][N] (N contiguous): staged as [k][n] rows, fragments by ds_read_b32
+// (lanes r -> consecutive banks).
+// Pipeline: global -> registers -> LDS (two buffers), one barrier per 32-deep k-tile.  A k-tile is
+// 1-4 k MFMA cycles per wave, an L2 round trip under load ~2 k: TWO k-tiles of loads are in flight
+// in two register sets (one on the 128x192 tile, whose accumulators leave no room); the main loop
+// is branch-free (the last iterations re-load the last tile instead of testing for the end), so
+// the loads and LDS stores of the next tiles interleave with the MFMAs of this one.
+template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)))
+void rows_gemm_kernel(const Args p) {
+  constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN, NT = 64 * WM * WN;
+  constexpr int LA = (BM * 8) / NT, LB = (BN * 8) / NT;   // float4 per thread and k-tile
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "every thread stages LA + LB float4 per k-tile");
+  constexpr int ASZ = BM * LD, BSZ = BKN ? BK * BN : BN * LD;
+  constexpr int BQ = BN / 4;                               // float4 per staged [k][n] row
+  constexpr int PF = TI * TJ <= 4 ? 2 : 1;                 // k-tiles of global loads in flight (register sets)
+  extern __shared__ float lds[];                           // [2][ASZ + BSZ]
+  // XCD-aware order: blocks b, b + 8, ... share an L2; each XCD owns a contiguous chunk of tiles
+  // (n fastest), so the tiles_n re-reads of an A row band hit that L2.
+  const int chunk = (p.tiles + 7) >> 3;
+  const int slot = blockIdx.x >> 3;
+  const int tile = (blockIdx.x & 7) * chunk + slot;
+  if (slot >= chunk || tile >= p.tiles) return;
+#ifdef PDAE_ROWS_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    long long* st = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    st[4] = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    st[5] = ((long long)xcc << 32) | hwid;
+  }
+#endif
+  PDAE_STAMP(0)
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int M = p.M, N = p.N;
+  const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int scol = (tid & 7) * 4;
+
+  // 32-bit BYTE offsets from the (uniform) operand bases: one VGPR per staged row and the
+  // scalar-base + vector-offset form of global_load (the launcher checks the operands are < 4 GB);
+  // rows past the matrix edge are clamped (their products are never stored)
+  unsigned aoff[LA], boff[LB];
+  bool bcol_ok[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i)
+    aoff[i] = ((unsigned)min(m0 + ((tid + i * NT) >> 3), M - 1) * (unsigned)p.lda + scol) * 4u;
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    if (BKN) {
+      const int c = n0 + ((tid + i * NT) % BQ) * 4;
+      bcol_ok[i] = c < N;
+      boff[i] = ((unsigned)((tid + i * NT) / BQ) * (unsigned)p.ldb + (unsigned)min(c, N - 4)) * 4u;
+    } else {
+      bcol_ok[i] = true;
+      boff[i] = ((unsigned)min(n0 + ((tid + i * NT) >> 3), N - 1) * (unsigned)p.ldb + scol) * 4u;
+    }
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Bb = reinterpret_cast<const char*>(p.B);
+  const size_t bstep = BKN ? (size_t)p.ldb * 4 : 4;        // bytes per unit of k in B
+  const int KT = (kend - kbeg + BK - 1) / BK;
+  // guarded loads only where the tile is not whole: a partial last k-tile (K % 32 != 0) or the
+  // last column tile of a [K][N] operand
+  const bool guarded = (kend - kbeg) % BK != 0 || (BKN && n0 + BN > N);
+
+  auto load_set = [&](float4 (&ra)[LA], float4 (&rb)[LB], int kt, auto guard_c) __attribute__((always_inline)) {
+    constexpr bool GUARD = decltype(guard_c)::value;
+    const int k = kbeg + min(kt, KT - 1) * BK;             // past the end: the last tile again (never stored... or stored where nobody reads)
+    const char* Ak = Ab + (size_t)k * 4;
+    const char* Bk = Bb + (size_t)k * bstep;
+    if (!GUARD) {
+#pragma unroll
+      for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(Ak + aoff[i]);
+#pragma unroll
+      for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bk + boff[i]);
+    } else {
+      const bool ain = k + scol < kend;
+#pragma unroll
+      for (int i = 0; i < LA; ++i) {
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ain) ra[i] = *reinterpret_cast<const float4*>(Ak + aoff[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in = BKN ? (bcol_ok[i] && k + (tid + i * NT) / BQ < kend) : ain;
+        if (in) rb[i] = *reinterpret_cast<const float4*>(Bk + boff[i]);
+      }
+    }
+  };
+  auto store_set = [&](const float4 (&ra)[LA], const float4 (&rb)[LB], int buf) __attribute__((always_inline)) {
+    float* As = lds + buf * (ASZ + BSZ);
+    float* Bs = As + ASZ;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(As + ((tid + i * NT) >> 3) * LD + scol) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      if (BKN) *reinterpret_cast<float4*>(Bs + (tid + i * NT) * 4) = rb[i];   // [k][n], n contiguous
+      else *reinterpret_cast<float4*>(Bs + ((tid + i * NT) >> 3) * LD + scol) = rb[i];
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x16 acc2;                                             // second chain of the single-tile wave (odd k-steps)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+
+  int buf = 0;
+  // One k-tile: MFMAs on LDS[buf] (tile kt); meanwhile the loads of tile kt + PF go into the
+  // register set `ld` and the set `st` (tile kt + 1) goes to LDS[buf ^ 1]; one barrier.
+  // ONE wave per SIMD issues in order: eight global loads in a row in front of the MFMAs leave the
+  // matrix pipe idle for ~640 cycles per k-tile, eight ds_write_b128 in a row for ~370 (in-kernel
+  // stamps, tools/lab/stamps.py), while one or two memory instructions behind a group of four
+  // MFMAs (256 cycles) are free.  So the order is written out -- after MFMA group (s, i, j) come
+  // its share of the global loads (slab 0), of the LDS stores (slab 1 with two register sets: their
+  // data landed a k-tile ago) and of the next slab's fragment reads -- and a sched_barrier keeps the
+  // compiler from regrouping them.  With two register sets the barrier sits INSIDE the last slab,
+  // behind its first MFMAs, and the first fragments of the next k-tile are read right behind it:
+  // the LDS round trip at the k-tile boundary (~390 cycles per k-tile of 1024 MFMA cycles on the
+  // 64x64 tile) runs under the slab's remaining MFMAs.
+  float4 a[2][TI], b[2][TJ];                               // fragments: [slab parity][tile]
+  constexpr int G = TI * TJ, NL = LA + LB, NF = TI + TJ;
+  auto frag = [&](const float* As, const float* Bs, int st, int s, int q) __attribute__((always_inline)) {   // fragment q of slab s: A rows first, then B
+    if (q < TI) {
+      a[st][q] = *reinterpret_cast<const float4*>(As + q * 32 * LD + s * 8);
+    } else if (BKN) {
+      const float* w = Bs + s * 8 * BN + (q - TI) * 32;
+      b[st][q - TI] = make_float4(w[0], w[BN], w[2 * BN], w[3 * BN]);
+    } else {
+      b[st][q - TI] = *reinterpret_cast<const float4*>(Bs + (q - TI) * 32 * LD + s * 8);
+    }
+  };
+  auto frag_base = [&](int bf, const float*& As, const float*& Bs) __attribute__((always_inline)) {
+    As = lds + bf * (ASZ + BSZ) + (wm * TI * 32 + r) * LD + 4 * h;
+    Bs = lds + bf * (ASZ + BSZ) + ASZ + (BKN ? 4 * h * BN + wn * TJ * 32 + r : (wn * TJ * 32 + r) * LD + 4 * h);
+  };
+  auto ktile = [&](float4 (&lda_)[LA], float4 (&ldb_)[LB], float4 (&sta_)[LA], float4 (&stb_)[LB], int kt,
+                   auto guard_c) __attribute__((always_inline)) {
+    constexpr bool GUARD = decltype(guard_c)::value;
+    constexpr int SST = PF == 2 ? 1 : BK / 8 - 1;          // the slab whose MFMAs cover the LDS stores
+    const int kl = kbeg + min(kt + PF, KT - 1) * BK;       // past the end: the last tile again (stored where nobody reads)
+    const char* Ak = Ab + (size_t)kl * 4;
+    const char* Bk = Bb + (size_t)kl * bstep;
+    if (GUARD) load_set(lda_, ldb_, kt + PF, guard_c);     // (guarded loads sit behind branches: nothing to interleave)
+    const float *As, *Bs, *An, *Bn;
+    frag_base(buf, As, Bs);
+    frag_base(buf ^ 1, An, Bn);
+    float* Ad = lds + (buf ^ 1) * (ASZ + BSZ);
+    float* Bd = Ad + ASZ;
+    if (PF == 1) {
+#pragma unroll
+      for (int q = 0; q < NF; ++q) frag(As, Bs, 0, 0, q);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      const bool last = s == BK / 8 - 1;
+      // four rounds (the k-steps x, y, z, w of the slab), each ONE MFMA per accumulator tile: back
+      // to back MFMAs on the same accumulator issue every ~72 cycles, on alternating accumulators
+      // every 64 (measured: the 64x64 tile's single chain ran 13 % under the rate)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int i = g / TJ, j = g % TJ;
+          const float av = t == 0 ? a[cur][i].x : t == 1 ? a[cur][i].y : t == 2 ? a[cur][i].z : a[cur][i].w;
+          const float bv = t == 0 ? b[cur][j].x : t == 1 ? b[cur][j].y : t == 2 ? b[cur][j].z : b[cur][j].w;
+          if (G == 1 && (t & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+        }
+        if (PF == 2 && last && t == 0) {
+#ifndef PDAE_LAB_NOBARRIER
+          __syncthreads();
+#endif
+#pragma unroll
+          for (int q = 0; q < NF; ++q) frag(An, Bn, nxt, 0, q);
+        }
+        if (!last) {
+#pragma unroll
+          for (int q = 0; q < NF; ++q)
+            if ((q * 4) / NF == t) frag(As, Bs, nxt, s + 1, q);
+        }
+#ifndef PDAE_LAB_NOGLOAD
+        if (!GUARD && s == 0) {
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if ((l * 4) / NL == t) {
+              if (l < LA) lda_[l] = *reinterpret_cast<const float4*>(Ak + aoff[l]);
+              else ldb_[l - LA] = *reinterpret_cast<const float4*>(Bk + boff[l - LA]);
+            }
+        }
+#endif
+#ifndef PDAE_LAB_NOLSTORE
+        if (s == SST) {
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if ((l * 4) / NL == t) {
+              if (l < LA) *reinterpret_cast<float4*>(Ad + ((tid + l * NT) >> 3) * LD + scol) = sta_[l];
+              else if (BKN) *reinterpret_cast<float4*>(Bd + (tid + (l - LA) * NT) * 4) = stb_[l - LA];
+              else *reinterpret_cast<float4*>(Bd + ((tid + (l - LA) * NT) >> 3) * LD + scol) = stb_[l - LA];
+            }
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (PF == 1) {
+#ifndef PDAE_LAB_NOBARRIER
+      __syncthreads();
+#endif
+    }
+    buf ^= 1;
+  };
+
+  float4 r0a[LA], r0b[LB], r1a[LA], r1b[LB];
+  auto run = [&](auto guard_c) __attribute__((always_inline)) {
+    load_set(r0a, r0b, 0, guard_c);
+    if (PF == 2) load_set(r1a, r1b, 1, guard_c);
+    store_set(r0a, r0b, 0);
+    __syncthreads();
+    if (PF == 2) {
+      const float *As, *Bs;
+      frag_base(0, As, Bs);
+#pragma unroll
+      for (int q = 0; q < NF; ++q) frag(As, Bs, 0, 0, q);
+    }
+    PDAE_STAMP(1)
+    if (PF == 1) {
+      for (int kt = 0; kt < KT; ++kt) ktile(r0a, r0b, r0a, r0b, kt, guard_c);
+    } else {
+      for (int kt = 0; kt < KT; kt += 2) {
+        ktile(r0a, r0b, r1a, r1b, kt, guard_c);
+        if (kt + 1 < KT) ktile(r1a, r1b, r0a, r0b, kt + 1, guard_c);
+      }
+    }
+  };
+  if (KT > 0) {
+    if (guarded) run(std::true_type{});
+    else run(std::false_type{});
+  }
+
+  if (TI * TJ == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
+  PDAE_STAMP(2)
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
+  // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
+  float* Cs = p.C + (size_t)blockIdx.y * p.slab;
+  auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const unsigned ldc = (unsigned)p.ldc;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + (wn * TJ + j) * 32 + r;
+      const bool colok = FULL || col < N;
+      const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int rbase = m0 + (wm * TI + i) * 32 + 4 * h;
+        const size_t off = (size_t)rbase * ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int lr = (e & 3) + 8 * (e >> 2);
+          if (!FULL && !(colok && rbase + lr < M)) continue;
+          float v = acc[i][j][e] + bv;
+          if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+          if (EPI == EPI_BIAS_GELU2) {
+            // one erf for both: GELU(z) = z Phi(z), GELU'(z) = Phi(z) + z phi(z)
+            const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+            p.Z[off + (unsigned)lr * ldc] = cdf + v * pdf;
+            v = v * cdf;
+          }
+          if (EPI == EPI_MUL_GELUGRAD) v *= p.Z[off + (unsigned)lr * ldc];
+          Cs[off + (unsigned)lr * ldc] = v;
+        }
+      }
+    }
+  };
+  if (m0 + BM <= M && n0 + BN <= N)
+    epilogue(std::true_type{});
+  else
+    epilogue(std::false_type{});
+#ifdef PDAE_ROWS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PDAE_STAMP(3)
+  if (p.stamps && threadIdx.x == 0)
+    p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradients.  dW_p[N_p, K_p] = sum over rows m of dY_p[m, n] X_p[m, k] for every
+// layer p of a group in ONE launch; tiles are read "down the columns": lane (r, h) of MFMA step t
+// takes dY[m = 2t + h][n0 + r] (ds_read_b32, consecutive banks).
+//
+// Work = (output tile, 32-row chunk of the reduction) units in tile-major order, dealt in EQUAL
+// contiguous ranges to a fixed grid that fills the chip once (stream-K along the reduction): a
+// block of 108 tiles x 92 chunks (a block's qkv, proj, fc1, fc2 at M = 2944) is 9936 units = 19.4
+// per block of a 512-block grid, instead of 108 x splits tiles that never divide 256 CUs (the
+// uniform-split version ran 2 or 4 blocks on a CU: 117 us where the MFMAs need 66).  A block writes
+// the partial tile of every output tile its range touches into its own slots; wgrad_reduce adds a
+// tile's partials in block order: no atomics, bit-identical run to run.
+constexpr int WG_MAX = 8;
+constexpr int TBK = 16;                 // rows per LDS slab
+constexpr int WCH = 32;                 // rows per work unit
+constexpr int WTM = 128, WTN = 128;     // output tile (n of dY x k of X)
+constexpr int WSLOT = WTM * WTN + WTM;  // floats per partial: the tile + the column sums of its dY band
+struct WgradProb {
+  const float* dY;    // [M, N]
+  const float* X;     // [M, K]
+  float* dW;          // [N, K]
+  float* db;          // [N] or null: column sums of dY
+  int N, K;
+  int tk;             // tiles along K
+  int tile0;          // first tile of this problem in the group
+};
+struct WgradArgs {
+  int M, nprob, tiles, chunks, blocks, slots;   // chunks per tile; grid; slots per block
+  long long units;
+  float* partials;                              // [blocks][slots][WSLOT]
+  WgradProb p[WG_MAX];
+};
+
+__device__ __forceinline__ long long wg_start(const WgradArgs& g, int b) {
+  return ((long long)b * g.units) / g.blocks;
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
+  constexpr int TM = WTM, TN = WTN, WN = TN / 64, NT = 256;
+  constexpr int ROW4 = (TM + TN) / 4;                 // float4 per staged row
+  constexpr int SLOTS = (TBK * ROW4 + NT - 1) / NT;   // float4 per thread per slab
+  static_assert(NT % ROW4 == 0 && (TBK * ROW4) % NT == 0, "slot layout");
+  constexpr int RSTEP = NT / ROW4;
+  __shared__ float lds[2][TBK * (TM + TN)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int srow0 = tid / ROW4, scol = (tid % ROW4) * 4;   // a thread stages the SAME four columns in every slot
+  const bool isb = scol >= TM;
+  long long u = wg_start(g, blockIdx.x);
+  const long long uend = wg_start(g, blockIdx.x + 1);
+  float* slot = g.partials + (size_t)blockIdx.x * g.slots * WSLOT;
+  for (; u < uend; slot += WSLOT) {
+    const int tile = (int)(u / g.chunks), c0 = (int)(u % g.chunks);
+    const int c1 = (int)min((long long)g.chunks, c0 + (uend - u));
+    u += c1 - c0;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < WG_MAX; ++q)
+      if (q < g.nprob && tile >= g.p[q].tile0) pi = q;
+    const WgradProb& P = g.p[pi];
+    const int lt = tile - P.tile0;
+    const int bx = lt % P.tk, by = lt / P.tk;
+    const int n0 = by * TM, k0 = bx * TN;
+    const int N = P.N, K = P.K;
+    const int mbeg = c0 * WCH, mend = min(g.M, c1 * WCH);
+    const int gcol = isb ? k0 + scol - TM : n0 + scol;
+    const bool ok = isb ? gcol < K : gcol < N;
+    const float* src = isb ? P.X + gcol : P.dY + gcol;
+    const int ld = isb ? K : N;
+    float4 rg[SLOTS];
+    float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this thread's dY elements
+    const bool sum_a = P.db != nullptr && bx == 0 && !isb;
+    auto gload = [&](int mt) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int gm = mt + srow0 + i * RSTEP;
+        rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && gm < mend) rg[i] = *reinterpret_cast<const float4*>(src + (size_t)gm * ld);
+      }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const float4 v = rg[i];
+        if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
+        *reinterpret_cast<float4*>(&lds[buf][(srow0 + i * RSTEP) * (TM + TN) + scol]) = v;
+      }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    gload(mbeg);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mt = mbeg; mt < mend; mt += TBK) {
+      const bool more = mt + TBK < mend;
+      if (more) gload(mt + TBK);
+      const float* T = lds[buf] + h * (TM + TN);
+      float fa[2][2][2], fb[2][2][2];   // [stage][step within stage][tile]
+#define PDAE_WG_FREAD(st, t)                                  \
+      {                                                       \
+        const float* row = T + 2 * (t) * (TM + TN);           \
+        fa[st][(t) & 1][0] = row[wm * 64 + r];                \
+        fa[st][(t) & 1][1] = row[wm * 64 + 32 + r];           \
+        fb[st][(t) & 1][0] = row[TM + wn * 64 + r];           \
+        fb[st][(t) & 1][1] = row[TM + wn * 64 + 32 + r];      \
+      }
+      PDAE_WG_FREAD(0, 0)
+      PDAE_WG_FREAD(0, 1)
+#pragma unroll
+      for (int tt = 0; tt < TBK / 4; ++tt) {
+        const int cur = tt & 1, nxt = cur ^ 1;
+        if (tt + 1 < TBK / 4) {
+          PDAE_WG_FREAD(nxt, 2 * tt + 2)
+          PDAE_WG_FREAD(nxt, 2 * tt + 3)
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][0], fb[cur][q][0], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][0], fb[cur][q][1], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][1], fb[cur][q][0], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][1], fb[cur][q][1], acc[1][1], 0, 0, 0);
+        }
+        if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x020, SLOTS, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (tt + 1 < TBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          else if (q < SLOTS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        if (tt == TBK / 4 - 2 && more) lstore(buf ^ 1);
+      }
+#undef PDAE_WG_FREAD
+      __syncthreads();
+      buf ^= 1;
+    }
+    // ---- the partial tile (whole 128 x 128, edges included: the reduction stores what is inside)
+    if (P.db != nullptr && bx == 0) {
+      // the RSTEP threads that staged the same four columns add up in thread order (fixed)
+      float* red = &lds[0][0];                          // [RSTEP][TM]; the slab buffers are free now
+      if (!isb) *reinterpret_cast<float4*>(red + srow0 * TM + scol) = asum;
+      __syncthreads();
+      if (tid < TM) {
+        float sum = red[tid];
+#pragma unroll
+        for (int q = 1; q < RSTEP; ++q) sum += red[q * TM + tid];
+        slot[TM * TN + tid] = sum;
+      }
+      __syncthreads();                                  // red is the next segment's slab buffer
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          slot[row * TN + wn * 64 + j * 32 + r] = acc[i][j][e];
+        }
+  }
+}
+
+// dW tile = sum of its partials in block order (fixed => bit-identical run to run).  One block per
+// (tile, 1/16 of it): one float4 per thread, the partials' loads eight at a time in flight (a tile
+// of a narrow weight can have 64 partials: one thread walking them one by one took 237 us).  The
+// first sixteenth also reduces the bias-gradient column sums.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+  const int tile = blockIdx.x >> 4, part = blockIdx.x & 15;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < WG_MAX; ++q)
+    if (q < g.nprob && tile >= g.p[q].tile0) pi = q;
+  const WgradProb& P = g.p[pi];
+  const int lt = tile - P.tile0;
+  const int bx = lt % P.tk, by = lt / P.tk;
+  const int n0 = by * WTM, k0 = bx * WTN;
+  // blocks whose ranges meet this tile's units [tile * chunks, (tile + 1) * chunks)
+  const long long u0 = (long long)tile * g.chunks, u1 = u0 + g.chunks - 1;
+  const int b0 = (int)(((u0 + 1) * g.blocks - 1) / g.units), b1 = (int)(((u1 + 1) * g.blocks - 1) / g.units);
+  const int tid = threadIdx.x;
+  const int e = part * 1024 + tid * 4;                               // element of the 128 x 128 tile
+  const bool bias = part == 0 && bx == 0 && P.db && tid < WTM;
+  // block b's slot that holds this tile: the (tile - first tile of b's range)-th
+  auto src_of = [&](int b) {
+    return g.partials + ((size_t)b * g.slots + (tile - (int)(wg_start(g, b) / g.chunks))) * WSLOT;
+  };
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bs = 0.f;
+  for (int b = b0; b <= b1; b += 8) {
+    float4 v[8];
+    float w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f), w[q] = 0.f;
+      if (b + q <= b1) {
+        const float* src = src_of(b + q);
+        v[q] = *reinterpret_cast<const float4*>(src + e);
+        if (bias) w[q] = src[WTM * WTN + tid];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s.x += v[q].x, s.y += v[q].y, s.z += v[q].z, s.w += v[q].w, bs += w[q];
+  }
+  const int row = n0 + e / WTN, col = k0 + e % WTN;
+  if (row < P.N && col < P.K) *reinterpret_cast<float4*>(P.dW + (size_t)row * P.K + col) = s;
+  if (bias && n0 + tid < P.N) P.db[n0 + tid] = bs;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct Cfg {
+  int ti, tj, wm, wn;
+};
+constexpr int NCFG = 8;
+static const Cfg kCfg[NCFG] = {
+    {2, 2, 2, 2},   // 0: 128 x 128
+    {1, 2, 2, 2},   // 1:  64 x 128
+    {2, 1, 2, 2},   // 2: 128 x  64
+    {1, 1, 2, 2},   // 3:  64 x  64
+    {1, 3, 2, 2},   // 4:  64 x 192
+    {3, 1, 1, 4},   // 5:  96 x 128
+    {1, 3, 4, 1},   // 6: 128 x  96
+    {2, 3, 2, 2},   // 7: 128 x 192
+};
+
+static size_t lds_bytes(const Cfg& c, bool bkn) {
+  const int bm = 32 * c.ti * c.wm, bn = 32 * c.tj * c.wn;
+  return 2 * sizeof(float) * ((size_t)bm * LD + (bkn ? (size_t)BK * bn : (size_t)bn * LD));
+}
+
+// Cost of a plan in MFMA issue slots (64 cycles) of the busiest SIMD.  Blocks are dealt to the 256
+// CUs round robin and the blocks resident on a CU share its four SIMDs, so the busiest CU decides:
+// ceil(blocks / 256) blocks of TI TJ K/2 MFMAs per SIMD each.  Calibrated on tools/lab_rows.py
+// sweeps (M = 1664 .. 8192, the eight GEMMs of a block): small tiles win -- four or more blocks
+// stay resident per CU and cover each other's load / store issue and epilogues -- unless a larger
+// tile saves a whole round; a block alone on its CU pays its memory-instruction issue in full
+// (+33 % on the 64x64 tile, +12 % on 128x128, in-kernel stamps); every launch pays ~3 us of ramp
+// and drain, every split-K slab a little consumer time.
+static double plan_cost(int M, int N, int K, int cfg, int splits, bool bkn) {
+  const Cfg& c = kCfg[cfg];
+  const int bm = 32 * c.ti * c.wm, bn = 32 * c.tj * c.wn;
+  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const int kc = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+  const long long per_cu = (tiles * splits + 255) / 256;
+  const int g = c.ti * c.tj;
+  const double mfma = (double)g * (kc / 2);                       // per wave = per SIMD and block
+  const double big = g == 1 ? 1.0 : g == 2 ? 1.04 : g == 3 ? 1.07 : g == 4 ? 1.15 : 1.25;
+  const double alone = g == 1 ? 1.33 : g == 2 ? 1.2 : 1.12;      // nobody to cover the issue bubbles
+  double cost = per_cu * mfma * (per_cu == 1 ? alone : big) + 100.;
+  if (splits > 1) cost += 8. * splits;                            // the consumer reads `splits` slabs
+  (void)bkn;
+  return cost;
+}
+
+static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, int* splits) {
+  static const int order[] = {3, 1, 2, 6, 4, 0, 5, 7};           // ties go to the smaller tile
+  double best = 1e300;
+  *cfg = 3, *splits = 1;
+  for (int c : order)
+    for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
+      if (s > 1 && K / s < 128) continue;
+      const double t = plan_cost(M, N, K, c, s, bkn);
+      if (t < best * 0.995) best = t, *cfg = c, *splits = s;
+    }
+}
+
+template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
+static void launch_cfg(Args& a, int splits, hipStream_t s) {
+  constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+  a.kchunk = ((a.K + splits - 1) / splits + BK - 1) / BK * BK;
+  const Cfg c = {TI, TJ, WM, WN};
+  const size_t lds = lds_bytes(c, BKN);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rows_gemm_kernel<TI, TJ, WM, WN, BKN, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  const int chunk = (a.tiles + 7) / 8;
+  hipLaunchKernelGGL((rows_gemm_kernel<TI, TJ, WM, WN, BKN, EPI>), dim3(8 * chunk, splits), dim3(WM * WN * 64),
+                     lds, s, a);
+}
+
+template <bool BKN, int EPI>
+static void launch_rows(Args& a, int cfg, int splits, hipStream_t s) {
+  switch (cfg) {
+    case 0: launch_cfg<2, 2, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 1: launch_cfg<1, 2, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 2: launch_cfg<2, 1, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 3: launch_cfg<1, 1, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 4: launch_cfg<1, 3, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 5: launch_cfg<3, 1, 1, 4, BKN, EPI>(a, splits, s); break;
+    case 6: launch_cfg<1, 3, 4, 1, BKN, EPI>(a, splits, s); break;
+    default: launch_cfg<2, 3, 2, 2, BKN, EPI>(a, splits, s); break;
+  }
+}
+
+}  // namespace rows
+}  // namespace pdae
+
+using namespace pdae;
+using namespace pdae::rows;
+
+#ifdef PDAE_ROWS_STAMPS
+static long long* g_stamps = nullptr;
+extern "C" void pdae_lab_set_stamps(long long* p) { g_stamps = p; }
+#endif
+
+extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits) {
+  if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits) return bad_arg("rows_gemm_plan: bad argument");
+  plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits);
+  return PDAE_OK;
+}
+
+extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn,
+                              const float* bias, int epi, float* Z, float* Y, int cfg, int splits,
+                              pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0) return bad_arg("rows_gemm: bad size");
+  if (K % 4 != 0 || (w_kn && N % 4 != 0)) return unsupported("rows_gemm: K (and N for a [K,N] weight) must be multiples of 4");
+  if (epi < 0 || epi > 3) return bad_arg("rows_gemm: epi must be 0..3");
+  if ((long long)M * (K > N ? K : N) >= (1LL << 30) || (long long)N * K >= (1LL << 30))
+    return unsupported("rows_gemm: operands of 4 GB or more (32-bit byte offsets)");
+  if (cfg >= NCFG || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
+  if (cfg < 0 || splits < 0) {
+    int c, s;
+    plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s);
+    if (cfg < 0) cfg = c;
+    if (splits < 0) splits = 1;
+  }
+  if (splits > 1 && (epi != EPI_STORE || bias)) return bad_arg("rows_gemm: split-K slabs take the plain store epilogue without bias");
+  if (M == 0) return PDAE_OK;
+  if (!X || !W || !Y) return bad_arg("rows_gemm: null pointer");
+  if ((epi == EPI_BIAS_GELU2 || epi == EPI_MUL_GELUGRAD) && !Z) return bad_arg("rows_gemm: this epilogue needs Z");
+  if (epi == EPI_BIAS_GELU2 && w_kn) return unsupported("rows_gemm: bias+GELU epilogue on a [K,N] weight");
+  if (epi == EPI_BIAS_RELU && w_kn) return unsupported("rows_gemm: bias+ReLU epilogue on a [K,N] weight");
+  if (epi == EPI_MUL_GELUGRAD && !w_kn) return unsupported("rows_gemm: GELU' epilogue on an [N,K] weight");
+  Args a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = w_kn ? N : K, a.C = Y, a.ldc = N;
+  a.Z = Z, a.bias = bias, a.slab = (long long)M * N;
+#ifdef PDAE_ROWS_STAMPS
+  a.stamps = g_stamps;
+#endif
+  hipStream_t s = as_stream(stream);
+  if (!w_kn) {
+    if (epi == EPI_STORE) launch_rows<false, EPI_STORE>(a, cfg, splits, s);
+    else if (epi == EPI_BIAS_RELU) launch_rows<false, EPI_BIAS_RELU>(a, cfg, splits, s);
+    else launch_rows<false, EPI_BIAS_GELU2>(a, cfg, splits, s);
+  } else {
+    if (epi == EPI_STORE) launch_rows<true, EPI_STORE>(a, cfg, splits, s);
+    else launch_rows<true, EPI_MUL_GELUGRAD>(a, cfg, splits, s);
+  }
+  return check_launch("rows_gemm");
+}
+
+static int wgrad_layout(int M, int nprob, const int* Ns, const int* Ks, WgradArgs* g) {
+  int tiles = 0;
+  for (int q = 0; q < nprob; ++q) {
+    if (Ns[q] <= 0 || Ks[q] <= 0 || Ns[q] % 4 != 0 || Ks[q] % 4 != 0)
+      return unsupported("rows_wgrad: N, K positive multiples of 4");
+    g->p[q].N = Ns[q], g->p[q].K = Ks[q];
+    g->p[q].tk = (Ks[q] + WTN - 1) / WTN;
+    g->p[q].tile0 = tiles;
+    tiles += ((Ns[q] + WTM - 1) / WTM) * g->p[q].tk;
+  }
+  g->M = M, g->nprob = nprob, g->tiles = tiles;
+  g->chunks = M > 0 ? (M + WCH - 1) / WCH : 1;
+  g->units = (long long)tiles * g->chunks;
+  // one residency of the chip: 256 CUs x 2 blocks (32 KB of LDS, 122 registers each)
+  g->blocks = (int)(g->units < 512 ? g->units : 512);
+  const long long len = (g->units + g->blocks - 1) / g->blocks;       // longest range
+  g->slots = (int)((len + g->chunks - 2) / g->chunks) + 1;            // tiles a range of `len` units can touch
+  return PDAE_OK;
+}
+
+extern "C" int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks, long long* floats) {
+  if (M < 0 || nprob <= 0 || nprob > WG_MAX || !Ns || !Ks || !floats)
+    return bad_arg("rows_wgrad_workspace: bad argument");
+  WgradArgs g = {};
+  int rc = wgrad_layout(M, nprob, Ns, Ks, &g);
+  if (rc) return rc;
+  *floats = (long long)g.blocks * g.slots * WSLOT;
+  return PDAE_OK;
+}
+
+extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const float* const* X,
+                               float* const* dW, float* const* db, const int* Ns, const int* Ks,
+                               float* workspace, pdae_stream_t stream) {
+  if (M < 0 || nprob <= 0 || nprob > WG_MAX || !dY || !X || !dW || !Ns || !Ks)
+    return bad_arg("rows_wgrad: bad argument");
+  WgradArgs g = {};
+  int rc = wgrad_layout(M, nprob, Ns, Ks, &g);
+  if (rc) return rc;
+  for (int q = 0; q < nprob; ++q) {
+    if (!dW[q] || (M > 0 && (!dY[q] || !X[q]))) return bad_arg("rows_wgrad: null pointer");
+    g.p[q].dY = dY[q], g.p[q].X = X[q], g.p[q].dW = dW[q], g.p[q].db = db ? db[q] : nullptr;
+  }
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    for (int q = 0; q < nprob; ++q) {
+      (void)hipMemsetAsync(g.p[q].dW, 0, sizeof(float) * (size_t)g.p[q].N * g.p[q].K, s);
+      if (g.p[q].db) (void)hipMemsetAsync(g.p[q].db, 0, sizeof(float) * (size_t)g.p[q].N, s);
+    }
+    return check_launch("rows_wgrad");
+  }
+  if (!workspace) return bad_arg("rows_wgrad: null workspace");
+  g.partials = workspace;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g.tiles * 16), dim3(256), 0, s, g);
+  return check_launch("rows_wgrad");
+}

@@ -1,12 +1,15 @@
 """Dense layers of the pretraining step on flat (rows, channels) activations.
 
 The model code (point_cae_transformer.py, point_cae_pointnetv2.py) only calls
-the functions below.  Plain GEMMs (nn.Linear without a fusable neighbour) go to
-the BLAS library (hipBLASLt through torch.mm / addmm); everything around them --
-the fused patch embedder (patch_embed.py), the attention core, LayerNorm with
-the position / residual adds, GELU, bias + DropPath + residual -- runs on the
-hand-written gfx950 kernels of csrc/{gemm,embed,attention,block}.hip through
-autograd Functions whose backward calls the matching backward kernels.
+the functions below.  Every dense layer runs on the hand-written gfx950 kernels:
+the Linear layers of the Transformer blocks, pos_embed and the heads on the row
+GEMM family of csrc/rows_gemm.hip (fp32 MFMA, fused bias / GELU / GELU'
+epilogues, split-K slabs, grouped weight gradients -- no BLAS library in the
+step), the patch embedder on csrc/{gemm,embed}.hip (patch_embed.py), and the
+attention core, LayerNorm with the position / residual adds, DropPath on
+csrc/{attention,block}.hip.  A whole pre-LN block is ONE autograd Function
+(_TransformerBlock) whose backward issues the data-gradient chain and then the
+block's four weight gradients as one grouped launch.
 Parameters are read from the reference-layout nn.Modules that own them.
 """
 import torch
@@ -34,17 +37,9 @@ class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, gamma, beta, eps):
         x = x.contiguous()
-        M, C = x.shape
-        y = torch.empty_like(x)
-        mean, rstd = _empty((M,), x), _empty((M,), x)
         if pos is not None:
             pos = pos.contiguous()
-            s = torch.empty_like(x)
-        else:
-            s = x
-        _lib.call('pdae_add_layernorm_forward', x, M, C, _lib.ptr(x), _lib.ptr(pos), _lib.ptr(gamma),
-                  _lib.ptr(beta), float(eps), _lib.ptr(s) if pos is not None else None, _lib.ptr(y),
-                  _lib.ptr(mean), _lib.ptr(rstd))
+        s, y, mean, rstd = _add_ln_forward(x, pos, gamma, beta, eps)
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.has_pos = pos is not None
         ctx.mark_non_differentiable(mean, rstd)
@@ -57,13 +52,69 @@ class _AddLayerNorm(torch.autograd.Function):
         M, C = s.shape
         if dy is None:                        # only the pass-through sum was used
             return ds, (ds if ctx.has_pos else None), None, None, None
-        dx = torch.empty_like(s)
-        gb, _ = arena.take(2 * C, s)
-        dg, db = gb[:C], gb[C:]
-        dres = ds.contiguous() if ds is not None else None
-        _lib.call('pdae_layernorm_backward', s, M, C, _lib.ptr(dy.contiguous()), _lib.ptr(s), _lib.ptr(mean),
-                  _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), 1)
+        dx, dg, db = _ln_backward(dy.contiguous(), s, mean, rstd, gamma, ds.contiguous() if ds is not None else None)
         return dx, (dx if ctx.has_pos else None), dg, db, None
+
+
+def _slabs(t):
+    """Slab count of a GEMM output: (S, M, C) = S split-K slabs of partial products, (M, C) = 1."""
+    return t.shape[0] if t.dim() == 3 else 1
+
+
+def _to_slabs(g, slabs):
+    """Gradient w.r.t. S slabs that are summed = the same gradient for each (a view, no copy)."""
+    return g if slabs == 1 else g.unsqueeze(0).expand(slabs, *g.shape)
+
+
+def _from_slabs(g):
+    """The (M, C) gradient out of what _to_slabs made (autograd may have materialised it)."""
+    return g if g.dim() == 2 else g[0]
+
+
+def _add_ln_forward(x, pos, gamma, beta, eps):
+    M, C = x.shape
+    y = torch.empty_like(x)
+    mean, rstd = _empty((M,), x), _empty((M,), x)
+    s = torch.empty_like(x) if pos is not None else x
+    _lib.call('pdae_add_layernorm_forward', x, M, C, _lib.ptr(x), _lib.ptr(pos), _lib.ptr(gamma),
+              _lib.ptr(beta), float(eps), _lib.ptr(s) if pos is not None else None, _lib.ptr(y),
+              _lib.ptr(mean), _lib.ptr(rstd))
+    return s, y, mean, rstd
+
+
+def _ln_backward(dy, s, mean, rstd, gamma, dres):
+    """dy may be split-K slabs (S, M, C).  -> dx, dgamma, dbeta"""
+    M, C = s.shape
+    dx = torch.empty_like(s)
+    gb, _ = arena.take(2 * C, s)
+    dg, db = gb[:C], gb[C:]
+    _lib.call('pdae_layernorm_backward', s, M, C, _lib.ptr(dy), _slabs(dy), _lib.ptr(s), _lib.ptr(mean),
+              _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), 1)
+    return dx, dg, db
+
+
+def _res_ln_forward(a, bias, keep, res, pos, gamma, beta, eps, T):
+    M, C = res.shape
+    s, y = torch.empty_like(res), torch.empty_like(res)
+    mean, rstd = _empty((M,), res), _empty((M,), res)
+    _lib.call('pdae_residual_layernorm_forward', res, M, C, T, _lib.ptr(a), _slabs(a), _lib.ptr(bias),
+              _lib.ptr(keep), _lib.ptr(res), _lib.ptr(pos), _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+              _lib.ptr(s), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd))
+    return s, y, mean, rstd
+
+
+def _res_ln_backward(dy, s, mean, rstd, gamma, dres, keep, T):
+    """dy may be split-K slabs (S, M, C).  -> dx (w.r.t. the stream), da (w.r.t. the branch),
+    dgamma, dbeta, dbias (column sums of da)"""
+    M, C = s.shape
+    dx = torch.empty_like(s)
+    buf, _ = arena.take(3 * C, s)
+    dg, db, dbias = buf[:C], buf[C:2 * C], buf[2 * C:]
+    da = torch.empty_like(s) if keep is not None else dx
+    _lib.call('pdae_residual_layernorm_backward', s, M, C, T, _lib.ptr(dy), _slabs(dy), _lib.ptr(s),
+              _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(keep), _lib.ptr(dx),
+              _lib.ptr(da) if keep is not None else None, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), 1)
+    return dx, da, dg, db, dbias
 
 
 class _ResidualLayerNorm(torch.autograd.Function):
@@ -73,17 +124,12 @@ class _ResidualLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, bias, keep, res, pos, gamma, beta, eps, T):
+        """`a` may be (S, M, C): split-K slabs of the branch, added up by the kernel."""
         a, res = a.contiguous(), res.contiguous()
-        M, C = a.shape
-        s, y = torch.empty_like(a), torch.empty_like(a)
-        mean, rstd = _empty((M,), a), _empty((M,), a)
-        if pos is not None:
-            pos = pos.contiguous()
-        _lib.call('pdae_residual_layernorm_forward', a, M, C, T, _lib.ptr(a), _lib.ptr(bias), _lib.ptr(keep),
-                  _lib.ptr(res), _lib.ptr(pos), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(s),
-                  _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd))
+        M, C = res.shape
+        s, y, mean, rstd = _res_ln_forward(a, bias, keep, res, pos, gamma, beta, eps, T)
         ctx.save_for_backward(s, mean, rstd, gamma, keep)
-        ctx.T, ctx.has_pos, ctx.has_bias = T, pos is not None, bias is not None
+        ctx.T, ctx.has_pos, ctx.has_bias, ctx.slabs = T, pos is not None, bias is not None, _slabs(a)
         ctx.mark_non_differentiable(mean, rstd)
         ctx.set_materialize_grads(False)
         return s, y
@@ -101,16 +147,10 @@ class _ResidualLayerNorm(torch.autograd.Function):
                           _lib.ptr(dbias), 1)
             else:
                 da, dbias = ds, (_colsum(ds) if ctx.has_bias else None)
-            return da, dbias, None, ds, (ds if ctx.has_pos else None), None, None, None, None
-        dx = torch.empty_like(s)
-        buf, _ = arena.take(3 * C, s)
-        dg, db, dbias = buf[:C], buf[C:2 * C], buf[2 * C:]
-        da = torch.empty_like(s) if keep is not None else dx
-        dres = ds.contiguous() if ds is not None else None
-        _lib.call('pdae_residual_layernorm_backward', s, M, C, ctx.T, _lib.ptr(dy.contiguous()), _lib.ptr(s),
-                  _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(keep), _lib.ptr(dx),
-                  _lib.ptr(da) if keep is not None else None, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), 1)
-        return da, (dbias if ctx.has_bias else None), None, dx, (dx if ctx.has_pos else None), dg, db, None, None
+            return _to_slabs(da, ctx.slabs), dbias, None, ds, (ds if ctx.has_pos else None), None, None, None, None
+        dx, da, dg, db, dbias = _res_ln_backward(dy.contiguous(), s, mean, rstd, gamma, ds, keep, ctx.T)
+        return (_to_slabs(da, ctx.slabs), (dbias if ctx.has_bias else None), None, dx, (dx if ctx.has_pos else None),
+                dg, db, None, None)
 
 
 class Pending:
@@ -122,7 +162,8 @@ class Pending:
         self.a, self.bias, self.keep, self.res, self.T = a, bias, keep, res, T
 
     def resolve(self):
-        return _ScaleResidual.apply(self.a, self.bias, self.keep, self.res, self.T)
+        a = self.a.sum(0) if self.a.dim() == 3 else self.a      # split-K slabs of the branch
+        return _ScaleResidual.apply(a, self.bias, self.keep, self.res, self.T)
 
 
 def residual_layer_norm(x, pos, ln):
@@ -266,43 +307,71 @@ def draw_drop_path(B, drop_probs, training, keep):
     return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(drop_probs)]
 
 
+def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
+    """y = epi(x . op(w)) on the row-GEMM family (csrc/rows_gemm.hip, include/pdae.h).
+    w_kn False: w is (N, K), torch's (out, in): a Linear's forward; True: w is (K, N): the same
+    weight as the data-gradient operand.  epi 0 store (+bias) | 1 bias+ReLU | 2 GELU(z) -> y and
+    GELU'(z) -> z | 3 y = acc * z.  may_split: the result may be (S, M, N) split-K slabs whose
+    consumer adds them up (the LayerNorm kernels do)."""
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    cfg, splits = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
+    y = _empty((splits, M, N) if splits > 1 else (M, N), x)
+    _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), epi, _lib.ptr(z),
+              _lib.ptr(y), cfg, splits)
+    return y
+
+
+def rows_wgrad(dys, xs, with_bias):
+    """Weight (and bias) gradients of a group of Linear layers that share their rows, one grouped
+    launch (+ the ordered slab reduction).  -> ([dW], [db or None])"""
+    M = dys[0].shape[0]
+    Ns, Ks = [t.shape[1] for t in dys], [t.shape[1] for t in xs]
+    ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dys[0])
+    dws = [_empty((n, k), dys[0]) for n, k in zip(Ns, Ks)]
+    dbs = [_empty((n,), dys[0]) if f else None for n, f in zip(Ns, with_bias)]
+    _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws)
+    return dws, dbs
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b on rows: the three GEMMs go to the BLAS library, the bias
-    gradient to the column-sum kernel (autograd's own `grad.sum(0)` is a
-    single-wave-per-column reduction: 20-55 us on the (B*G, C) activations here)."""
+    """y = act(x W^T + b) on rows; act None or 'relu' (the ReLU mask is recomputed from y)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+    def forward(ctx, x, w, b, relu):
+        x = x.contiguous()
+        y = rows_gemm(x, w, False, b, 1 if relu else 0)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias, ctx.relu = b is not None, relu
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(dy.t(), x) if ctx.needs_input_grad[1] else None
-        db = _colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = rows_gemm(dy, w, True) if ctx.needs_input_grad[0] else None
+        dws, dbs = rows_wgrad([dy], [x], [ctx.has_bias])
+        return dx, dws[0], dbs[0], None
 
 
-def _linear_rows(x, w, b):
-    if x.dim() != 2 or not x.is_cuda or b is None or b.numel() % 4 != 0:
-        return F.linear(x, w, b)
-    return _Linear.apply(x, w, b)
+def _rows_ok(x, w):
+    return x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0
+
+
+def _linear_rows(x, w, b, relu=False):
+    if not _rows_ok(x, w):
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+    return _Linear.apply(x, w, b, relu)
 
 
 def linear(x, lin, act=None):
-    """Plain nn.Linear on rows -> BLAS library GEMM (bias in its epilogue, or fused
-    with the GELU that follows)."""
-    if act == 'gelu' and x.dim() == 2 and x.is_cuda and lin.bias is not None and lin.bias.numel() % 4 == 0:
-        return bias_gelu(torch.mm(x, lin.weight.t()), lin.bias)
-    y = _linear_rows(x, lin.weight, lin.bias)
+    """nn.Linear on rows (bias, and a following ReLU, in the GEMM epilogue)."""
+    y = _linear_rows(x, lin.weight, lin.bias, act == 'relu')
     if act == 'gelu':
         y = gelu(y)
-    elif act == 'relu':
-        y = F.relu(y)
     return y
 
 
@@ -311,24 +380,124 @@ def conv1x1(x_rows, conv):
     return _linear_rows(x_rows, conv.weight.squeeze(-1), conv.bias)
 
 
+class _PosEmbed(torch.autograd.Function):
+    """Linear(3,128) -> GELU -> Linear(128,C) on centre rows (PointCAE_transformer.py:329-333).
+    The 3 input columns are padded to 4 (the GEMMs reduce in multiples of 4); GELU and the factor
+    its backward needs come out of the first GEMM's epilogue.  Centres carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, xyz, w1, b1, w2, b2):
+        M = xyz.shape[0]
+        xp = torch.zeros((M, 4), device=xyz.device, dtype=xyz.dtype)
+        xp[:, :3] = xyz
+        w1p = torch.zeros((w1.shape[0], 4), device=xyz.device, dtype=xyz.dtype)
+        w1p[:, :3] = w1
+        gp = _empty((M, w1.shape[0]), xyz)
+        h = rows_gemm(xp, w1p, False, b1, 2, gp)
+        y = rows_gemm(h, w2, False, b2, 0)
+        ctx.save_for_backward(xp, gp, h, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, gp, h, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dz = rows_gemm(dy, w2, True, None, 3, gp)
+        (dw2, dw1p), (db2, db1) = rows_wgrad([dy, dz], [h, xp], [True, True])
+        return None, dw1p[:, :3], db1, dw2, db2
+
+
 def pos_embed(xyz_rows, seq):
     """Linear(3,128) -> GELU -> Linear(128,C) (PointCAE_transformer.py:329-333)."""
-    return linear(linear(xyz_rows, seq[0], 'gelu'), seq[2])
+    if not xyz_rows.is_cuda:
+        return seq[2](F.gelu(seq[0](xyz_rows)))
+    return _PosEmbed.apply(xyz_rows.contiguous(), seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
+
+
+class _TransformerBlock(torch.autograd.Function):
+    """One pre-LN block on rows (Block.forward, PointCAE_transformer.py:155-158 with :174-177):
+
+        stream = res + keep_in * (a_in + bias_in)   (the previous block's MLP branch; or stream = res)
+        x1 = stream + pos;   x2 = x1 + keep1 * (proj(attn(qkv(LN1 x1))) + b_proj)
+        -> (a2, x2) with the block's output = x2 + keep2 * (a2 + b_fc2), added by the NEXT norm.
+
+    Forward: 4 GEMMs (fc1's epilogue yields GELU and GELU'), 2 LayerNorm launches that fold the
+    bias / DropPath / residual adds, the attention core.  Backward: the data-gradient chain
+    (dz straight out of the fc2-transposed GEMM's epilogue), then the four weight gradients +
+    fc1's bias gradient as ONE grouped launch.  GEMMs with a long reduction and a narrow output
+    (fc2, and the fc1 / qkv data gradients) may come back as split-K slabs; the LayerNorm kernel
+    that consumes them adds the slabs."""
+
+    @staticmethod
+    def forward(ctx, a_in, bias_in, keep_in, res, pos, keep1, keep2, g1, b1, wqkv, wproj, bproj, g2, b2, w1,
+                bf1, w2, B, T, H, scale, eps1, eps2):
+        res = res.contiguous()
+        M, C = res.shape
+        if a_in is not None:
+            x1, n1, mean1, rstd1 = _res_ln_forward(a_in.contiguous(), bias_in, keep_in, res, pos, g1, b1, eps1, T)
+        else:
+            x1, n1, mean1, rstd1 = _add_ln_forward(res, pos, g1, b1, eps1)
+        qkv = rows_gemm(n1, wqkv)
+        D = wqkv.shape[0] // (3 * H)
+        o = _empty((M, H * D), res)
+        lse = _empty((B, H, T), res)
+        _lib.call('pdae_attention_forward', qkv, B, T, H, D, float(scale), _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse))
+        a1 = rows_gemm(o, wproj, may_split=True)
+        x2, n2, mean2, rstd2 = _res_ln_forward(a1, bproj, keep1, x1, None, g2, b2, eps2, T)
+        gp = _empty((M, w1.shape[0]), res)
+        h = rows_gemm(n2, w1, False, bf1, 2, gp)
+        a2 = rows_gemm(h, w2, may_split=True)
+        ctx.save_for_backward(x1, n1, mean1, rstd1, qkv, o, lse, x2, n2, mean2, rstd2, gp, h, keep_in, keep1,
+                              g1, wqkv, wproj, g2, w1, w2)
+        ctx.dims = (B, T, H, D, float(scale))
+        ctx.has_in, ctx.has_pos, ctx.has_bias_in, ctx.in_slabs = a_in is not None, pos is not None, bias_in is not None, \
+            (_slabs(a_in) if a_in is not None else 1)
+        ctx.a2_slabs = _slabs(a2)
+        ctx.set_materialize_grads(False)
+        return a2, x2
+
+    @staticmethod
+    def backward(ctx, da2, dx2):
+        (x1, n1, mean1, rstd1, qkv, o, lse, x2, n2, mean2, rstd2, gp, h, keep_in, keep1,
+         g1, wqkv, wproj, g2, w1, w2) = ctx.saved_tensors
+        B, T, H, D, scale = ctx.dims
+        da2 = _from_slabs(da2).contiguous()
+        dz = rows_gemm(da2, w2, True, None, 3, gp)                        # (M, 4C): GELU' in the epilogue
+        dn2 = rows_gemm(dz, w1, True, may_split=True)
+        dx1, da1, dg2, db2, dbproj = _res_ln_backward(dn2, x2, mean2, rstd2, g2,
+                                                      dx2.contiguous() if dx2 is not None else None, keep1, T)
+        do = rows_gemm(da1, wproj, True)
+        dqkv = torch.empty_like(qkv)
+        _lib.call('pdae_attention_backward', qkv, B, T, H, D, scale, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse),
+                  _lib.ptr(do), _lib.ptr(dqkv))
+        dn1 = rows_gemm(dqkv, wqkv, True, may_split=True)
+        if ctx.has_in:
+            dx0, da0, dg1, db1, dbias_in = _res_ln_backward(dn1, x1, mean1, rstd1, g1, dx1, keep_in, T)
+            da0 = _to_slabs(da0, ctx.in_slabs)
+        else:
+            dx0, dg1, db1 = _ln_backward(dn1, x1, mean1, rstd1, g1, dx1)
+            da0 = dbias_in = None
+        (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
+                                                                [False, False, True, False])
+        return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dx0 if ctx.has_pos else None, None, None,
+                dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None)
 
 
 def transformer_block(x, pos, B, T, blk, keeps, pending=False):
     """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
-    (PointCAE_transformer.py:155-158, :174-177) in 9 launches.  `keeps` =
+    (PointCAE_transformer.py:155-158, :174-177) as one autograd Function.  `keeps` =
     (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path.
     x may be a Pending (the previous block's MLP branch, added here by norm1's
     kernel); with pending=True the result is one too (for the next norm)."""
-    attn = blk.attn
-    x1, n1 = residual_layer_norm(x, pos, blk.norm1)
-    qkv = F.linear(n1, attn.qkv.weight, attn.qkv.bias)
-    o = attention_core(qkv, B, T, attn.num_heads, attn.scale)
+    attn, mlp = blk.attn, blk.mlp
     keep1, keep2 = keeps
-    x2, n2 = residual_layer_norm(Pending(torch.mm(o, attn.proj.weight.t()), attn.proj.bias, keep1, x1, T), None,
-                                 blk.norm2)
-    h = bias_gelu(torch.mm(n2, blk.mlp.fc1.weight.t()), blk.mlp.fc1.bias)
-    out = Pending(torch.mm(h, blk.mlp.fc2.weight.t()), blk.mlp.fc2.bias, keep2, x2, T)
+    if isinstance(x, Pending):
+        a_in, bias_in, keep_in, res = x.a, x.bias, x.keep, x.res
+    else:
+        a_in, bias_in, keep_in, res = None, None, None, x
+    a2, x2 = _TransformerBlock.apply(a_in, bias_in, keep_in, res, pos, keep1, keep2, blk.norm1.weight, blk.norm1.bias,
+                                     attn.qkv.weight, attn.proj.weight, attn.proj.bias, blk.norm2.weight,
+                                     blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, B, T,
+                                     attn.num_heads, attn.scale, blk.norm1.eps, blk.norm2.eps)
+    out = Pending(a2, mlp.fc2.bias, keep2, x2, T)
     return out if pending else out.resolve()

@@ -20,7 +20,8 @@ cuDNN convs and separate BatchNorm / ReLU / max / concat / add passes:
   backward  max-pool / ReLU / BatchNorm backward are three fused sweeps
             (group_max_scatter, bnrelu_backward, group_scatter_add); weight
             gradients recompute the BN+ReLU activations in the GEMM producer;
-            plain data-gradient GEMMs go to the BLAS library.
+            data-gradient GEMMs read the (out, in) weights as [K][N] operands on the row
+            GEMM family (csrc/rows_gemm.hip): no transposed copies, no BLAS library.
 
 Training-mode BatchNorm semantics are PyTorch's: biased batch variance for the
 normalisation, unbiased for the running estimate, momentum 0.1.
@@ -42,6 +43,27 @@ def _colsum(t):
     out = arena.take(t.shape[1], t)[0]
     _lib.call('pdae_colsum', t, t.shape[0], t.shape[1], _lib.ptr(t), _lib.ptr(out), 1)
     return out
+
+
+def _gemm(x, w, w_kn=False, bias=None):
+    """x . w^T (+ bias) with w (N, K), or x . w with w (K, N) when w_kn (csrc/rows_gemm.hip)."""
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    cfg, splits = _lib.rows_gemm_plan(M, N, K, w_kn, False)
+    y = _empty((M, N), x)
+    _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), 0, None,
+              _lib.ptr(y), cfg, 1)
+    return y
+
+
+def _wgrad(dy, x):
+    """dy^T . x on the grouped weight-gradient kernel (one problem)."""
+    M = dy.shape[0]
+    Ns, Ks = [dy.shape[1]], [x.shape[1]]
+    ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dy)
+    dw = _empty((Ns[0], Ks[0]), dy)
+    _lib.rows_wgrad(dy, M, [dy], [x], [dw], [None], ws)
+    return dw
 
 
 def _bn_finalize(bn, rows, like, stats64=None, partials=None):
@@ -109,7 +131,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         # conv3 on concat([g, f]): global half once per group, local half as the GEMM
         wg = w3m[:, :c2].contiguous()
         wl = w3m[:, c2:].contiguous()
-        gb = F.linear(g, wg, b3)
+        gb = _gemm(g, wg, False, b3)
         h3 = _empty((R, c3), x)
         stats = _empty((8, 2, c3), x)
         # the largest hand-written kernel of the step: bench.py's roofline kernel
@@ -159,7 +181,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         dw4 = _empty((c4, c3), x)
         _lib.call('pdae_bnrelu_linear_backward_weight', x, Rv, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
                   _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), None, _lib.ptr(groups))
-        d3c = torch.mm(dy4, w4m)                                  # (Rv, 512) grad of relu(bn2(h3)) rows
+        d3c = _gemm(dy4, w4m, True)                               # (Rv, 512) grad of relu(bn2(h3)) rows
         del dy4
         # ---- ReLU + BN2 backward + per-group sums for the global half
         S2 = _empty((2, c3), x)
@@ -173,26 +195,28 @@ class PatchEmbedFunction(torch.autograd.Function):
         # ---- conv3 (split weight)
         dwl = _empty((c3, c2), x)
         _lib.call('pdae_linear_backward_weight', x, R, c3, c2, _lib.ptr(d3), _lib.ptr(f), _lib.ptr(dwl), None)
-        dwg = torch.mm(dgb.t(), g)
+        dwg = _wgrad(dgb, g)
         db3 = _colsum(dgb)
         dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
-        df = torch.mm(d3, wl)                                     # (R, 256)
+        df = _gemm(d3, wl, True)                                  # (R, 256)
         del d3
-        dg = torch.mm(dgb, wg)                                    # (BG, 256) -> arg-max rows of f
+        dg = _gemm(dgb, wg, True)                                 # (BG, 256) -> arg-max rows of f
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
         dw2 = _empty((c2, c1), x)
         db2 = _empty((c2,), x)                                    # column sums of df, from the same kernel
         _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c2, c1, _lib.ptr(df), _lib.ptr(y1),
                   _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2), _lib.ptr(db2), None)
-        d1 = torch.mm(df, w2m)                                    # (R, 128)
+        d1 = _gemm(df, w2m, True)                                 # (R, 128)
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)
         S1 = _empty((2, c1), x)
         _lib.call('pdae_bnrelu_backward', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
                   _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None, BG, None, None, None)
         dbe1, dg1 = S1[0], S1[1]
-        dw1 = torch.mm(d1.t(), x).unsqueeze(-1)
+        xp = torch.zeros((R, 4), device=x.device, dtype=x.dtype)      # K = 3 padded to the GEMMs' multiple of 4
+        xp[:, :3] = x
+        dw1 = _wgrad(d1, xp)[:, :3].unsqueeze(-1)
         db1 = _colsum(d1)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
                 dw4.unsqueeze(-1), db4, None, None, None, None)

@@ -1,0 +1,154 @@
+"""GPU numerics of the Transformer-block GEMM family (csrc/rows_gemm.hip): every tile shape, both
+weight layouts, the fused epilogues, split-K slabs and the grouped weight-gradient launch, against
+fp64 PyTorch compositions of the same ops (tolerance: fp32 GEMM reassociation, 2e-5 of the output
+scale) -- and bit-identical results run to run (no atomics anywhere)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from point_dae_amd import _lib
+    return _lib
+
+
+def _close(a, b, tol=2e-5):
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b.to(a.dtype)).abs().max().item() / scale
+    assert err <= tol, err
+
+
+def _gemm(L, x, w, w_kn, bias, epi, z, cfg, splits):
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    y = torch.full((max(splits, 1), M, N), float('nan'), device='cuda')
+    L.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), int(w_kn), L.ptr(bias), epi, L.ptr(z),
+           y.data_ptr(), cfg, splits)
+    return y
+
+
+SHAPES = [(2944, 1152, 384), (1664, 384, 384), (4096, 1536, 384), (2944, 384, 1536), (8192, 384, 1152),
+          (1000, 96, 384), (37, 128, 132), (300, 1536, 388), (5248, 96, 384), (8192, 384, 128)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+@pytest.mark.parametrize('cfg', list(range(8)) + [-1])
+def test_rows_gemm_store(M, N, K, cfg):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5          # (out, in)
+    b = torch.randn(N, device='cuda', generator=g)
+    ref = F.linear(x.double(), w.double())
+    _close(_gemm(L, x, w, 0, None, 0, None, cfg, 1)[0], ref)
+    _close(_gemm(L, x, w, 0, b, 0, None, cfg, 1)[0], ref + b.double())
+    _close(_gemm(L, x, w, 0, b, 1, None, cfg, 1)[0], F.relu(ref + b.double()))
+    # the same weight as the data-gradient operand: dX[M,K] = dY[M,N] . W[N,K]
+    dy = torch.randn(M, N, device='cuda', generator=g)
+    if N % 4 == 0:
+        _close(_gemm(L, dy, w, 1, None, 0, None, cfg, 1)[0], dy.double() @ w.double())
+
+
+@pytest.mark.parametrize('M,N,K', [(2944, 1536, 384), (8192, 1536, 384), (333, 1536, 384), (2944, 128, 4)])
+@pytest.mark.parametrize('cfg', [0, 1, 4, 5, 7, -1])
+def test_rows_gemm_gelu_pair(M, N, K, cfg):
+    """fc1 + GELU forward (Z and H in one pass) and its backward twin dz = (dh . W2) * GELU'(Z)."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w1 = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    b1 = torch.randn(N, device='cuda', generator=g)
+    gp = torch.full((M, N), float('nan'), device='cuda')     # GELU'(z): the factor the backward needs
+    h = _gemm(L, x, w1, 0, b1, 2, gp, cfg, 1)[0]
+    zr = F.linear(x.double(), w1.double(), b1.double()).requires_grad_(True)
+    hr = F.gelu(zr)
+    _close(h, hr.detach())
+    hr.sum().backward()
+    _close(gp, zr.grad, 1e-5)
+    # backward: da (M, C) -> dh = da . W2 (W2 is (C, N)), dz = dh * gelu'(z)
+    C = 384
+    da = torch.randn(M, C, device='cuda', generator=g)
+    w2 = torch.randn(C, N, device='cuda', generator=g) / N ** 0.5
+    dz = _gemm(L, da, w2, 1, None, 3, gp, cfg, 1)[0]
+    zz = zr.detach().clone().requires_grad_(True)
+    F.gelu(zz).backward(da.double() @ w2.double())
+    _close(dz, zz.grad)
+
+
+@pytest.mark.parametrize('M,N,K', [(2944, 384, 1536), (1664, 384, 1152), (8192, 384, 1536), (100, 96, 384)])
+@pytest.mark.parametrize('w_kn', [0, 1])
+@pytest.mark.parametrize('splits', [2, 3, 4])
+def test_rows_gemm_split_slabs(M, N, K, w_kn, splits):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(K, N, device='cuda', generator=g) / K ** 0.5 if w_kn else \
+        torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    ref = x.double() @ (w.double() if w_kn else w.double().t())
+    for cfg in (0, 1, 6, -1):
+        y = _gemm(L, x, w, w_kn, None, 0, None, cfg, splits)
+        assert torch.isfinite(y).all()
+        _close(y.sum(0), ref)
+        y2 = _gemm(L, x, w, w_kn, None, 0, None, cfg, splits)
+        assert torch.equal(y, y2)                                  # deterministic
+
+
+def test_rows_gemm_plan_and_errors():
+    L = _lib()
+    for M, N, K in SHAPES:
+        for w_kn in (0, 1):
+            cfg, s = L.rows_gemm_plan(M, N, K, w_kn, True)
+            assert 0 <= cfg < 8 and 1 <= s <= 4
+            assert L.rows_gemm_plan(M, N, K, w_kn, False)[1] == 1
+    x = torch.zeros(8, 6, device='cuda')
+    with pytest.raises(RuntimeError):                              # K % 4 != 0
+        L.call('pdae_rows_gemm', x, 8, 4, 6, x.data_ptr(), x.data_ptr(), 0, None, 0, None, x.data_ptr(), -1, 1)
+    with pytest.raises(RuntimeError):                              # slabs with a bias
+        L.call('pdae_rows_gemm', x, 8, 4, 8, x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), 0, None, x.data_ptr(), -1, 2)
+    # M = 0 is a no-op
+    L.call('pdae_rows_gemm', x, 0, 4, 8, None, None, 0, None, 0, None, None, -1, 1)
+
+
+def _wgrad(L, M, dims, bias_flags, gen):
+    dys = [torch.randn(M, n, device='cuda', generator=gen) for n, _ in dims]
+    xs = [torch.randn(M, k, device='cuda', generator=gen) for _, k in dims]
+    Ns, Ks = [n for n, _ in dims], [k for _, k in dims]
+    floats = L.rows_wgrad_workspace(M, Ns, Ks)
+    ws = torch.full((max(floats, 1),), float('nan'), device='cuda')
+    dws = [torch.full((n, k), float('nan'), device='cuda') for n, k in dims]
+    dbs = [torch.full((n,), float('nan'), device='cuda') if f else None for (n, _), f in zip(dims, bias_flags)]
+    L.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws)
+    return dys, xs, dws, dbs, floats
+
+
+@pytest.mark.parametrize('M', [1664, 2944, 8192, 100, 16, 33])
+def test_rows_wgrad_block_group(M):
+    """The four Linear layers of a Transformer block in one grouped launch."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M)
+    dims = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
+    flags = [False, False, True, False]
+    dys, xs, dws, dbs, splits = _wgrad(L, M, dims, flags, g)
+    for dy, x, dw, db in zip(dys, xs, dws, dbs):
+        _close(dw, dy.double().t() @ x.double(), 5e-5)
+        if db is not None:
+            _close(db, dy.double().sum(0), 5e-5)
+    g2 = torch.Generator(device='cuda').manual_seed(M)
+    again = _wgrad(L, M, dims, flags, g2)
+    for a, b in zip(dws, again[2]):
+        assert torch.equal(a, b)                                   # fixed reduction order
+
+
+@pytest.mark.parametrize('dims,flags', [([(96, 384)], [True]), ([(128, 4), (384, 128)], [True, True]),
+                                        ([(100, 260)], [False]), ([(4096, 2048)], [True]), ([(512, 256)], [False])])
+def test_rows_wgrad_odd_shapes(dims, flags):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for M in (5248, 77, 1):
+        dys, xs, dws, dbs, _ = _wgrad(L, M, dims, flags, g)
+        for dy, x, dw, db in zip(dys, xs, dws, dbs):
+            _close(dw, dy.double().t() @ x.double(), 5e-5)
+            if db is not None:
+                _close(db, dy.double().sum(0), 5e-5)

@@ -6,5 +6,6 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py 
 grep '"metric"' gpurun_out/prof_bench.log | cut -c1-220
 python tools/prof_db.py gpurun_out/prof/bench_results.db 30 60 > gpurun_out/prof_summary.txt
 python tools/prof_db.py gpurun_out/prof/bench_results.db 30 40 pdae::gemm > gpurun_out/prof_gemm.txt
+python tools/prof_db.py gpurun_out/prof/bench_results.db 30 80 pdae::rows > gpurun_out/prof_rows.txt
 python tools/prof_db.py gpurun_out/prof/bench_results.db 30 0 SEQ > gpurun_out/prof_seq.txt
 rm -f gpurun_out/prof/bench_results.db
