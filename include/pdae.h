@@ -381,7 +381,8 @@ int pdae_layernorm_backward(int M, int C, const float* dy, int dy_slabs, const f
                             const float* mean, const float* rstd,
                             const float* gamma, const float* dres /*nullable*/,
                             float* dx, float* dgamma, float* dbeta,
-                            int accumulate, pdae_stream_t stream);
+                            int accumulate, float* dacc /*nullable*/, int dacc_mode,
+                            pdae_stream_t stream);
 /*   residual_layernorm_forward / _backward: the previous sub-layer's tail folded in
  *       (Block.forward :155-158: x = x + drop_path(branch(...)) followed by the next
  *       norm):  s = res + keep[row/T] * (a + bias) (+ pos);  y = LayerNorm(s);
@@ -391,7 +392,11 @@ int pdae_layernorm_backward(int M, int C, const float* dy, int dy_slabs, const f
  *       dbias = column sums of da; dgamma / dbeta as layernorm_backward.
  *       a_slabs / dy_slabs (1..8): `a` / `dy` arrive as that many split-K slabs
  *       [slabs][M][C] of partial products (pdae_rows_gemm with splits > 1) and are
- *       added up in slab order while they are read; 1 = a plain [M][C] matrix.     */
+ *       added up in slab order while they are read; 1 = a plain [M][C] matrix.
+ *       dacc / dacc_mode (both backward entries): dacc_mode 1 also writes dx to dacc,
+ *       2 adds dx to dacc (the position embedding is re-added before EVERY block of a
+ *       stack, :174-177, so its gradient is the sum of the blocks' dx: accumulated
+ *       here instead of by one elementwise add per block); 0 = off.                  */
 int pdae_residual_layernorm_forward(int M, int C, int T, const float* a, int a_slabs,
                                     const float* bias /*nullable*/,
                                     const float* keep /*nullable*/,
@@ -406,7 +411,8 @@ int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, int d
                                      const float* keep /*nullable*/, float* dx,
                                      float* da /*nullable unless keep*/,
                                      float* dgamma, float* dbeta, float* dbias,
-                                     int accumulate, pdae_stream_t stream);
+                                     int accumulate, float* dacc /*nullable*/,
+                                     int dacc_mode, pdae_stream_t stream);
 int pdae_gelu_forward(long long n, const float* z, float* h,
                       pdae_stream_t stream);
 int pdae_gelu_backward(long long n, const float* z, const float* dh, float* dz,

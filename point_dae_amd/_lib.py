@@ -44,7 +44,7 @@ _SIGNATURES = {
     "pdae_attention_forward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "pdae_attention_backward": [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_add_layernorm_forward": [_i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
-    "pdae_layernorm_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_layernorm_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "pdae_bias_gelu_forward": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_bias_gelu_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_gelu_forward": [ctypes.c_longlong, _vp, _vp, _vp],
@@ -52,7 +52,7 @@ _SIGNATURES = {
     "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_colsum": [_i, _i, _vp, _vp, _i, _vp],
     "pdae_residual_layernorm_forward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
-    "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "pdae_scale_colsum": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_embed_conv1_stats": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bn_finalize": [_i, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -113,8 +113,10 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ keep, int T,
-    float* __restrict__ da, float* __restrict__ dbias, int dy_slabs) {
-  // (dy_slabs > 1: dy arrives as split-K slabs [dy_slabs][M][C], added up in slab order)
+    float* __restrict__ da, float* __restrict__ dbias, int dy_slabs, float* __restrict__ dacc, int dacc_mode) {
+  // (dy_slabs > 1: dy arrives as split-K slabs [dy_slabs][M][C], added up in slab order;
+  //  dacc: a second copy of dx that is written (mode 1) or added to (mode 2): the gradient of the
+  //  position embedding, which every block of a stack re-adds, sums over the blocks right here)
   // (keep / da / dbias: the backward of the branch folded into the forward -- da =
   //  keep[row/T] * dx, dbias += column sums of da; see residual_layernorm_backward)
   extern __shared__ float red[];  // [NW][3][C]: one plain-store slot per wave (LDS float
@@ -182,6 +184,13 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
         o.z = rs_ * (gd[i].z - m1 - xh[i].z * m2) + sk[i].z;
         o.w = rs_ * (gd[i].w - m1 - xh[i].w * m2) + sk[i].w;
         *reinterpret_cast<float4*>(dx + (size_t)row * C + c4 * 4) = o;
+        if (dacc_mode == 1) {
+          *reinterpret_cast<float4*>(dacc + (size_t)row * C + c4 * 4) = o;
+        } else if (dacc_mode == 2) {
+          float4 t = *reinterpret_cast<const float4*>(dacc + (size_t)row * C + c4 * 4);
+          t.x += o.x, t.y += o.y, t.z += o.z, t.w += o.w;
+          *reinterpret_cast<float4*>(dacc + (size_t)row * C + c4 * 4) = t;
+        }
         if (dbias) {
           if (keep) o.x *= kp_, o.y *= kp_, o.z *= kp_, o.w *= kp_;
           if (da) *reinterpret_cast<float4*>(da + (size_t)row * C + c4 * 4) = o;
@@ -419,7 +428,8 @@ extern "C" int pdae_residual_layernorm_forward(int M, int C, int T, const float*
 static int ln_backward(const char* what, int M, int C, int T, const float* dy, int dy_slabs, const float* x,
                        const float* mean, const float* rstd, const float* gamma, const float* dres,
                        const float* keep, float* dx, float* da, float* dgamma, float* dbeta, float* dbias,
-                       int accumulate, pdae_stream_t stream) {
+                       int accumulate, float* dacc, int dacc_mode, pdae_stream_t stream) {
+  if (dacc_mode < 0 || dacc_mode > 2 || (dacc_mode && !dacc)) return bad_arg("layernorm backward: bad dacc");
   if (M < 0 || C <= 0 || C % 4 != 0 || C > 4 * kWave * LN_MAX4 || T <= 0 || dy_slabs < 1 || dy_slabs > 8)
     return bad_arg("layernorm backward: C must be a multiple of 4, at most 2048; T > 0; 1..8 slabs");
   if (!dgamma || !dbeta) return bad_arg("layernorm backward: null pointer");
@@ -440,13 +450,13 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
     const int rows = 16 * per_wave;
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
                        16 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias, dy_slabs);
+                       dbeta, keep, T, da, dbias, dy_slabs, dacc, dacc_mode);
   } else {
     int rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
     if (rows > 32) rows = 32;
     hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3((M + rows - 1) / rows), dim3(256),
                        4 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias, dy_slabs);
+                       dbeta, keep, T, da, dbias, dy_slabs, dacc, dacc_mode);
   }
   return check_launch(what);
 }
@@ -454,9 +464,9 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
 extern "C" int pdae_layernorm_backward(int M, int C, const float* dy, int dy_slabs, const float* x,
                                        const float* mean, const float* rstd, const float* gamma,
                                        const float* dres, float* dx, float* dgamma, float* dbeta,
-                                       int accumulate, pdae_stream_t stream) {
+                                       int accumulate, float* dacc, int dacc_mode, pdae_stream_t stream) {
   return ln_backward("layernorm_backward", M, C, 1, dy, dy_slabs, x, mean, rstd, gamma, dres, nullptr, dx, nullptr,
-                     dgamma, dbeta, nullptr, accumulate, stream);
+                     dgamma, dbeta, nullptr, accumulate, dacc, dacc_mode, stream);
 }
 
 extern "C" int pdae_residual_layernorm_backward(int M, int C, int T, const float* dy, int dy_slabs, const float* x,
@@ -464,10 +474,10 @@ extern "C" int pdae_residual_layernorm_backward(int M, int C, int T, const float
                                                 const float* gamma, const float* dres,
                                                 const float* keep, float* dx, float* da, float* dgamma,
                                                 float* dbeta, float* dbias, int accumulate,
-                                                pdae_stream_t stream) {
+                                                float* dacc, int dacc_mode, pdae_stream_t stream) {
   if (!dbias) return bad_arg("residual_layernorm_backward: null pointer");
   return ln_backward("residual_layernorm_backward", M, C, T, dy, dy_slabs, x, mean, rstd, gamma, dres, keep, dx, da,
-                     dgamma, dbeta, dbias, accumulate, stream);
+                     dgamma, dbeta, dbias, accumulate, dacc, dacc_mode, stream);
 }
 
 extern "C" int pdae_gelu_forward(long long n, const float* z, float* h, pdae_stream_t stream) {

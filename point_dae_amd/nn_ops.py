@@ -82,14 +82,36 @@ def _add_ln_forward(x, pos, gamma, beta, eps):
     return s, y, mean, rstd
 
 
-def _ln_backward(dy, s, mean, rstd, gamma, dres):
+class PosGrad:
+    """Gradient of a stack's position embedding.  The reference re-adds `pos` before EVERY block
+    (PointCAE_transformer.py:174-177), so d pos = the sum over the blocks of each block's d(stream);
+    the LayerNorm-backward kernel of each block adds its dx into one buffer (the last block of the
+    stack, first in the backward pass, writes it; the first block returns it to autograd) instead
+    of autograd running one elementwise add per block."""
+    __slots__ = ('n', 'buf')
+
+    def __init__(self, n):
+        self.n, self.buf = n, None
+
+    def mode(self, index, like):
+        """-> (buffer or None, kernel mode, this block returns the buffer as its pos gradient)"""
+        if self.n <= 1:
+            return None, 0, False
+        if index == self.n - 1:
+            self.buf = torch.empty_like(like)
+            return self.buf, 1, False
+        return self.buf, 2, index == 0
+
+
+def _ln_backward(dy, s, mean, rstd, gamma, dres, dacc=None, dacc_mode=0):
     """dy may be split-K slabs (S, M, C).  -> dx, dgamma, dbeta"""
     M, C = s.shape
     dx = torch.empty_like(s)
     gb, _ = arena.take(2 * C, s)
     dg, db = gb[:C], gb[C:]
     _lib.call('pdae_layernorm_backward', s, M, C, _lib.ptr(dy), _slabs(dy), _lib.ptr(s), _lib.ptr(mean),
-              _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), 1)
+              _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), 1,
+              _lib.ptr(dacc), dacc_mode)
     return dx, dg, db
 
 
@@ -103,7 +125,7 @@ def _res_ln_forward(a, bias, keep, res, pos, gamma, beta, eps, T):
     return s, y, mean, rstd
 
 
-def _res_ln_backward(dy, s, mean, rstd, gamma, dres, keep, T):
+def _res_ln_backward(dy, s, mean, rstd, gamma, dres, keep, T, dacc=None, dacc_mode=0):
     """dy may be split-K slabs (S, M, C).  -> dx (w.r.t. the stream), da (w.r.t. the branch),
     dgamma, dbeta, dbias (column sums of da)"""
     M, C = s.shape
@@ -113,7 +135,8 @@ def _res_ln_backward(dy, s, mean, rstd, gamma, dres, keep, T):
     da = torch.empty_like(s) if keep is not None else dx
     _lib.call('pdae_residual_layernorm_backward', s, M, C, T, _lib.ptr(dy), _slabs(dy), _lib.ptr(s),
               _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(dres), _lib.ptr(keep), _lib.ptr(dx),
-              _lib.ptr(da) if keep is not None else None, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), 1)
+              _lib.ptr(da) if keep is not None else None, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dbias), 1,
+              _lib.ptr(dacc), dacc_mode)
     return dx, da, dg, db, dbias
 
 
@@ -151,6 +174,26 @@ class _ResidualLayerNorm(torch.autograd.Function):
         dx, da, dg, db, dbias = _res_ln_backward(dy.contiguous(), s, mean, rstd, gamma, ds, keep, ctx.T)
         return (_to_slabs(da, ctx.slabs), (dbias if ctx.has_bias else None), None, dx, (dx if ctx.has_pos else None),
                 dg, db, None, None)
+
+
+class _ExpandToken(torch.autograd.Function):
+    """token (1,1,C) -> (B, M, C) view; backward = column sums on the colsum kernel (ATen's strided
+    reduction of the decoder's mask-token gradient took 46 us)."""
+
+    @staticmethod
+    def forward(ctx, token, B, M):
+        return token.expand(B, M, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        return _colsum(g2).clone().reshape(1, 1, -1), None, None
+
+
+def expand_token(token, B, M):
+    if not token.is_cuda or token.shape[-1] % 4 != 0:
+        return token.expand(B, M, -1)
+    return _ExpandToken.apply(token, B, M)
 
 
 class Pending:
@@ -430,7 +473,7 @@ class _TransformerBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a_in, bias_in, keep_in, res, pos, keep1, keep2, g1, b1, wqkv, wproj, bproj, g2, b2, w1,
-                bf1, w2, B, T, H, scale, eps1, eps2):
+                bf1, w2, B, T, H, scale, eps1, eps2, pos_grad):
         res = res.contiguous()
         M, C = res.shape
         if a_in is not None:
@@ -453,6 +496,7 @@ class _TransformerBlock(torch.autograd.Function):
         ctx.has_in, ctx.has_pos, ctx.has_bias_in, ctx.in_slabs = a_in is not None, pos is not None, bias_in is not None, \
             (_slabs(a_in) if a_in is not None else 1)
         ctx.a2_slabs = _slabs(a2)
+        ctx.pos_grad = pos_grad if pos is not None else None          # (PosGrad, index of this block in its stack)
         ctx.set_materialize_grads(False)
         return a2, x2
 
@@ -471,24 +515,28 @@ class _TransformerBlock(torch.autograd.Function):
         _lib.call('pdae_attention_backward', qkv, B, T, H, D, scale, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse),
                   _lib.ptr(do), _lib.ptr(dqkv))
         dn1 = rows_gemm(dqkv, wqkv, True, may_split=True)
+        dacc, dmode, ret_acc = ctx.pos_grad[0].mode(ctx.pos_grad[1], x1) if ctx.pos_grad is not None else (None, 0, False)
         if ctx.has_in:
-            dx0, da0, dg1, db1, dbias_in = _res_ln_backward(dn1, x1, mean1, rstd1, g1, dx1, keep_in, T)
+            dx0, da0, dg1, db1, dbias_in = _res_ln_backward(dn1, x1, mean1, rstd1, g1, dx1, keep_in, T, dacc, dmode)
             da0 = _to_slabs(da0, ctx.in_slabs)
         else:
-            dx0, dg1, db1 = _ln_backward(dn1, x1, mean1, rstd1, g1, dx1)
+            dx0, dg1, db1 = _ln_backward(dn1, x1, mean1, rstd1, g1, dx1, dacc, dmode)
             da0 = dbias_in = None
+        # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
+        dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
         (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
                                                                 [False, False, True, False])
-        return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dx0 if ctx.has_pos else None, None, None,
-                dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None)
+        return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
+                dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None)
 
 
-def transformer_block(x, pos, B, T, blk, keeps, pending=False):
+def transformer_block(x, pos, B, T, blk, keeps, pending=False, pos_grad=None):
     """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
     (PointCAE_transformer.py:155-158, :174-177) as one autograd Function.  `keeps` =
     (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path.
     x may be a Pending (the previous block's MLP branch, added here by norm1's
-    kernel); with pending=True the result is one too (for the next norm)."""
+    kernel); with pending=True the result is one too (for the next norm).  pos_grad =
+    (PosGrad of the stack, index of this block): d pos is summed inside the kernels."""
     attn, mlp = blk.attn, blk.mlp
     keep1, keep2 = keeps
     if isinstance(x, Pending):
@@ -498,6 +546,6 @@ def transformer_block(x, pos, B, T, blk, keeps, pending=False):
     a2, x2 = _TransformerBlock.apply(a_in, bias_in, keep_in, res, pos, keep1, keep2, blk.norm1.weight, blk.norm1.bias,
                                      attn.qkv.weight, attn.proj.weight, attn.proj.bias, blk.norm2.weight,
                                      blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, B, T,
-                                     attn.num_heads, attn.scale, blk.norm1.eps, blk.norm2.eps)
+                                     attn.num_heads, attn.scale, blk.norm1.eps, blk.norm2.eps, pos_grad)
     out = Pending(a2, mlp.fc2.bias, keep2, x2, T)
     return out if pending else out.resolve()

@@ -96,11 +96,11 @@ class Block(nn.Module):
         self.attn = Attention(dim, num_heads)
         self.drop_prob = float(drop_path)
 
-    def forward(self, x, pos, B, T, keeps=(None, None), pending=False):
+    def forward(self, x, pos, B, T, keeps=(None, None), pending=False, pos_grad=None):
         """x, pos: (B*T, C) rows; computes block(x + pos).  x may be, and with
         pending=True the result is, an nn_ops.Pending (a branch not yet added to the
         residual stream: the next norm's kernel adds it)."""
-        return nn_ops.transformer_block(x, pos, B, T, self, keeps, pending)
+        return nn_ops.transformer_block(x, pos, B, T, self, keeps, pending, pos_grad)
 
 
 def _stack_keeps(stack, B):
@@ -115,8 +115,9 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, x, pos, B, T):
         keeps = _stack_keeps(self, B)
-        for blk, k in zip(self.blocks, keeps):   # position re-added before EVERY block (:174-177)
-            x = blk(x, pos, B, T, k, pending=True)
+        pg = nn_ops.PosGrad(len(self.blocks))
+        for i, (blk, k) in enumerate(zip(self.blocks, keeps)):   # position re-added before EVERY block (:174-177)
+            x = blk(x, pos, B, T, k, pending=True, pos_grad=(pg, i))
         return x                                 # nn_ops.Pending: the caller's norm adds the last branch
 
 
@@ -141,8 +142,9 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, x, pos, B, T, return_token_num=-1):
         keeps = _stack_keeps(self, B)
-        for blk, k in zip(self.blocks, keeps):
-            x = blk(x, pos, B, T, k, pending=True)
+        pg = nn_ops.PosGrad(len(self.blocks))
+        for i, (blk, k) in enumerate(zip(self.blocks, keeps)):
+            x = blk(x, pos, B, T, k, pending=True, pos_grad=(pg, i))
         # LayerNorm is row-wise: norm(x[:, -n:]) (:229-231) == norm(x)[:, -n:]; normalising every row
         # lets the norm's kernel also do the last block's bias + DropPath + residual add
         y = nn_ops.layer_norm(x, self.norm)
@@ -298,7 +300,7 @@ class PointCAE_transformer(nn.Module):
         ctr = center.reshape(B * G, 3)
         order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
         pos_full = nn_ops.pos_embed(ctr.index_select(0, order), self.decoder_pos_embed)
-        x_full = torch.cat([x_vis.reshape(B, Tvis, C), self.mask_token.expand(B, M, -1)], dim=1)
+        x_full = torch.cat([x_vis.reshape(B, Tvis, C), nn_ops.expand_token(self.mask_token, B, M)], dim=1)
         x_full = x_full.reshape(B * G, C)
         if self.all_patch == 'True':
             x_rec = self.MAE_decoder(x_full, pos_full, B, G)

@@ -21,7 +21,7 @@ for M in (2944, 8192):
     gb = torch.zeros(2 * C, device='cuda')
     f = lambda: _lib.call('pdae_add_layernorm_forward', x, M, C, x.data_ptr(), None, g.data_ptr(), b.data_ptr(), 1e-5, None, y.data_ptr(), mean.data_ptr(), rstd.data_ptr())
     f()
-    bw = lambda: _lib.call('pdae_layernorm_backward', x, M, C, dy.data_ptr(), 1, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dres.data_ptr(), dx.data_ptr(), gb.data_ptr(), gb[C:].data_ptr(), 1)
+    bw = lambda: _lib.call('pdae_layernorm_backward', x, M, C, dy.data_ptr(), 1, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dres.data_ptr(), dx.data_ptr(), gb.data_ptr(), gb[C:].data_ptr(), 1, None, 0)
     print(f"M={M}: ln fwd {timeit(f):.1f} us  ln bwd {timeit(bw):.1f} us  (bytes bwd {4*M*C*4/1e6:.1f} MB)")
     B, T, H = (128, M // 128, 6)
     qkv = torch.randn(M, 1152, device='cuda'); o = torch.empty(M, 384, device='cuda'); lse = torch.empty(B, H, T, device='cuda'); do = torch.randn(M, 384, device='cuda'); dqkv = torch.empty_like(qkv)
