@@ -165,8 +165,6 @@ def main():
     use_created_stream(device)      # one created stream for everything: NULL-stream work breaks hipGraph replays here
 
     from point_dae_amd import builder, nn_ops
-    from point_dae_amd.tuning import enable_tuned_gemms
-    tuned = enable_tuned_gemms(retune=os.environ.get('PDAE_RETUNE') == '1', out=os.environ.get('PDAE_RETUNE_OUT'))
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.misc import set_random_seed
@@ -285,7 +283,7 @@ def main():
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
                        'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
                        'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay',
-                       'library_gemm_selection': 'TunableOp lookup of point_dae_amd/tunableop_gfx950.csv' if tuned else 'default heuristic'},
+                       'dense_layers': 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
             'roofline': roof,
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},

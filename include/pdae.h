@@ -213,8 +213,12 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  *                [S][M][N] of partial products (epi 0, no bias) which the
  *                consumer adds up (residual_layernorm_forward / layernorm_backward
  *                take a slab count); -1 = 1.
- *   rows_gemm_plan: the (cfg, splits) rows_gemm would pick; may_split = 0 keeps
- *       splits = 1.
+ *       stream_blocks : 0, or P (a multiple of 8) = stream-K: the (tile, k-tile)
+ *                units are dealt in equal contiguous ranges to P blocks; the q-th
+ *                piece of a tile goes to slab q of Y, unused slabs of a tile are
+ *                zero-filled (`splits` = number of slabs, as planned).
+ *   rows_gemm_plan: the (cfg, splits, stream_blocks) rows_gemm would pick;
+ *       may_split = 0 keeps splits = 1 and stream_blocks = 0.
  *   rows_wgrad: weight gradients of a GROUP of nprob <= 8 Linear layers that
  *       share M in one launch: dW_p[N_p,K_p] = dY_p[M,N_p]^T . X_p[M,K_p],
  *       db_p[N_p] = column sums of dY_p (db or db[p] nullable).  Pointer arrays
@@ -225,9 +229,10 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  */
 int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn,
                    const float* bias /*nullable*/, int epi, float* Z /*epi 2,3*/,
-                   float* Y, int cfg, int splits, pdae_stream_t stream);
+                   float* Y, int cfg, int splits, int stream_blocks,
+                   pdae_stream_t stream);
 int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg,
-                        int* splits);
+                        int* splits, int* stream_blocks);
 int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks,
                               long long* floats);
 int pdae_rows_wgrad(int M, int nprob, const float* const* dY,

@@ -31,7 +31,7 @@ _SIGNATURES = {
     "pdae_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "pdae_linear_backward_data": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "pdae_rows_gemm": [_i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "pdae_rows_gemm": [_i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "pdae_rows_wgrad": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -63,7 +63,7 @@ _SIGNATURES = {
 }
 # host-side queries (no stream argument)
 _HOST = {
-    "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp],
+    "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
 }
 _STR = ("pdae_version", "pdae_last_error")
@@ -152,15 +152,16 @@ _plan_cache = {}
 
 
 def rows_gemm_plan(M, N, K, w_kn, may_split):
-    """(cfg, splits) of pdae_rows_gemm for a shape (host-side query, cached)."""
+    """(cfg, splits, stream_blocks) of pdae_rows_gemm for a shape (host-side query, cached)."""
     key = (M, N, K, w_kn, may_split)
     hit = _plan_cache.get(key)
     if hit is None:
         handle = lib()
-        cfg, splits = ctypes.c_int(0), ctypes.c_int(0)
+        cfg, splits, sb = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _check(handle, 'pdae_rows_gemm_plan',
-               handle.pdae_rows_gemm_plan(M, N, K, int(w_kn), int(may_split), ctypes.byref(cfg), ctypes.byref(splits)))
-        hit = _plan_cache[key] = (cfg.value, splits.value)
+               handle.pdae_rows_gemm_plan(M, N, K, int(w_kn), int(may_split), ctypes.byref(cfg), ctypes.byref(splits),
+                                          ctypes.byref(sb)))
+        hit = _plan_cache[key] = (cfg.value, splits.value, sb.value)
     return hit
 
 

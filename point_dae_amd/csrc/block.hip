@@ -11,6 +11,7 @@
 //   rowscale            da = keep[b] * dy                (its backward)
 //   colsum              bias gradients
 // One wave per row for the LayerNorm kernels (C <= 2048), float4 everywhere.
+#include <cstdlib>
 #include "common.h"
 
 namespace pdae {
@@ -446,7 +447,8 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
   if (C <= 512) {
     // 16-wave blocks, one row per wave (two from 6144 rows on: fewer blocks = fewer atomics);
     // measured 13 us at M = 2944 and 20 us at M = 8192 (was 24 / 29 us with LDS atomics)
-    const int per_wave = M >= 6144 ? 2 : 1;
+    static const int force = getenv("PDAE_LN_PER_WAVE") ? atoi(getenv("PDAE_LN_PER_WAVE")) : 0;   // lab override
+    const int per_wave = force ? force : (M >= 6144 ? 2 : 1);
     const int rows = 16 * per_wave;
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
                        16 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,

@@ -230,18 +230,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
       // keep the compiler from sinking those reads back to their first use
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      // k-steps outermost: consecutive MFMAs go to different accumulators (back-to-back MFMAs on
-      // ONE accumulator issue every ~72 cycles instead of 64, rows_gemm.hip)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float av = t == 0 ? a[cur][i].x : t == 1 ? a[cur][i].y : t == 2 ? a[cur][i].z : a[cur][i].w;
-            const float bv = t == 0 ? b[cur][j].x : t == 1 ? b[cur][j].y : t == 2 ? b[cur][j].z : b[cur][j].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].x, b[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].y, b[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].z, b[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].w, b[cur][j].w, acc[i][j], 0, 0, 0);
+        }
 #ifndef PDAE_NT_NO_SGB
       // issue order: one fragment read of the next k-group behind every four MFMAs (the reads
       // then never queue up in front of an MFMA that needs them; measured 99 -> 104 TFLOP/s in

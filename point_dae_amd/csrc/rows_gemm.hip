@@ -50,6 +50,8 @@ struct Args {
   int tiles_n, tiles;
   int kchunk;         // reduction range of one split (blockIdx.y), a multiple of BK
   long long slab;     // elements between the C slabs of consecutive splits
+  int stream_blocks;  // > 0: stream-K over (tile, k-tile) units on this many blocks, `slabs` C slabs
+  int slabs;
 #ifdef PDAE_ROWS_STAMPS
   long long* stamps;  // diagnostic build (tools/lab): [block][8] s_memrealtime / s_memtime marks
 #endif
@@ -84,12 +86,34 @@ void rows_gemm_kernel(const Args p) {
   constexpr int BQ = BN / 4;                               // float4 per staged [k][n] row
   constexpr int PF = TI * TJ <= 4 ? 2 : 1;                 // k-tiles of global loads in flight (register sets)
   extern __shared__ float lds[];                           // [2][ASZ + BSZ]
-  // XCD-aware order: blocks b, b + 8, ... share an L2; each XCD owns a contiguous chunk of tiles
-  // (n fastest), so the tiles_n re-reads of an A row band hit that L2.
-  const int chunk = (p.tiles + 7) >> 3;
-  const int slot = blockIdx.x >> 3;
-  const int tile = (blockIdx.x & 7) * chunk + slot;
-  if (slot >= chunk || tile >= p.tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int scol = (tid & 7) * 4;
+  const int M = p.M, N = p.N;
+  // Work of this block.  Plain mode: ONE tile (XCD-aware order: blocks b, b + 8, ... share an L2;
+  // each XCD owns a contiguous chunk of tiles, n fastest, so the tiles_n re-reads of an A row band
+  // hit that L2) and the k range of split blockIdx.y.  Stream mode (narrow outputs with a long
+  // reduction: proj, fc2, the fc1 / qkv data gradients): (tile, k-tile) units in tile-major order,
+  // dealt in EQUAL contiguous ranges to a grid that is resident at once; a range crosses tile
+  // boundaries, the piece of tile t that is the q-th one in unit order goes to slab q of the
+  // output, the block that ends a tile zero-fills the slabs the tile did not need, and the
+  // consumer (a LayerNorm kernel) adds the slabs: no block carries more MFMAs than another, where
+  // 276 or 414 equal tiles leave a quarter of the 256 CUs with twice the work.
+  const int KTA = (p.K + BK - 1) / BK;
+  const long long units = (long long)p.tiles * KTA;
+  long long u = 0, uend = 1;
+  int sb = 0;
+  if (p.stream_blocks) {
+    const int P = p.stream_blocks;
+    sb = (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3);   // an XCD's blocks take consecutive ranges
+    u = sb * units / P, uend = (sb + 1) * units / P;
+    if (u >= uend) return;
+  } else {
+    const int chunk = (p.tiles + 7) >> 3;
+    const int slot = blockIdx.x >> 3;
+    if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
+  }
 #ifdef PDAE_ROWS_STAMPS
   if (p.stamps && threadIdx.x == 0) {
     long long* st = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
@@ -102,14 +126,25 @@ void rows_gemm_kernel(const Args p) {
   }
 #endif
   PDAE_STAMP(0)
+  for (;;) {
+  int tile, kbeg, kend, piece = 0;
+  bool tile_ends = false;
+  if (p.stream_blocks) {
+    tile = (int)(u / KTA);
+    const int k0 = (int)(u % KTA), k1 = (int)min((long long)KTA, k0 + (uend - u));
+    u += k1 - k0;
+    kbeg = k0 * BK, kend = min(p.K, k1 * BK);
+    tile_ends = k1 == KTA;
+    // blocks before this one that hold a piece of the tile: the tile's first unit lies in block
+    // floor(((u_first + 1) P - 1) / units)
+    const long long uf = (long long)tile * KTA;
+    piece = sb - (int)(((uf + 1) * p.stream_blocks - 1) / units);
+  } else {
+    tile = (int)(blockIdx.x & 7) * ((p.tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+    kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    piece = blockIdx.y;
+  }
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-  const int M = p.M, N = p.N;
-  const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
-  const int scol = (tid & 7) * 4;
-
   // 32-bit BYTE offsets from the (uniform) operand bases: one VGPR per staged row and the
   // scalar-base + vector-offset form of global_load (the launcher checks the operands are < 4 GB);
   // rows past the matrix edge are clamped (their products are never stored)
@@ -326,9 +361,10 @@ void rows_gemm_kernel(const Args p) {
   PDAE_STAMP(2)
   // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
   // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
-  float* Cs = p.C + (size_t)blockIdx.y * p.slab;
-  auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+  float* Cs = p.C + (size_t)piece * p.slab;
+  auto epilogue = [&](auto full_c, auto zero_c) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_c)::value;
+    constexpr bool ZERO = decltype(zero_c)::value;     // zero-fill of an unused slab (stream mode)
     const unsigned ldc = (unsigned)p.ldc;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -343,6 +379,10 @@ void rows_gemm_kernel(const Args p) {
         for (int e = 0; e < 16; ++e) {
           const int lr = (e & 3) + 8 * (e >> 2);
           if (!FULL && !(colok && rbase + lr < M)) continue;
+          if (ZERO) {
+            Cs[off + (unsigned)lr * ldc] = 0.f;
+            continue;
+          }
           float v = acc[i][j][e] + bv;
           if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
           if (EPI == EPI_BIAS_GELU2) {
@@ -358,10 +398,19 @@ void rows_gemm_kernel(const Args p) {
       }
     }
   };
-  if (m0 + BM <= M && n0 + BN <= N)
-    epilogue(std::true_type{});
-  else
-    epilogue(std::false_type{});
+  const bool full = m0 + BM <= M && n0 + BN <= N;
+  if (full) epilogue(std::true_type{}, std::false_type{});
+  else epilogue(std::false_type{}, std::false_type{});
+  if (!p.stream_blocks) break;
+  if (tile_ends)
+    for (int q = piece + 1; q < p.slabs; ++q) {
+      Cs = p.C + (size_t)q * p.slab;
+      if (full) epilogue(std::true_type{}, std::true_type{});
+      else epilogue(std::false_type{}, std::true_type{});
+    }
+  if (u >= uend) break;
+  __syncthreads();      // every wave is done with the LDS buffers before the next segment stages into them
+  }   // segments
 #ifdef PDAE_ROWS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PDAE_STAMP(3)
@@ -630,20 +679,48 @@ static double plan_cost(int M, int N, int K, int cfg, int splits, bool bkn) {
   return cost;
 }
 
-static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, int* splits) {
+// slabs a stream-K plan needs: the most pieces any tile is cut into when `units` = tiles * kt
+// units are dealt to P blocks in ranges [b units / P, (b + 1) units / P)
+static int stream_slabs(long long tiles, int kt, int P) {
+  const long long units = tiles * kt;
+  int most = 1;
+  for (long long t = 0; t < tiles; ++t) {
+    const long long u0 = t * kt, u1 = u0 + kt - 1;
+    const int n = (int)(((u1 + 1) * P - 1) / units - ((u0 + 1) * P - 1) / units) + 1;
+    if (n > most) most = n;
+  }
+  return most;
+}
+
+static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, int* splits, int* stream_blocks) {
   static const int order[] = {3, 1, 2, 6, 4, 0, 5, 7};           // ties go to the smaller tile
   double best = 1e300;
-  *cfg = 3, *splits = 1;
+  *cfg = 3, *splits = 1, *stream_blocks = 0;
   for (int c : order)
     for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
       if (s > 1 && K / s < 128) continue;
       const double t = plan_cost(M, N, K, c, s, bkn);
       if (t < best * 0.995) best = t, *cfg = c, *splits = s;
     }
+  if (may_split) {
+    // stream-K on the 64x64 tile: every SIMD carries units / P * 16 MFMAs per resident block
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    const int kt = (K + BK - 1) / BK;
+    for (int P : {1024, 512, 256}) {
+      const long long units = tiles * kt;
+      if (units < 2LL * P) continue;
+      const int S = stream_slabs(tiles, kt, P);
+      if (S > 4) continue;
+      const double per_simd = (double)((units + P - 1) / P) * 16. * (P / 256);
+      const double t = per_simd * (P == 256 ? 1.33 : 1.0) + 110. + 8. * S;
+      if (t < best * 0.97) best = t, *cfg = 3, *splits = S, *stream_blocks = P;
+      break;
+    }
+  }
 }
 
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
-static void launch_cfg(Args& a, int splits, hipStream_t s) {
+static void launch_cfg(Args& a, int splits, int stream_blocks, hipStream_t s) {
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
@@ -657,21 +734,22 @@ static void launch_cfg(Args& a, int splits, hipStream_t s) {
     once = true;
   }
   const int chunk = (a.tiles + 7) / 8;
-  hipLaunchKernelGGL((rows_gemm_kernel<TI, TJ, WM, WN, BKN, EPI>), dim3(8 * chunk, splits), dim3(WM * WN * 64),
-                     lds, s, a);
+  a.stream_blocks = stream_blocks, a.slabs = splits;
+  const dim3 grid = stream_blocks ? dim3(stream_blocks, 1) : dim3(8 * chunk, splits);
+  hipLaunchKernelGGL((rows_gemm_kernel<TI, TJ, WM, WN, BKN, EPI>), grid, dim3(WM * WN * 64), lds, s, a);
 }
 
 template <bool BKN, int EPI>
-static void launch_rows(Args& a, int cfg, int splits, hipStream_t s) {
+static void launch_rows(Args& a, int cfg, int splits, int sb, hipStream_t s) {
   switch (cfg) {
-    case 0: launch_cfg<2, 2, 2, 2, BKN, EPI>(a, splits, s); break;
-    case 1: launch_cfg<1, 2, 2, 2, BKN, EPI>(a, splits, s); break;
-    case 2: launch_cfg<2, 1, 2, 2, BKN, EPI>(a, splits, s); break;
-    case 3: launch_cfg<1, 1, 2, 2, BKN, EPI>(a, splits, s); break;
-    case 4: launch_cfg<1, 3, 2, 2, BKN, EPI>(a, splits, s); break;
-    case 5: launch_cfg<3, 1, 1, 4, BKN, EPI>(a, splits, s); break;
-    case 6: launch_cfg<1, 3, 4, 1, BKN, EPI>(a, splits, s); break;
-    default: launch_cfg<2, 3, 2, 2, BKN, EPI>(a, splits, s); break;
+    case 0: launch_cfg<2, 2, 2, 2, BKN, EPI>(a, splits, sb, s); break;
+    case 1: launch_cfg<1, 2, 2, 2, BKN, EPI>(a, splits, sb, s); break;
+    case 2: launch_cfg<2, 1, 2, 2, BKN, EPI>(a, splits, sb, s); break;
+    case 3: launch_cfg<1, 1, 2, 2, BKN, EPI>(a, splits, sb, s); break;
+    case 4: launch_cfg<1, 3, 2, 2, BKN, EPI>(a, splits, sb, s); break;
+    case 5: launch_cfg<3, 1, 1, 4, BKN, EPI>(a, splits, sb, s); break;
+    case 6: launch_cfg<1, 3, 4, 1, BKN, EPI>(a, splits, sb, s); break;
+    default: launch_cfg<2, 3, 2, 2, BKN, EPI>(a, splits, sb, s); break;
   }
 }
 
@@ -686,15 +764,16 @@ static long long* g_stamps = nullptr;
 extern "C" void pdae_lab_set_stamps(long long* p) { g_stamps = p; }
 #endif
 
-extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits) {
-  if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits) return bad_arg("rows_gemm_plan: bad argument");
-  plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits);
+extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits,
+                                   int* stream_blocks) {
+  if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits || !stream_blocks) return bad_arg("rows_gemm_plan: bad argument");
+  plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits, stream_blocks);
   return PDAE_OK;
 }
 
 extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn,
                               const float* bias, int epi, float* Z, float* Y, int cfg, int splits,
-                              pdae_stream_t stream) {
+                              int stream_blocks, pdae_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return bad_arg("rows_gemm: bad size");
   if (K % 4 != 0 || (w_kn && N % 4 != 0)) return unsupported("rows_gemm: K (and N for a [K,N] weight) must be multiples of 4");
   if (epi < 0 || epi > 3) return bad_arg("rows_gemm: epi must be 0..3");
@@ -702,10 +781,20 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
     return unsupported("rows_gemm: operands of 4 GB or more (32-bit byte offsets)");
   if (cfg >= NCFG || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
   if (cfg < 0 || splits < 0) {
-    int c, s;
-    plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s);
+    int c, s, b;
+    plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s, &b);
     if (cfg < 0) cfg = c;
-    if (splits < 0) splits = 1;
+    if (splits < 0) splits = 1, stream_blocks = 0;
+  }
+  if (stream_blocks < 0 || stream_blocks % 8 != 0) return bad_arg("rows_gemm: stream_blocks must be a multiple of 8");
+  if (stream_blocks) {
+    const Cfg& c = kCfg[cfg];
+    const long long tiles = (long long)((M + 32 * c.ti * c.wm - 1) / (32 * c.ti * c.wm)) *
+                            ((N + 32 * c.tj * c.wn - 1) / (32 * c.tj * c.wn));
+    if (M > 0 && (tiles * ((K + BK - 1) / BK) < stream_blocks ||
+                  stream_slabs(tiles, (K + BK - 1) / BK, stream_blocks) > splits))
+      return bad_arg("rows_gemm: too few slabs (or units) for this stream-K grid");
+    if (epi != EPI_STORE || bias) return bad_arg("rows_gemm: stream-K slabs take the plain store epilogue without bias");
   }
   if (splits > 1 && (epi != EPI_STORE || bias)) return bad_arg("rows_gemm: split-K slabs take the plain store epilogue without bias");
   if (M == 0) return PDAE_OK;
@@ -722,12 +811,12 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
 #endif
   hipStream_t s = as_stream(stream);
   if (!w_kn) {
-    if (epi == EPI_STORE) launch_rows<false, EPI_STORE>(a, cfg, splits, s);
-    else if (epi == EPI_BIAS_RELU) launch_rows<false, EPI_BIAS_RELU>(a, cfg, splits, s);
-    else launch_rows<false, EPI_BIAS_GELU2>(a, cfg, splits, s);
+    if (epi == EPI_STORE) launch_rows<false, EPI_STORE>(a, cfg, splits, stream_blocks, s);
+    else if (epi == EPI_BIAS_RELU) launch_rows<false, EPI_BIAS_RELU>(a, cfg, splits, 0, s);
+    else launch_rows<false, EPI_BIAS_GELU2>(a, cfg, splits, 0, s);
   } else {
-    if (epi == EPI_STORE) launch_rows<true, EPI_STORE>(a, cfg, splits, s);
-    else launch_rows<true, EPI_MUL_GELUGRAD>(a, cfg, splits, s);
+    if (epi == EPI_STORE) launch_rows<true, EPI_STORE>(a, cfg, splits, stream_blocks, s);
+    else launch_rows<true, EPI_MUL_GELUGRAD>(a, cfg, splits, 0, s);
   }
   return check_launch("rows_gemm");
 }

@@ -6,7 +6,6 @@ from . import dist_utils, parser
 from .config import get_config
 from .misc import set_random_seed
 from .runner_pretrain import run_net
-from .tuning import enable_tuned_gemms
 
 
 def main(argv=None):
@@ -23,7 +22,6 @@ def main(argv=None):
         import os
         dist_utils.init_dist(args.launcher, backend=os.environ.get('PDAE_DIST_BACKEND', 'nccl'))
         _, args.world_size = dist_utils.get_dist_info()
-    enable_tuned_gemms()
     config = get_config(args)
     if args.model_name != 'none':
         config.model.NAME = args.model_name

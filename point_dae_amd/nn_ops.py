@@ -358,10 +358,10 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
     consumer adds them up (the LayerNorm kernels do)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
-    cfg, splits = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
+    cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
     _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), epi, _lib.ptr(z),
-              _lib.ptr(y), cfg, splits)
+              _lib.ptr(y), cfg, splits, sb)
     return y
 
 

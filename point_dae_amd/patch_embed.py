@@ -49,10 +49,10 @@ def _gemm(x, w, w_kn=False, bias=None):
     """x . w^T (+ bias) with w (N, K), or x . w with w (K, N) when w_kn (csrc/rows_gemm.hip)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
-    cfg, splits = _lib.rows_gemm_plan(M, N, K, w_kn, False)
+    cfg, _, _ = _lib.rows_gemm_plan(M, N, K, w_kn, False)
     y = _empty((M, N), x)
     _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), 0, None,
-              _lib.ptr(y), cfg, 1)
+              _lib.ptr(y), cfg, 1, 0)
     return y
 
 

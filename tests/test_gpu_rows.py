@@ -20,12 +20,12 @@ def _close(a, b, tol=2e-5):
     assert err <= tol, err
 
 
-def _gemm(L, x, w, w_kn, bias, epi, z, cfg, splits):
+def _gemm(L, x, w, w_kn, bias, epi, z, cfg, splits, stream_blocks=0):
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
     y = torch.full((max(splits, 1), M, N), float('nan'), device='cuda')
     L.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), int(w_kn), L.ptr(bias), epi, L.ptr(z),
-           y.data_ptr(), cfg, splits)
+           y.data_ptr(), cfg, splits, stream_blocks)
     return y
 
 
@@ -95,20 +95,47 @@ def test_rows_gemm_split_slabs(M, N, K, w_kn, splits):
         assert torch.equal(y, y2)                                  # deterministic
 
 
+@pytest.mark.parametrize('M,N,K', [(2944, 384, 1536), (1664, 384, 384), (8192, 384, 1152), (4096, 384, 1536),
+                                   (1000, 96, 384), (300, 384, 388)])
+@pytest.mark.parametrize('w_kn', [0, 1])
+def test_rows_gemm_stream_k(M, N, K, w_kn):
+    """Stream-K: equal contiguous ranges of (tile, k-tile) units per block, pieces of a tile in
+    consecutive slabs, unused slabs zero-filled; the planned choice and forced grids."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(13)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(K, N, device='cuda', generator=g) / K ** 0.5 if w_kn else \
+        torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    ref = x.double() @ (w.double() if w_kn else w.double().t())
+    cfg, S, sb = L.rows_gemm_plan(M, N, K, w_kn, True)
+    y = _gemm(L, x, w, w_kn, None, 0, None, cfg, S, sb)
+    assert torch.isfinite(y).all()
+    _close(y.sum(0), ref)
+    for P in (8, 64, 256, 512):
+        for cfg2 in (3, 1, 0):
+            try:
+                y = _gemm(L, x, w, w_kn, None, 0, None, cfg2, 8, P)
+            except RuntimeError:            # fewer units than blocks, or more pieces than 8 slabs
+                continue
+            assert torch.isfinite(y).all()
+            _close(y.sum(0), ref)
+            assert torch.equal(y, _gemm(L, x, w, w_kn, None, 0, None, cfg2, 8, P))
+
+
 def test_rows_gemm_plan_and_errors():
     L = _lib()
     for M, N, K in SHAPES:
         for w_kn in (0, 1):
-            cfg, s = L.rows_gemm_plan(M, N, K, w_kn, True)
-            assert 0 <= cfg < 8 and 1 <= s <= 4
-            assert L.rows_gemm_plan(M, N, K, w_kn, False)[1] == 1
+            cfg, s, sb = L.rows_gemm_plan(M, N, K, w_kn, True)
+            assert 0 <= cfg < 8 and 1 <= s <= 4 and sb % 8 == 0
+            assert L.rows_gemm_plan(M, N, K, w_kn, False)[1:] == (1, 0)
     x = torch.zeros(8, 6, device='cuda')
     with pytest.raises(RuntimeError):                              # K % 4 != 0
-        L.call('pdae_rows_gemm', x, 8, 4, 6, x.data_ptr(), x.data_ptr(), 0, None, 0, None, x.data_ptr(), -1, 1)
+        L.call('pdae_rows_gemm', x, 8, 4, 6, x.data_ptr(), x.data_ptr(), 0, None, 0, None, x.data_ptr(), -1, 1, 0)
     with pytest.raises(RuntimeError):                              # slabs with a bias
-        L.call('pdae_rows_gemm', x, 8, 4, 8, x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), 0, None, x.data_ptr(), -1, 2)
+        L.call('pdae_rows_gemm', x, 8, 4, 8, x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), 0, None, x.data_ptr(), -1, 2, 0)
     # M = 0 is a no-op
-    L.call('pdae_rows_gemm', x, 0, 4, 8, None, None, 0, None, 0, None, None, -1, 1)
+    L.call('pdae_rows_gemm', x, 0, 4, 8, None, None, 0, None, 0, None, None, -1, 1, 0)
 
 
 def _wgrad(L, M, dims, bias_flags, gen):

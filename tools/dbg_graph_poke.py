@@ -3,7 +3,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from point_dae_amd import builder
-from point_dae_amd.tuning import enable_tuned_gemms
 from point_dae_amd.config import cfg_from_yaml_file
 from point_dae_amd.data_parallel import FlatDataParallel
 from point_dae_amd.graph_step import GraphedTrainStep
@@ -11,7 +10,6 @@ from point_dae_amd.synthetic import shapenet_like_clouds
 from point_dae_amd.misc import set_random_seed
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-enable_tuned_gemms()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
 cfg.npoints = 1024

@@ -5,14 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from point_dae_amd import builder
-from point_dae_amd.tuning import enable_tuned_gemms
 from point_dae_amd.config import cfg_from_yaml_file
 from point_dae_amd.data_parallel import FlatDataParallel
 from point_dae_amd.graph_step import GraphedTrainStep
 from point_dae_amd.synthetic import shapenet_like_clouds
 from point_dae_amd.misc import set_random_seed
 
-enable_tuned_gemms()
 cfg = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
 cfg.npoints = 1024
 dev = torch.device('cuda')

@@ -7,7 +7,7 @@ import torch
 here = os.path.dirname(os.path.abspath(__file__))
 L = ctypes.CDLL(os.path.join(here, 'libpdae_lab%s.so' % os.environ.get('LABTAG', '')))
 vp, ci = ctypes.c_void_p, ctypes.c_int
-L.pdae_rows_gemm.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp]
+L.pdae_rows_gemm.argtypes = [ci, ci, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp]
 L.pdae_lab_set_stamps.argtypes = [vp]
 L.pdae_last_error.restype = ctypes.c_char_p
 
@@ -21,7 +21,7 @@ def run(M, N, K, w_kn, epi, cfg, splits):
     st = torch.zeros(8192 * 8, dtype=torch.int64, device='cuda')
     s = torch.cuda.current_stream().cuda_stream
     call = lambda: L.pdae_rows_gemm(M, N, K, x.data_ptr(), w.data_ptr(), w_kn, b.data_ptr() if b is not None else None, epi,
-                                    z.data_ptr() if z is not None else None, y.data_ptr(), cfg, splits, s)
+                                    z.data_ptr() if z is not None else None, y.data_ptr(), cfg, splits, 0, s)
     L.pdae_lab_set_stamps(None)
     for _ in range(3):
         assert call() == 0, L.pdae_last_error()

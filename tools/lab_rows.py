@@ -45,11 +45,15 @@ for M in Ms:
         fl = 2.0 * M * N * K / 1e6
         res = {}
         for cfg in range(8):
-            for sp in ((1, 2, 3, 4) if epi == 0 and K >= 1152 else (1,)):
+            for sp in ((1, 2, 3, 4) if epi == 0 and N == 384 else (1,)):
                 f = lambda: _lib.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), w_kn, _lib.ptr(b), epi,
-                                      _lib.ptr(z), y.data_ptr(), cfg, sp)
+                                      _lib.ptr(z), y.data_ptr(), cfg, sp, 0)
                 res[(cfg, sp)] = timeit(f)
-        pc, ps = _lib.rows_gemm_plan(M, N, K, w_kn, epi == 0 and K >= 1152)
+        pc, ps, psb = _lib.rows_gemm_plan(M, N, K, w_kn, epi == 0 and N == 384)
+        if psb:
+            res[(pc, ps)] = timeit(lambda: _lib.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), w_kn, None, 0,
+                                                       None, y.data_ptr(), pc, ps, psb))
+            name = name + '*'          # planned = stream-K
         lib = timeit((lambda: torch.mm(x, w)) if w_kn else (lambda: torch.mm(x, w.t())))
         best = min(res, key=res.get)
         top = sorted(res, key=res.get)[:4]
