@@ -358,6 +358,15 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
     consumer adds them up (the LayerNorm kernels do)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
+    if M * max(K, N) >= 1 << 30:             # the kernels address an operand with 32-bit byte offsets: row chunks
+        rows = ((1 << 30) // max(K, N) - 1) // 128 * 128
+        y = _empty((M, N), x)
+        for m0 in range(0, M, rows):
+            m1 = min(M, m0 + rows)
+            cfg, _, _ = _lib.rows_gemm_plan(m1 - m0, N, K, w_kn, False)
+            _lib.call('pdae_rows_gemm', x, m1 - m0, N, K, _lib.ptr(x[m0:m1]), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
+                      epi, _lib.ptr(z[m0:m1]) if z is not None else None, _lib.ptr(y[m0:m1]), cfg, 1, 0)
+        return y
     cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
     _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), epi, _lib.ptr(z),
@@ -399,15 +408,29 @@ class _Linear(torch.autograd.Function):
         return dx, dws[0], dbs[0], None
 
 
-def _rows_ok(x, w):
-    return x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0
-
-
 def _linear_rows(x, w, b, relu=False):
-    if not _rows_ok(x, w):
+    return linear_any(x, w, b, relu)
+
+
+def linear_any(x, w, b=None, relu=False):
+    """x W^T (+ b) (+ ReLU) for any K, N on the row GEMMs: they reduce in multiples of 4 and write
+    multiples of 4, so a ragged weight (K = 3 xyz columns, N = 3 output coordinates) is zero-padded
+    (the weight is small; an activation is padded only when it is narrow -- wide ones should be built
+    padded by the caller, as the set-abstraction grouping does)."""
+    if not (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32):
         y = F.linear(x, w, b)
         return F.relu(y) if relu else y
-    return _Linear.apply(x, w, b, relu)
+    N, K = w.shape
+    pk, pn = (-K) % 4, (-N) % 4
+    if pk:
+        if x.shape[1] == K:
+            x = F.pad(x, (0, pk))
+        w = F.pad(w, (0, pk))
+    if pn:
+        w = F.pad(w, (0, 0, 0, pn))
+        b = F.pad(b, (0, pn)) if b is not None else None
+    y = _Linear.apply(x, w, b, relu)
+    return y[:, :N] if pn else y
 
 
 def linear(x, lin, act=None):

@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import nn_ops
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from .pointnet2_utils import ball_query, furthest_point_sample_with_centres
 from .registry import MODELS
@@ -40,10 +41,15 @@ class _ConvBN(nn.Sequential):
         self.add_module('activation', nn.ReLU(inplace=True))
         nn.init.kaiming_normal_(self.conv.weight)
 
-    def rows(self, x):
-        """(rows, cin) -> relu(bn(conv)) (rows, cout); BatchNorm statistics over the rows."""
+    def rows(self, x, pad_at=None):
+        """(rows, cin) -> relu(bn(conv)) (rows, cout); BatchNorm statistics over the rows.
+        pad_at: x carries a zero column at that index (the 3 xyz columns padded to 4 so that the
+        row GEMM reduces over a multiple of 4); the weight gets the matching zero column."""
         bn = self.bn.bn
-        y = F.linear(x, self.conv.weight.reshape(self.conv.weight.shape[0], -1))
+        w = self.conv.weight.reshape(self.conv.weight.shape[0], -1)
+        if pad_at is not None:
+            w = torch.cat([w[:, :pad_at], w.new_zeros(w.shape[0], 1), w[:, pad_at:]], dim=1)
+        y = nn_ops.linear_any(x, w)
         if self.training:
             bn.num_batches_tracked += 1
         y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training,
@@ -79,17 +85,16 @@ class PointnetSAModule(nn.Module):
                 flat = (idx.long() + torch.arange(B, device=xyz.device).view(B, 1, 1) * N).reshape(-1)
             g = xyz.reshape(B * N, 3).index_select(0, flat).reshape(B, self.npoint, self.nsample, 3)
             g = (g - new_xyz.unsqueeze(2)).reshape(-1, 3)
-            if features is not None:
-                g = torch.cat([g, features.index_select(0, flat)], dim=1)
+            zero = g.new_zeros(g.shape[0], 1)                          # xyz | 0 | features: K a multiple of 4
+            g = torch.cat([g, zero] + ([features.index_select(0, flat)] if features is not None else []), dim=1)
             groups, per = B * self.npoint, self.nsample
         else:
             new_xyz = None
             g = xyz.reshape(B * N, 3)
-            if features is not None:
-                g = torch.cat([g, features], dim=1)
+            g = torch.cat([g, g.new_zeros(g.shape[0], 1)] + ([features] if features is not None else []), dim=1)
             groups, per = B, N
-        for layer in self.mlps[0]:
-            g = layer.rows(g)
+        for i, layer in enumerate(self.mlps[0]):
+            g = layer.rows(g, pad_at=3 if i == 0 else None)
         return new_xyz, g.reshape(groups, per, -1).max(dim=1)[0]
 
 
@@ -142,16 +147,18 @@ class Point_CAE_PointNetv2(nn.Module):
                 raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
         B = pts.shape[0]
         feature = self.pointnetv2_encoder(corrupted_pts)                       # (B, 1024)
-        coarse = self.folding1(feature).view(B, self.num_coarse, 3)
+        f1 = self.folding1
+        coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(feature, f1[0], 'relu'), f1[2], 'relu'), f1[4])
+        coarse = coarse.view(B, self.num_coarse, 3)
         # folding2[0] on [grid(2) | coarse point(3) | global feature(1024)], split by column block
         w = self.folding2[0].weight.squeeze(-1)                                # (512, 1029)
         g2 = self.grid_size ** 2
-        a = F.linear(feature, w[:, 5:], self.folding2[0].bias)                 # (B, 512)      once per cloud
-        p = F.linear(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
+        a = nn_ops.linear_any(feature, w[:, 5:].contiguous(), self.folding2[0].bias)        # (B, 512)  once per cloud
+        p = nn_ops.linear_any(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
         gd = F.linear(self.grid, w[:, :2])                                     # (16, 512)     once per grid cell
         h = F.relu(a.view(B, 1, 1, -1) + p + gd.view(1, 1, g2, -1)).reshape(B * self.num_fine, -1)
-        h = F.relu(F.linear(h, self.folding2[2].weight.squeeze(-1), self.folding2[2].bias))
-        off = F.linear(h, self.folding2[4].weight.squeeze(-1), self.folding2[4].bias)
+        h = nn_ops.linear_any(h, self.folding2[2].weight.squeeze(-1), self.folding2[2].bias, relu=True)
+        off = nn_ops.linear_any(h, self.folding2[4].weight.squeeze(-1), self.folding2[4].bias)
         fine = off.reshape(B, self.num_coarse, g2, 3) + coarse.unsqueeze(2)
         fine = fine.reshape(B, self.num_fine, 3)
         if capture is not None:

@@ -362,10 +362,10 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
         patch, extra (P, 36, e) or (36, e) per point.  -> (P*36, 3)."""
         C = tok.shape[1]
         w = stage[0].weight.squeeze(-1)
-        a = F.linear(tok, w[:, :C], stage[0].bias).unsqueeze(1)                    # (P, 1, C)
+        a = nn_ops.linear_any(tok, w[:, :C].contiguous(), stage[0].bias).unsqueeze(1)   # (P, 1, C)
         h = F.relu(a + F.linear(extra, w[:, C:C + extra_w_cols]))                  # (P, 36, C)
-        h = F.relu(F.linear(h.reshape(-1, C), stage[2].weight.squeeze(-1), stage[2].bias))
-        return F.linear(h, stage[4].weight.squeeze(-1), stage[4].bias)
+        h = nn_ops.linear_any(h.reshape(-1, C), stage[2].weight.squeeze(-1), stage[2].bias, relu=True)
+        return nn_ops.linear_any(h, stage[4].weight.squeeze(-1), stage[4].bias)
 
     def forward(self, corrupted_pts, pts, vis=False, return_feat=False, mask=None, steps=None, capture=None,
                 rows=None, **kwargs):
