@@ -19,10 +19,12 @@ because the metric is quoted "(N=1024,G=64) at 1/2/4/8 MI355X": its N=1 point
 is cfg3 and its N>1 points are cfg4 (local B=128 per GPU, weak scaling).
 `--workload cfg2` times the PointNet++ experiment instead (when built).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra
-objects: `roofline` for the dominant kernel, timed live with HIP events on the
-launch stream inside the timed region, and `cpu_baseline`, the CPU oracle
-(oracle/, "port") timed on the host cores on a bounded sample.
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+`roofline` for the dominant kernel (timed live with HIP events on the launch
+stream), `roofline_geometry` (FPS / kNN / Chamfer launch times against the HBM
+and the vector-op rooflines), `also.cfg2` (BASELINE config 2 as a second, short
+timed leg with the roofline of its large Chamfer kernel) and `cpu_baseline`, the
+CPU oracle (oracle/, "port") timed on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -41,6 +43,9 @@ CFG3 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p00
 CFG2 = 'cfgs/pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 HBM_PEAK_GBS = 8000.0
+VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
+                                  # kernels are sub / mul / add / min chains
+ROUND = 2                         # profiles/*_rNN.json this bench refers to
 
 
 def parse():
@@ -57,7 +62,111 @@ def parse():
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--cpu-steps', type=int, default=1000, help='upper bound; the sample stops after ~20 s')
     p.add_argument('--probe-steps', type=int, default=5, help='eager steps after the timed region that time the roofline kernel')
+    p.add_argument('--no-also', action='store_true', help='skip the geometry-kernel rooflines and the cfg2 leg')
+    p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 leg')
     return p.parse_args()
+
+
+def _event_time_us(fn, iters=20, warm=3):
+    """Average launch duration with HIP events on the launch stream (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def geometry_rooflines(args, clouds):
+    """FPS / kNN+group / Chamfer forward+backward at the workload's shapes: average launch time (HIP
+    events on the launch stream, back-to-back launches) against BOTH rooflines north_star names --
+    algorithmic bytes over the 8 TB/s HBM peak, and pair operations (9 per point pair:
+    3 sub, 3 mul, 2 add, 1 min/compare) over the 78.6 T op/s non-FMA fp32 vector peak.  These kernels
+    move 26 MB per step in total; they are latency / VALU bound by construction (63 dependent FPS
+    iterations), which is what the two fractions show."""
+    from point_dae_amd import _lib
+    B, N, G, k = args.batch, args.npoints, args.num_group, 32
+    x = clouds[:B].contiguous()
+    dev = x.device
+    idx = torch.empty(B, G, dtype=torch.int32, device=dev)
+    ctr = torch.empty(B, G, 3, device=dev)
+    nn_idx = torch.empty(B, G, k, dtype=torch.int64, device=dev)
+    dist_ = torch.empty(B, G, k, device=dev)
+    nbr = torch.empty(B, G, k, 3, device=dev)
+    out = []
+
+    def row(name, us, nbytes, pairs):
+        out.append({'kernel': name, 'avg_us': us, 'algorithmic_bytes': nbytes,
+                    'hbm_frac': nbytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                    'pair_ops': pairs * 9, 'valu_frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12)})
+    us = _event_time_us(lambda: _lib.call('pdae_furthest_point_sampling', x, B, N, G, _lib.ptr(x), _lib.ptr(idx), _lib.ptr(ctr)))
+    row('fps_kernel (B=%d, %d->%d, + centre gather)' % (B, N, G), us, B * (12 * N + 4 * G + 12 * G), B * (G - 1) * N)
+    us = _event_time_us(lambda: _lib.call('pdae_knn', x, B, N, G, k, _lib.ptr(x), _lib.ptr(ctr), _lib.ptr(nn_idx),
+                                          _lib.ptr(dist_), _lib.ptr(nbr)))
+    row('knn_kernel (B=%d, %dx%d -> %d, idx + dist + centred patches)' % (B, G, N, k), us,
+        B * (12 * N + 12 * G + 8 * G * k + 4 * G * k + 12 * G * k), B * G * N)
+    P = B * int(0.65 * G)                                    # masked patches at the mean ratio
+    a = nbr.reshape(-1, k, 3)[:P].contiguous()
+    b = torch.roll(a, 1, 0).contiguous()
+    d1, d2 = torch.empty(P, k, device=dev), torch.empty(P, k, device=dev)
+    i1, i2 = torch.empty(P, k, dtype=torch.int32, device=dev), torch.empty(P, k, dtype=torch.int32, device=dev)
+    us = _event_time_us(lambda: _lib.call('pdae_chamfer_forward', a, P, k, _lib.ptr(a), k, _lib.ptr(b), _lib.ptr(d1),
+                                          _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2)))
+    row('chamfer_fwd_packed (%d patches of %dx%d)' % (P, k, k), us, P * (12 * 2 * k + 8 * 2 * k), P * 2 * k * k)
+    g1, g2 = torch.ones(P, k, device=dev), torch.ones(P, k, device=dev)
+    ga, gb = torch.empty_like(a), torch.empty_like(b)
+    us = _event_time_us(lambda: _lib.call('pdae_chamfer_backward', a, P, k, _lib.ptr(a), k, _lib.ptr(b), _lib.ptr(i1),
+                                          _lib.ptr(i2), _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(ga), _lib.ptr(gb)))
+    row('chamfer_bwd_packed (%d patches of %dx%d)' % (P, k, k), us, P * (12 * 2 * k + 4 * 2 * k + 4 * 2 * k + 12 * 2 * k), P * 2 * k)
+    return out
+
+
+def cfg2_leg(args, device, rank):
+    """BASELINE config 2 (Point_CAE_PointNetv2, B=128, N=1024: FPS, ball query, grouping, the 1024^2 and
+    16384x1024 Chamfer losses) as a second, shorter timed leg of the same run -> {value, ms_per_step,
+    roofline of chamfer_fwd_tiled on the 16384x1024 fine loss (pair rate vs the vector peak)}."""
+    from point_dae_amd import _lib, builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedStaticStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG2))
+    model = FlatDataParallel(builder.model_builder(config.model).to(device), broadcast=False, process_group=None)
+    model.world_size = 1                         # a local leg on rank 0: no collective
+    optimizer, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+    B, N = 128, 1024
+    x = torch.from_numpy(shapenet_like_clouds(2 * B, N, seed=300 + rank)).to(device)
+    gstep = GraphedStaticStep(model, optimizer, lambda a, b: a + float(config.normal_weight) * b * 0.5, B, N)
+    for i in range(4):
+        gstep(x[:B], x[B:])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.also_steps):
+        gstep(x[:B], x[B:])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the one large geometry kernel of this config: Chamfer of the 16384-point fine cloud against the 1024-point input
+    fine, gt = torch.randn(B, 16384, 3, device=device), x[:B].contiguous()
+    d1, d2 = torch.empty(B, 16384, device=device), torch.empty(B, N, device=device)
+    i1 = torch.empty(B, 16384, dtype=torch.int32, device=device)
+    i2 = torch.empty(B, N, dtype=torch.int32, device=device)
+    us = _event_time_us(lambda: _lib.call('pdae_chamfer_forward', fine, B, 16384, _lib.ptr(fine), N, _lib.ptr(gt),
+                                          _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2)), iters=5, warm=2)
+    pairs = B * 2 * 16384 * N
+    del model, optimizer, gstep
+    return {'workload': 'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2), '
+                        'B=128, N=1024, full train step, hipGraph replay',
+            'value': B * args.also_steps / dt, 'unit': 'clouds/s', 'ms_per_step': dt / args.also_steps * 1e3,
+            'steps': args.also_steps,
+            'roofline': {'kernel': 'chamfer_fwd_tiled (128 x 16384 x 1024)', 'bound': 'valu', 'avg_us': us,
+                         'achieved': pairs * 9 / (us * 1e-6) / 1e12, 'peak': VALU_F32_PEAK_TOPS, 'unit': 'T op/s',
+                         'frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),
+                         'hbm_frac': B * (12 * (16384 + N) + 8 * (16384 + N)) / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)}}
 
 
 def cpu_baseline(config, args):
@@ -242,8 +351,10 @@ def main():
         # kernel inside the graph replays for comparison.
         nn_ops.set_probe(probe)
         model.require_sync = False            # rank-0-only steps: no collective (the other ranks are not in them)
-        for i in range(args.probe_steps):
-            train_step(model, optimizer, config, batches[i % pool], batches[i % pool])
+        for i in range(args.probe_steps):       # forward + backward only: the replicas' parameters stay in step
+            lx, ln = model(batches[i % pool], batches[i % pool])
+            (lx + float(config.normal_weight) * ln.sum()).backward()
+            model.zero_grad()
         model.require_sync = True
         torch.cuda.synchronize()
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
@@ -260,14 +371,18 @@ def main():
         roof = None
         if kern:
             ach = kern['flops'] / (kern['avg_ms'] * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'pmc_r01.json')   # same kernel, same shape (B=128, G=64)
-            if os.path.exists(pmc):            # bytes per launch from the committed rocprofv3 --pmc passes
-                rec = json.load(open(pmc)).get('gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>')
-                if rec and args.batch == 128 and args.num_group == 64:
-                    traffic = rec['hbm_bytes_per_launch']
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot
+            # be collected inside this run); the newest committed profile of the same kernel and shape, or null
+            traffic, traffic_src = None, None
+            for rnd in range(ROUND, 0, -1):
+                pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % rnd)
+                if os.path.exists(pmc) and args.batch == 128 and args.num_group == 64 and args.npoints == 1024:
+                    rec = json.load(open(pmc)).get('gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>')
+                    if rec:
+                        traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/pmc_r%02d.json (rocprofv3 --pmc, not this run)' % rnd
+                        break
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'kernel': kern['name'],
+                    'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kern['name'],
                     'avg_us': kern['avg_ms'] * 1e3, 'launches': kern['launches'],
                     'flops_per_launch': kern['flops'], 'timing': probe_mode,
                     'peak_note': 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
@@ -288,6 +403,11 @@ def main():
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
+        if args.workload == 'cfg3' and not args.no_also:
+            line['roofline_geometry'] = geometry_rooflines(args, clouds)
+            if world == 1:
+                del step
+                line['also'] = {'cfg2': cfg2_leg(args, device, rank)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
         print(json.dumps(line), flush=True)

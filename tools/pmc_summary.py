@@ -16,6 +16,17 @@ NAMES = {
     r'gemm_nt_kernel<256, 256, 1, 5>': 'gemm_nt_kernel<256,256,BNRELU,STORE_GROUPMAX>',
     r'gemm_tn_kernel<128, 128, 1>': 'gemm_tn_kernel<BNRELU>',
     r'gemm_tn_kernel<128, 128, 0>': 'gemm_tn_kernel<NONE>',
+    r'rows_gemm_kernel<1, 1, 2, 2, false, 0>': 'rows_gemm_kernel<64x64,NT,STORE>',
+    r'rows_gemm_kernel<1, 1, 2, 2, true, 0>': 'rows_gemm_kernel<64x64,KN,STORE>',
+    r'rows_gemm_kernel<1, 1, 2, 2, false, 2>': 'rows_gemm_kernel<64x64,NT,GELU>',
+    r'rows_gemm_kernel<1, 1, 2, 2, true, 3>': 'rows_gemm_kernel<64x64,KN,MUL>',
+    r'rows::wgrad_kernel': 'wgrad_kernel',
+    r'rows::wgrad_reduce_kernel': 'wgrad_reduce_kernel',
+    r'fps_kernel': 'fps_kernel',
+    r'knn_kernel': 'knn_kernel',
+    r'chamfer_fwd_packed': 'chamfer_fwd_packed',
+    r'chamfer_bwd_packed': 'chamfer_bwd_packed',
+    r'add_layernorm_fwd_kernel': 'add_layernorm_fwd_kernel',
     r'attention_fwd_kernel': 'attention_fwd_kernel',
     r'attention_bwd_kernel': 'attention_bwd_kernel',
     r'layernorm_bwd_kernel': 'layernorm_bwd_kernel',

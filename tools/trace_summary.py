@@ -22,7 +22,7 @@ def short(n):
     if n.startswith('Cijk_'):
         m = re.search(r'(Cijk_[A-Za-z]+_[A-Za-z]+)_.*?(MT\d+x\d+x\d+)', n)
         return 'library GEMM ' + (m.group(1) + ' ' + m.group(2) if m else '')
-    if 'pdae::gemm' in n or 'pdae::layernorm_bwd' in n or 'pdae::colsum2' in n or 'pdae::fps' in n or 'pdae::knn' in n:
+    if 'pdae::gemm' in n or 'pdae::rows::' in n or 'pdae::layernorm_bwd' in n or 'pdae::colsum2' in n or 'pdae::fps' in n or 'pdae::knn' in n:
         return re.sub(r'\(.*', '', n).replace('void ', '')
     return re.sub(r'[<(].*', '', n).replace('void ', '')[:80]
 
@@ -35,7 +35,7 @@ for n, s, e in sel:
 tot = sum(v[1] for v in agg.values())
 lib = sum(v[1] for k, v in agg.items() if k.startswith('library GEMM'))
 mine = sum(v[1] for k, v in agg.items() if k.startswith('pdae::'))
-print('# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline   (timed region: the last %d steps, hipGraph replays)' % steps)
+print('# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-also --probe-steps 0   (timed region: the last %d steps, hipGraph replays)' % steps)
 print('# wall %.3f ms/step, GPU busy %.3f ms/step, %.1f kernels/step' % (span / steps, tot / 1e6 / steps, sum(v[0] for v in agg.values()) / steps))
 print('# library GEMMs %.3f ms/step, hand-written pdae:: kernels %.3f ms/step, other (torch) %.3f ms/step'
       % (lib / 1e6 / steps, mine / 1e6 / steps, (tot - lib - mine) / 1e6 / steps))
