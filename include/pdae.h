@@ -111,6 +111,29 @@ int pdae_knn(int b, int n, int g, int k, const float* ref, const float* query,
              pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Feature propagation (PointNet++ FP modules; segmentation / Point-M2AE heads).
+ * Replaces three_nn_kernel_wrapper / three_interpolate_kernel_wrapper /
+ *   three_interpolate_grad_kernel_wrapper, extensions/pointnet2/_ext_src/src/
+ *   interpolate_gpu.cu:12-146 (Python: pointnet2_utils.py:118-204).
+ * three_nn: unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances to
+ *   the three nearest known points, ascending, idx (b,n,3) i32; strict `<`
+ *   insertion as the reference (ties keep the earlier index; fewer than three
+ *   known points leave +inf / index 0).  The Python wrapper returns sqrt(dist2).
+ * three_interpolate: points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) =
+ *   sum_k points[b,c,idx[b,n,k]] * weight[b,n,k].
+ * three_interpolate_grad: grad_out (b,c,n) -> grad_points (b,c,m), fully written
+ *   (the reference zero-fills and scatters with global atomics).
+ */
+int pdae_three_nn(int b, int n, int m, const float* unknown, const float* known,
+                  float* dist2, int32_t* idx, pdae_stream_t stream);
+int pdae_three_interpolate(int b, int c, int m, int n, const float* points,
+                           const int32_t* idx, const float* weight, float* out,
+                           pdae_stream_t stream);
+int pdae_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                const int32_t* idx, const float* weight,
+                                float* grad_points, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * In-forward patch corruption.  Fuses, for PointCAE_transformer.forward
  * (models/PointCAE_transformer.py:680-684):
  *     neighborhood += center; (t_nb, t_c) = corrupt_data(neighborhood, center);
@@ -127,6 +150,20 @@ int pdae_knn(int b, int n, int g, int k, const float* ref, const float* query,
 int pdae_patch_affine(int b, int g, int k, int nsteps, const float* nbr,
                       const float* center, const float* steps, float* gt_nbr,
                       float* t_nbr, float* t_center, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Loader-side corruption on the device.  Replaces corrupt_dropout_local
+ *   datasets/corrupt_util.py:590-612, which the reference runs per item in its
+ *   DataLoader workers (ShapeNet55Dataset.__getitem__ :90-119).
+ * xyz (b,p,3) f32; for cloud i, nclusters[i] <= 8 clusters c = 0..: the seed is
+ * the seed_rank[i*8+c]-th surviving point in index order, the sizes[i*8+c]
+ * survivors nearest to it (squared distance, ties by lower index) are dropped.
+ * alive (b,p) u8 receives 1 for survivors.  The draws are inputs: the host side
+ * draws them with the reference's distributions.  p <= 16384.
+ */
+int pdae_dropout_local(int b, int p, const float* xyz, const int32_t* nclusters,
+                       const int32_t* seed_rank, const int32_t* sizes,
+                       unsigned char* alive, pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Chamfer distance.  Replaces chamfer_cuda_forward(xyz1, xyz2)

@@ -101,6 +101,50 @@ def gather_operation_grad(grad_out, idx, N):
     return g
 
 
+def dropout_local(xyz, nclusters, seed_rank, sizes):
+    """xyz (B,P,3); nclusters (B,), seed_rank / sizes (B,8) i32 -> alive (B,P) u8."""
+    xyz = _f32(xyz)
+    B, P, _ = xyz.shape
+    nclusters, seed_rank, sizes = _i32(nclusters), _i32(seed_rank), _i32(sizes)
+    alive = np.zeros((B, P), np.uint8)
+    _check(lib().oracle_dropout_local(B, P, _p(xyz, _f32p), _p(nclusters, _i32p), _p(seed_rank, _i32p),
+                                      _p(sizes, _i32p), alive.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+           "dropout_local")
+    return alive
+
+
+def three_nn(unknown, known):
+    """unknown (B,n,3), known (B,m,3) -> (dist2 (B,n,3) SQUARED, idx (B,n,3) i32)."""
+    unknown, known = _f32(unknown), _f32(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.zeros((B, n, 3), np.float32)
+    idx = np.zeros((B, n, 3), np.int32)
+    _check(lib().oracle_three_nn(B, n, m, _p(unknown, _f32p), _p(known, _f32p), _p(d2, _f32p), _p(idx, _i32p)),
+           "three_nn")
+    return d2, idx
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,c,m), idx (B,n,3) i32, weight (B,n,3) -> (B,c,n)."""
+    points, idx, weight = _f32(points), _i32(idx), _f32(weight)
+    B, c, m = points.shape
+    n = idx.shape[1]
+    out = np.zeros((B, c, n), np.float32)
+    _check(lib().oracle_three_interpolate(B, c, m, n, _p(points, _f32p), _p(idx, _i32p), _p(weight, _f32p),
+                                          _p(out, _f32p)), "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, idx, weight = _f32(grad_out), _i32(idx), _f32(weight)
+    B, c, n = grad_out.shape
+    g = np.zeros((B, c, int(m)), np.float32)
+    _check(lib().oracle_three_interpolate_grad(B, c, n, int(m), _p(grad_out, _f32p), _p(idx, _i32p),
+                                               _p(weight, _f32p), _p(g, _f32p)), "three_interpolate_grad")
+    return g
+
+
 def ball_query(radius, nsample, xyz, new_xyz):
     """xyz (B,N,3), new_xyz (B,m,3) -> (B,m,nsample) i32."""
     xyz, new_xyz = _f32(xyz), _f32(new_xyz)

@@ -161,6 +161,109 @@ int oracle_gather_points_grad(int b, int c, int n, int npoints,
   return 0;
 }
 
+/* -------------------------------------------------------- dropout_local --
+ * datasets/corrupt_util.py:590-612 with the random draws as inputs: per cluster
+ * the seed is the rank-th surviving point in index order (the reference takes
+ * the first point of a fresh shuffle), then the K survivors nearest to it are
+ * cut off (the reference argsorts all distances descending and truncates);
+ * ties by lower index.                                                        */
+int oracle_dropout_local(int b, int p, const float* xyz_all, const int32_t* nclusters,
+                         const int32_t* seed_rank, const int32_t* sizes, unsigned char* alive_all) {
+  if (b < 0 || p < 0) return -1;
+  float* d = (float*)malloc(sizeof(float) * (size_t)(p > 0 ? p : 1));
+  for (int bi = 0; bi < b; ++bi) {
+    const float* xyz = xyz_all + (size_t)bi * p * 3;
+    unsigned char* alive = alive_all + (size_t)bi * p;
+    memset(alive, 1, (size_t)p);
+    const int nc = nclusters[bi] < 8 ? nclusters[bi] : 8;
+    for (int c = 0; c < nc; ++c) {
+      int K = sizes[bi * 8 + c], r = seed_rank[bi * 8 + c], s = -1;
+      for (int k = 0; k < p && s < 0; ++k)
+        if (alive[k] && r-- == 0) s = k;
+      if (s < 0) { free(d); return -2; }
+      for (int k = 0; k < p; ++k) {
+        const float dx = xyz[k * 3] - xyz[s * 3], dy = xyz[k * 3 + 1] - xyz[s * 3 + 1],
+                    dz = xyz[k * 3 + 2] - xyz[s * 3 + 2];
+        d[k] = dx * dx + dy * dy + dz * dz;
+      }
+      for (; K > 0; --K) {                         /* K times: drop the nearest survivor, lowest index first */
+        int best = -1;
+        for (int k = 0; k < p; ++k)
+          if (alive[k] && (best < 0 || d[k] < d[best])) best = k;
+        if (best < 0) break;
+        alive[best] = 0;
+      }
+    }
+  }
+  free(d);
+  return 0;
+}
+
+/* ------------------------------------------------- three_nn / interpolate --
+ * interpolate_gpu.cu:12-62 (three_nn: double running bests initialised to 1e40,
+ * float distance compared with strict <), :66-97 (interpolate), :107-137 (grad:
+ * atomicAdd scatter; here in ascending j)                                     */
+int oracle_three_nn(int b, int n, int m, const float* unknown_all, const float* known_all,
+                    float* dist2_all, int32_t* idx_all) {
+  if (b < 0 || n < 0 || m < 0) return -1;
+  PARALLEL_CLOUDS
+  for (int bi = 0; bi < b; ++bi) {
+    const float* unknown = unknown_all + (size_t)bi * n * 3;
+    const float* known = known_all + (size_t)bi * m * 3;
+    for (int j = 0; j < n; ++j) {
+      const float ux = unknown[j * 3 + 0], uy = unknown[j * 3 + 1], uz = unknown[j * 3 + 2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
+        const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        if (d < best1) {
+          best3 = best2; besti3 = besti2; best2 = best1; besti2 = besti1; best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2; best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+      float* d2 = dist2_all + ((size_t)bi * n + j) * 3;
+      int32_t* id = idx_all + ((size_t)bi * n + j) * 3;
+      d2[0] = (float)best1; d2[1] = (float)best2; d2[2] = (float)best3;
+      id[0] = besti1; id[1] = besti2; id[2] = besti3;
+    }
+  }
+  return 0;
+}
+
+int oracle_three_interpolate(int b, int c, int m, int n, const float* points, const int32_t* idx,
+                             const float* weight, float* out) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float* w = weight + ((size_t)bi * n + j) * 3;
+        const int32_t* id = idx + ((size_t)bi * n + j) * 3;
+        const float* row = points + ((size_t)bi * c + l) * m;
+        out[((size_t)bi * c + l) * n + j] = row[id[0]] * w[0] + row[id[1]] * w[1] + row[id[2]] * w[2];
+      }
+  return 0;
+}
+
+int oracle_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out, const int32_t* idx,
+                                  const float* weight, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * m);
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < n; ++j) {
+        const float* w = weight + ((size_t)bi * n + j) * 3;
+        const int32_t* id = idx + ((size_t)bi * n + j) * 3;
+        float* row = grad_points + ((size_t)bi * c + l) * m;
+        const float v = grad_out[((size_t)bi * c + l) * n + j];
+        row[id[0]] += v * w[0];
+        row[id[1]] += v * w[1];
+        row[id[2]] += v * w[2];
+      }
+  return 0;
+}
+
 /* ----------------------------------------------------------- ball query --
  * ball_query_gpu.cu:12-47; idx zero-init ball_query.cpp:22-24               */
 int oracle_ball_query(int b, int n, int m, float radius, int nsample,

@@ -24,6 +24,10 @@ _SIGNATURES = {
     "pdae_ball_query": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "pdae_group_points": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_dropout_local": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_three_interpolate_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_knn": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_patch_affine": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],

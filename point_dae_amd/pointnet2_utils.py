@@ -77,6 +77,63 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
+class ThreeNN(Function):
+    """pointnet2_utils.py:118-147: unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) = sqrt of the
+    squared distances, idx (B,n,3) i32), no grad."""
+
+    @staticmethod
+    def forward(ctx, unknown, known):
+        _lib.require(unknown, "unknown", torch.float32, 3)
+        _lib.require(known, "known", torch.float32, 3)
+        B, n, _ = unknown.shape
+        m = known.shape[1]
+        dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+        _lib.call("pdae_three_nn", unknown, B, n, m, _lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2),
+                  _lib.ptr(idx))
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """pointnet2_utils.py:150-204: features (B,c,m), idx (B,n,3) i32, weight (B,n,3) -> (B,c,n);
+    grad -> features."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        _lib.require(features, "features", torch.float32, 3)
+        _lib.require(idx, "idx", torch.int32, 3)
+        _lib.require(weight, "weight", torch.float32, 3)
+        B, c, m = features.shape
+        n = idx.shape[1]
+        out = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+        _lib.call("pdae_three_interpolate", features, B, c, m, n, _lib.ptr(features), _lib.ptr(idx),
+                  _lib.ptr(weight), _lib.ptr(out))
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        B, c, n = grad_out.shape
+        grad = torch.empty((B, c, ctx.m), dtype=torch.float32, device=grad_out.device)
+        _lib.call("pdae_three_interpolate_grad", grad_out, B, c, n, ctx.m, _lib.ptr(grad_out), _lib.ptr(idx),
+                  _lib.ptr(weight), _lib.ptr(grad))
+        return grad, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
 class BallQuery(Function):
     """pointnet2_utils.py:258-289: (radius, nsample, xyz (B,N,3), new_xyz (B,m,3))
     -> idx (B,m,nsample) i32, no grad."""

@@ -59,9 +59,9 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     # ONE created stream (graph_step.use_created_stream explains why).
     from .graph_step import use_created_stream
     use_created_stream(device)
-    ds_cfg = dict(config.dataset.train.others)
-    ds_cfg.update(NAME=config.dataset.train._base_.NAME, seed=args.seed + rank, device=device,
-                  steps_per_epoch=getattr(args, 'steps_per_epoch', 50))
+    ds_cfg = dict(config.dataset.train._base_)          # NAME, N_POINTS, PC_PATH, DATA_PATH (reference schema)
+    ds_cfg.update(dict(config.dataset.train.others))
+    ds_cfg.update(seed=args.seed + rank, device=device, steps_per_epoch=getattr(args, 'steps_per_epoch', 50))
     ds_cfg.setdefault('bs', config.total_bs // world)
     train_loader = DATASETS.build(ds_cfg)
 

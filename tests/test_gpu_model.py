@@ -167,9 +167,13 @@ def test_pointnetv2_product_model_reproduces_reference_fixture():
         assert abs(got.item() - want) <= 1e-5 * abs(want), (key, got.item(), want)
     _close(cap['feature'], fx['feature'], 1e-4, 'feature')
     _close(cap['coarse'], fx['coarse'], 1e-4, 'coarse')
-    # (B = 2 through six training-mode BatchNorms: the gradients are differences of nearly equal sums, and
-    #  the library GEMMs of round 1 already sat at 2e-3 of the reference's; the stream-K reduction order at 4e-3)
-    check_grads(model, fx, 5e-3, 'pointnetv2')
+    # The set-abstraction max-pools sit on exact ties (ball-query padding repeats points), so the gradient is
+    # discontinuous there: jittering the LIBRARY GEMM outputs of the encoder by one ulp moves
+    # sa2.layer0.bn.bias by 6.5e-3 of its scale and sa2.layer0.conv.weight by 3.8e-3, the same figures a
+    # different (equally exact) summation order produces (tools/dbg_cfg1_noise.py, modes `noise` / `fwdmine`;
+    # every row GEMM of this step is within 2e-6 of fp64 on its own operands, tools/dbg_cfg1_ops.py).  1e-2
+    # admits one such tie flip; the loss (1e-5) and the activations (1e-4) above are unaffected by it.
+    check_grads(model, fx, 1e-2, 'pointnetv2')
     for bname, b in model.named_buffers():
         if b.dtype.is_floating_point and 'buf/' + bname in fx:
             _close(b, fx['buf/' + bname], 1e-4, bname)

@@ -458,3 +458,33 @@ def test_op_golden_vectors():
             np.testing.assert_allclose(g, w, rtol=1e-4, atol=1e-5, err_msg=k)   # atomic scatter order
         else:
             np.testing.assert_array_equal(g, w, err_msg=k)
+
+
+@pytest.mark.parametrize('B,n,m,c', [(4, 1024, 256, 64), (2, 2048, 128, 256), (3, 77, 5, 3), (1, 300, 2, 8),
+                                     (2, 513, 3000, 16)])
+def test_three_nn_interpolate_match_oracle(oracle_ops, B, n, m, c):
+    """three_nn distances + indices and three_interpolate bit-exact against the oracle (same
+    comparison sequence, same left-to-right rounded sum); the gradient within fp32 reassociation."""
+    import torch
+    from point_dae_amd import pointnet2_utils as P
+    rng = np.random.default_rng(B * 1000 + n)
+    unknown = rng.uniform(-1, 1, (B, n, 3)).astype(np.float32)
+    known = rng.uniform(-1, 1, (B, m, 3)).astype(np.float32)
+    if m > 8:
+        known[0, 7] = known[0, 3]
+    dist, idx = P.three_nn(torch.from_numpy(unknown).cuda(), torch.from_numpy(known).cuda())
+    d2, widx = oracle_ops.three_nn(unknown, known)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    if m < 3:
+        return
+    pts = rng.normal(size=(B, c, m)).astype(np.float32)
+    w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    f = torch.from_numpy(pts).cuda().requires_grad_(True)
+    out = P.three_interpolate(f, idx, torch.from_numpy(w).cuda())
+    assert np.array_equal(out.detach().cpu().numpy(), oracle_ops.three_interpolate(pts, widx, w))
+    g = rng.normal(size=(B, c, n)).astype(np.float32)
+    out.backward(torch.from_numpy(g).cuda())
+    want = oracle_ops.three_interpolate_grad(g, widx, w, m)
+    assert np.abs(f.grad.cpu().numpy() - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)

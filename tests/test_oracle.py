@@ -279,3 +279,32 @@ def test_oracle_reproduces_committed_op_vectors(oracle_ops):
         np.testing.assert_array_equal(np.asarray(got[k]), want[k], err_msg=k)
     assert abs(float(want['emd_two_point_cost']) - 0.355) < 1e-4     # extensions/emd/test_emd_loss.py
     assert (want['ball_512_32_idx'][0, 0] == 0).all()                  # empty ball: all slots stay 0 (ball_query_gpu.cu)
+
+
+def test_three_nn_and_interpolate_against_definitions(oracle_ops):
+    """three_nn: the three smallest squared distances, ascending, earliest index on ties; interpolate:
+    the weighted sum of the three gathered features; its gradient: the adjoint scatter."""
+    rng = np.random.default_rng(5)
+    B, n, m, c = 3, 70, 41, 6
+    unknown = rng.uniform(-1, 1, (B, n, 3)).astype(np.float32)
+    known = rng.uniform(-1, 1, (B, m, 3)).astype(np.float32)
+    known[0, 7] = known[0, 3]                                  # a duplicated known point: tie
+    d2, idx = oracle_ops.three_nn(unknown, known)
+    diff = unknown[:, :, None, :] - known[:, None, :, :]
+    full = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    order = np.argsort(full, axis=2, kind='stable')[:, :, :3]
+    assert np.array_equal(idx, order.astype(np.int32))
+    assert np.array_equal(d2, np.take_along_axis(full, order, 2))
+    pts = rng.normal(size=(B, c, m)).astype(np.float32)
+    w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
+    out = oracle_ops.three_interpolate(pts, idx, w)
+    want = sum(np.take_along_axis(pts, np.broadcast_to(idx[:, None, :, k], (B, c, n)), 2).astype(np.float64) *
+               w[:, None, :, k] for k in range(3))
+    assert np.allclose(out, want, rtol=1e-6, atol=1e-6)
+    g = rng.normal(size=(B, c, n)).astype(np.float32)
+    gp = oracle_ops.three_interpolate_grad(g, idx, w, m)
+    # adjoint identity: <out(pts), g> == <pts, grad(g)>
+    assert abs((out.astype(np.float64) * g).sum() - (pts.astype(np.float64) * gp).sum()) < 1e-3
+    # fewer than three known points: +inf and index 0 in the unused slots
+    d2s, idxs = oracle_ops.three_nn(unknown[:, :5], known[:, :2])
+    assert np.isinf(d2s[..., 2]).all() and (idxs[..., 2] == 0).all()
