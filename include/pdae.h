@@ -268,6 +268,12 @@ int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn
                    const float* bias /*nullable*/, int epi, float* Z /*epi 2,3*/,
                    float* Y, int cfg, int splits, int stream_blocks,
                    pdae_stream_t stream);
+/* Batched Y_b[M,N] = X_b[M,K] . W_b[N,K]^T, b < batch, element strides between the
+ * problems (W_b = X_b: the Gram matrices behind DGCNN's feature-space kNN,
+ * models/dgcnn_util.py:7-12).                                                  */
+int pdae_rows_gemm_batched(int batch, int M, int N, int K, const float* X,
+                           long long strideX, const float* W, long long strideW,
+                           float* Y, long long strideY, pdae_stream_t stream);
 int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg,
                         int* splits, int* stream_blocks);
 int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks,

@@ -540,3 +540,68 @@ class Point_CAE_PointNetv2(nn.Module):
         if capture is not None:
             capture.update(feature=feature, coarse=coarse, fine=fine)
         return self.loss_func(coarse, pts), self.loss_func(fine, pts)
+
+
+# ----------------------------------------------------------------------------------------------
+# Point_CAE_DGCNN_FCOnly (models/PointCAE_DGCNN.py:145-231, encoder models/dgcnn_util.py:7-34,87-136):
+# four EdgeConv layers on a k = 20 graph rebuilt in FEATURE space before every layer, concat,
+# conv5, global max -> 1024-d feature; three Linear layers -> 1024 coarse points; Chamfer loss.
+
+def dgcnn_knn(x, k):
+    """x (B,C,N) -> idx (B,N,k): the k largest of -|xi|^2 + 2 xi.xj - |xj|^2 (dgcnn_util.py:7-12)."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    return (-xx - inner - xx.transpose(2, 1)).topk(k=k, dim=-1)[1]
+
+
+def dgcnn_graph_feature(x, k=20):
+    """(B,C,N) -> (B,2C,N,k) = [x_j - x_i, x_i] over the k neighbours j of i (dgcnn_util.py:15-34)."""
+    B, C, N = x.shape
+    idx = (dgcnn_knn(x, k) + torch.arange(B, device=x.device).view(-1, 1, 1) * N).view(-1)
+    xt = x.transpose(2, 1).contiguous()
+    f = xt.view(B * N, C)[idx].view(B, N, k, C)
+    c = xt.view(B, N, 1, C).repeat(1, 1, k, 1)
+    return torch.cat((f - c, c), dim=3).permute(0, 3, 1, 2)
+
+
+class dgcnn_encoder(nn.Module):
+    def __init__(self, channel=3):
+        super().__init__()
+        self.bn1, self.bn2 = nn.BatchNorm2d(64), nn.BatchNorm2d(64)
+        self.bn3, self.bn4, self.bn5 = nn.BatchNorm2d(128), nn.BatchNorm2d(256), nn.BatchNorm1d(1024)
+        act = lambda: nn.LeakyReLU(negative_slope=0.2)
+        self.conv1 = nn.Sequential(nn.Conv2d(channel * 2, 64, kernel_size=1, bias=False), self.bn1, act())
+        self.conv2 = nn.Sequential(nn.Conv2d(64 * 2, 64, kernel_size=1, bias=False), self.bn2, act())
+        self.conv3 = nn.Sequential(nn.Conv2d(64 * 2, 128, kernel_size=1, bias=False), self.bn3, act())
+        self.conv4 = nn.Sequential(nn.Conv2d(128 * 2, 256, kernel_size=1, bias=False), self.bn4, act())
+        self.conv5 = nn.Sequential(nn.Conv1d(256 * 2, 1024, kernel_size=1, bias=False), self.bn5, act())
+
+    def forward(self, x):
+        B = x.shape[0]
+        feats = []
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
+            x = conv(dgcnn_graph_feature(x, k=20)).max(dim=-1)[0]
+            feats.append(x)
+        x = self.conv5(torch.cat(feats, dim=1))
+        return F.adaptive_max_pool1d(x, 1).view(B, -1)
+
+
+class Point_CAE_DGCNN_FCOnly(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.corrupt_type = config.corrupt_type
+        self.num_coarse = 1024
+        self.dgcnn_encoder = dgcnn_encoder(channel=3)
+        self.recfc = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(), nn.Linear(1024, 1024), nn.ReLU(),
+                                   nn.Linear(1024, self.num_coarse * 3))
+        self.loss_func = chamfer_l1 if config.loss == 'cdl1' else chamfer_l2
+
+    def forward(self, corrupted_pts, pts, vis=False, return_feat=False, **kwargs):
+        if return_feat:
+            return self.dgcnn_encoder(pts[:, :, :3].transpose(1, 2).contiguous())
+        corrupted_pts, pts = corrupted_pts[:, :, :3].contiguous(), pts[:, :, :3].contiguous()
+        feature = self.dgcnn_encoder(corrupted_pts.transpose(1, 2).contiguous())
+        coarse = self.recfc(feature).view(-1, self.num_coarse, 3)
+        loss = self.loss_func(coarse, pts)
+        return loss, torch.zeros(1)

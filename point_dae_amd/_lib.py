@@ -36,6 +36,7 @@ _SIGNATURES = {
     "pdae_linear_backward_data": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_gemm": [_i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "pdae_rows_gemm_batched": [_i, _i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp],
     "pdae_rows_wgrad": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import point_cae_pointnetv2, point_cae_transformer  # noqa: F401  (register the models)
+from . import point_cae_dgcnn, point_cae_pointnetv2, point_cae_transformer  # noqa: F401  (register the models)
 from .registry import build_model_from_cfg
 
 

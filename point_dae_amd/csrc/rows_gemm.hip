@@ -52,6 +52,7 @@ struct Args {
   long long slab;     // elements between the C slabs of consecutive splits
   int stream_blocks;  // > 0: stream-K over (tile, k-tile) units on this many blocks, `slabs` C slabs
   int slabs;
+  long long strideA, strideB, strideC;   // batched launch: element strides between the problems of blockIdx.z
 #ifdef PDAE_ROWS_STAMPS
   long long* stamps;  // diagnostic build (tools/lab): [block][8] s_memrealtime / s_memtime marks
 #endif
@@ -164,8 +165,8 @@ void rows_gemm_kernel(const Args p) {
       boff[i] = ((unsigned)min(n0 + ((tid + i * NT) >> 3), N - 1) * (unsigned)p.ldb + scol) * 4u;
     }
   }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Bb = reinterpret_cast<const char*>(p.B);
+  const char* Ab = reinterpret_cast<const char*>(p.A + (size_t)blockIdx.z * p.strideA);
+  const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)blockIdx.z * p.strideB);
   const size_t bstep = BKN ? (size_t)p.ldb * 4 : 4;        // bytes per unit of k in B
   const int KT = (kend - kbeg + BK - 1) / BK;
   // guarded loads only where the tile is not whole: a partial last k-tile (K % 32 != 0) or the
@@ -361,7 +362,7 @@ void rows_gemm_kernel(const Args p) {
   PDAE_STAMP(2)
   // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
   // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
-  float* Cs = p.C + (size_t)piece * p.slab;
+  float* Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)piece * p.slab;
   auto epilogue = [&](auto full_c, auto zero_c) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_c)::value;
     constexpr bool ZERO = decltype(zero_c)::value;     // zero-fill of an unused slab (stream mode)
@@ -404,7 +405,7 @@ void rows_gemm_kernel(const Args p) {
   if (!p.stream_blocks) break;
   if (tile_ends)
     for (int q = piece + 1; q < p.slabs; ++q) {
-      Cs = p.C + (size_t)q * p.slab;
+      Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)q * p.slab;
       if (full) epilogue(std::true_type{}, std::true_type{});
       else epilogue(std::false_type{}, std::true_type{});
     }
@@ -725,7 +726,7 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
 }
 
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
-static void launch_cfg(Args& a, int splits, int stream_blocks, hipStream_t s) {
+static void launch_cfg(Args& a, int splits, int stream_blocks, hipStream_t s, int batch = 1) {
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
@@ -740,7 +741,7 @@ static void launch_cfg(Args& a, int splits, int stream_blocks, hipStream_t s) {
   }
   const int chunk = (a.tiles + 7) / 8;
   a.stream_blocks = stream_blocks, a.slabs = splits;
-  const dim3 grid = stream_blocks ? dim3(stream_blocks, 1) : dim3(8 * chunk, splits);
+  const dim3 grid = stream_blocks ? dim3(stream_blocks, 1, batch) : dim3(8 * chunk, splits, batch);
   hipLaunchKernelGGL((rows_gemm_kernel<TI, TJ, WM, WN, BKN, EPI>), grid, dim3(WM * WN * 64), lds, s, a);
 }
 
@@ -881,4 +882,31 @@ extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const f
   hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g.tiles * 16), dim3(256), 0, s, g);
   return check_launch("rows_wgrad");
+}
+
+// Batched product Y_b[M,N] = X_b[M,K] . W_b[N,K]^T for b < batch (blockIdx.z), element strides between the
+// problems; W_b = X_b gives the Gram matrices of the DGCNN feature-space kNN (models/dgcnn_util.py:7-12).
+extern "C" int pdae_rows_gemm_batched(int batch, int M, int N, int K, const float* X, long long strideX,
+                                      const float* W, long long strideW, float* Y, long long strideY,
+                                      pdae_stream_t stream) {
+  if (batch < 0 || M < 0 || N <= 0 || K <= 0) return bad_arg("rows_gemm_batched: bad size");
+  if (K % 4 != 0) return unsupported("rows_gemm_batched: K must be a multiple of 4");
+  if (batch > 65535) return unsupported("rows_gemm_batched: more than 65535 problems");
+  if ((long long)M * (K > N ? K : N) >= (1LL << 30) || (long long)N * K >= (1LL << 30))
+    return unsupported("rows_gemm_batched: per-problem operands of 4 GB or more");
+  if (batch == 0 || M == 0) return PDAE_OK;
+  if (!X || !W || !Y) return bad_arg("rows_gemm_batched: null pointer");
+  int cfg, splits, sb;
+  plan_rows(M * (batch < 16 ? batch : 16), N, K, false, false, &cfg, &splits, &sb);   // the grid is batch x tiles
+  Args a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
+  a.slab = (long long)M * N, a.strideA = strideX, a.strideB = strideW, a.strideC = strideY;
+  hipStream_t s = as_stream(stream);
+  switch (cfg) {
+    case 0: launch_cfg<2, 2, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;
+    case 1: launch_cfg<1, 2, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;
+    case 2: launch_cfg<2, 1, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;
+    default: launch_cfg<1, 1, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;
+  }
+  return check_launch("rows_gemm_batched");
 }

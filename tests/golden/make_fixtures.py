@@ -139,9 +139,55 @@ def pointnetv2_fixture(name, B, seed):
     print(name, 'loss', l_coarse.item(), l_fine.item(), 'size %.0f KB' % (os.path.getsize(path) / 1024))
 
 
+def dgcnn_fixture(name, B, seed):
+    """Point_CAE_DGCNN_FCOnly (the published non-Transformer model), B=2, N=1024."""
+    from easydict import EasyDict
+    import yaml
+    import models.PointCAE_DGCNN as M
+    from oracle import model as OM
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    cfg = EasyDict(yaml.safe_load(open(os.path.join(R.REF, 'cfgs/pretrain_PointCAE_clean.yaml')))['model'])
+    cfg.NAME = 'Point_CAE_DGCNN_FCOnly'
+    R.seed_all(seed)
+    ref = M.Point_CAE_DGCNN_FCOnly(cfg)
+    ref.device = torch.device('cpu')
+    fill_state(ref, seed)
+    ref.train()
+    clean = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed))
+    corrupted = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=seed + 100))
+    cap = {}
+    ref.dgcnn_encoder.register_forward_hook(lambda m, i, o: cap.update(feature=o))
+    ref.recfc.register_forward_hook(lambda m, i, o: cap.update(coarse=o))
+    loss, loss2 = ref(corrupted, clean)
+    (loss + 0.5 * loss2.sum()).backward()
+    orc = fill_state(OM.Point_CAE_DGCNN_FCOnly(cfg), seed).train()
+    o1, o2 = orc(corrupted, clean)
+    assert o1.item() == loss.item(), (o1.item(), loss.item())
+    out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
+               loss=np.float32(loss.item()), feature=cap['feature'].detach().numpy(),
+               coarse=cap['coarse'].detach().numpy().reshape(B, 1024, 3))
+    for pname, p in ref.named_parameters():
+        g = p.grad
+        key = 'grad/' + pname
+        out[key + '/norm'] = np.float64(g.double().norm().item())
+        if g.numel() <= 1536:
+            out[key + '/full'] = g.numpy()
+        else:
+            out[key + '/sample'], _ = _sample(g)
+    for bname, b in ref.named_buffers():
+        if b.dtype.is_floating_point:
+            out['buf/' + bname] = b.numpy()
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(name, 'loss', loss.item(), 'size %.0f KB' % (os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
     R.setup()
     R.cpu_cuda_noop()
+    if len(sys.argv) > 1 and sys.argv[1] == 'dgcnn':
+        dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
+        sys.exit(0)
     pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
     transformer_fixture('transformer_folding_b2.npz', 2, 13, {'transformer_config.drop_path_rate': 0.0,
                         'transformer_config.depth': 4, 'transformer_config.decoder_depth': 2},

@@ -119,3 +119,19 @@ def test_oracle_pointnetv2_reproduces_reference_fixture():
     assert abs(lf.item() - float(fx['loss_fine'])) <= 1e-6 * abs(float(fx['loss_fine']))
     np.testing.assert_allclose(cap['feature'].detach().numpy(), fx['feature'], rtol=1e-4, atol=1e-5)
     check_grads(model, fx, 2e-4, 'pointnetv2')
+
+
+def test_oracle_dgcnn_reproduces_reference_fixture():
+    """Point_CAE_DGCNN_FCOnly (the published non-Transformer model; fixture from the live reference)."""
+    from oracle import model as OM
+    from point_dae_amd.config import cfg_from_yaml_file
+    fx = load_fixture('dgcnn_fconly_b2.npz')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_clean.yaml')).model
+    model = fill_state(OM.Point_CAE_DGCNN_FCOnly(cfg), int(fx['seed'])).train()
+    loss, zero = model(torch.from_numpy(fx['corrupted']), torch.from_numpy(fx['clean']))
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) <= 1e-6 * abs(float(fx['loss'])) and zero.item() == 0
+    check_grads(model, fx, 2e-4, 'dgcnn')
+    feat = model.eval()(None, torch.from_numpy(fx['clean']), return_feat=True)
+    assert feat.shape == (int(fx['B']), 1024)
