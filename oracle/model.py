@@ -308,14 +308,15 @@ class MaskTransformer(nn.Module):
 
 
 class PointCAE_transformer(nn.Module):
-    """models/PointCAE_transformer.py:616-742, 'Drop-Patch' branch with
-    all_patch 'False' or 'True'."""
+    """models/PointCAE_transformer.py:616-742: the 'Drop-Patch' branch with all_patch 'False' or
+    'True', and the branch without masking (:717-739; its NormalTransformer :473-541 is a
+    MaskTransformer that keeps every token and draws nothing)."""
 
     def __init__(self, config):
         super().__init__()
         tc = config.transformer_config
         self.trans_dim = tc.trans_dim
-        assert 'Drop-Patch' in config.corrupt_type
+        self.masked = 'Drop-Patch' in config.corrupt_type
         self.MAE_encoder = MaskTransformer(config)
         self.group_size, self.num_group = config.group_size, config.num_group
         self.corrupt_type, self.all_patch = config.corrupt_type, config.all_patch
@@ -336,6 +337,18 @@ class PointCAE_transformer(nn.Module):
         t_nb, t_c = apply_corruption(neighborhood, center, steps)
         neighborhood = neighborhood - center.unsqueeze(2)
         t_nb = t_nb - t_c.unsqueeze(2)
+        if not self.masked:                         # :717-739: every patch encoded, decoded and reconstructed
+            B, G = center.shape[:2]
+            x_vis, _ = self.MAE_encoder(t_nb, t_c, torch.zeros(B, G, dtype=torch.bool))
+            C = x_vis.shape[-1]
+            x_rec = self.MAE_decoder(x_vis, self.decoder_pos_embed(center).reshape(B, -1, C))
+            rebuild = self.increase_dim(x_rec.transpose(1, 2)).transpose(1, 2).reshape(B * G, -1, 3)
+            gt = neighborhood.reshape(B * G, -1, 3)
+            loss1 = self.loss_func(rebuild, gt)
+            if capture is not None:
+                capture.update(center=center, neighborhood=neighborhood, t_nb=t_nb, t_c=t_c, x_vis=x_vis,
+                               x_rec=x_rec, rebuild=rebuild, gt=gt)
+            return loss1, torch.zeros(1)
         x_vis, mask = self.MAE_encoder(t_nb, t_c, mask)
         B, _, C = x_vis.shape
         pos_vis = self.decoder_pos_embed(center[~mask]).reshape(B, -1, C)

@@ -151,6 +151,28 @@ def load_model(base_model, ckpt_path, logger=None):
     return sd.get('epoch', -1)
 
 
+def remap_pretrain_keys(state_dict):
+    """The key surgery the reference's downstream models apply to a pretraining checkpoint
+    (models/Point_MAE.py:643-656): strip 'module.', then 'MAE_encoder.<k>' -> '<k>' and
+    'base_model.<k>' -> '<k>' (the encoder of the auto-encoder becomes the backbone)."""
+    out = {}
+    for k, v in _strip_module(state_dict).items():
+        if k.startswith('MAE_encoder.'):
+            k = k[len('MAE_encoder.'):]
+        elif k.startswith('base_model.'):
+            k = k[len('base_model.'):]
+        out[k] = v
+    return out
+
+
+def load_pretrained_encoder(module, ckpt_path):
+    """Load a `ckpt-*.pth` of the pretraining runner into a backbone (a MaskTransformer, or any module
+    whose keys follow the remapped names) with strict=False, as load_model_from_ckpt does.
+    -> the incompatible-keys record (missing_keys, unexpected_keys)."""
+    ckpt = torch.load(ckpt_path, map_location='cpu')
+    return module.load_state_dict(remap_pretrain_keys(ckpt['base_model']), strict=False)
+
+
 def resume_model(base_model, args, logger=None):
     """builder.py:155-178: weights + epoch + best metric from ckpt-last.pth
     (the reference does not restore the optimiser state either, runner :92-93)."""

@@ -107,7 +107,9 @@ class FlatDataParallel(nn.Module):
 
     def finish(self):
         """Wait for the gradient all-reduce and turn the sum into the mean.
-        Call after backward(), before optimizer.step()."""
+        Call after backward(), before optimizer.step().  (Gradient accumulation: the micro-steps before
+        the last run with require_sync = False and only add into the flat buffer; the hooks of the last
+        backward pass then reduce buckets that hold the accumulated sums.)"""
         if self.world_size == 1:
             return
         if not self.require_sync:          # local step (no_sync): nothing was sent, nothing to wait for

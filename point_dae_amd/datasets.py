@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 from .registry import DATASETS
-from .synthetic import shapenet_like_clouds
+from .synthetic import labelled_clouds, shapenet_like_clouds
 
 AFFINE = ('translate', 'scale_nonorm', 'rotate', 'reflection', 'shear')
 _PASS = ('clean', 'dropout_patch_pointmae', 'Drop-Patch')
@@ -209,3 +209,27 @@ class ShapeNet:
             sel = order[(np.arange(self.bs) + i * self.bs) % n]
             corrupted, clean = self.batch(torch.from_numpy(sel).to(self._clouds.device))
             yield self.ids[int(sel[0])][0], i, corrupted, clean
+
+
+@DATASETS.register_module()
+class ModelNet:
+    """Labelled clouds for the SVM probe (datasets/ModelNetDataset.py of the reference yields
+    (taxonomy, model_id, (points, label))).  No ModelNet40 files ship with the image: labelled synthetic
+    clouds stand in (synthetic.labelled_clouds); `count` clouds, batches of `bs`, resident on the device."""
+
+    def __init__(self, config):
+        self.npoints = config.get('npoints', 1024)
+        self.bs = config.get('bs', 32)
+        self.count = config.get('count', 256)
+        self.subset = config.get('subset', 'test')
+        self.device = config.get('device', 'cuda')
+        seed = config.get('seed', 0) + (1000 if self.subset == 'train' else 2000)
+        x, y = labelled_clouds(self.count, self.npoints, seed=seed, classes=min(3, config.get('NUM_CATEGORY', 3)))
+        self.x, self.y = torch.from_numpy(x).to(self.device), torch.from_numpy(y).to(self.device)
+
+    def __len__(self):
+        return (self.count + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        for i in range(0, self.count, self.bs):
+            yield 'ModelNet', i, (self.x[i:i + self.bs], self.y[i:i + self.bs])

@@ -92,6 +92,8 @@ class GraphedTrainStep:
         self.normal_weight = float(config.normal_weight)
         if config.loss_type not in ('xyz', 'xyznormal'):
             raise NotImplementedError('graphed step: loss_type %s' % config.loss_type)
+        if not getattr(self.net, 'masked', True):
+            raise NotImplementedError('graphed step: the un-masked variant has one static shape; use GraphedStaticStep')
 
     def _draw(self):
         """Host RNG, in the order the eager forward consumes it: corruption

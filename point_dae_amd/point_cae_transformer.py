@@ -250,8 +250,9 @@ class PointCAE_transformer(nn.Module):
         self.config = config
         tc = config.transformer_config
         self.trans_dim = tc.trans_dim
-        if 'Drop-Patch' not in config.corrupt_type:
-            raise NotImplementedError("only the 'Drop-Patch' (masked) variant is on the hot path")
+        # without 'Drop-Patch' the reference builds a NormalTransformer (:473-541): the same modules under the
+        # same names, every token kept, no mask drawn -- here the MaskTransformer with an all-visible row list
+        self.masked = 'Drop-Patch' in config.corrupt_type
         self.MAE_encoder = MaskTransformer(config)
         self.group_size, self.num_group = config.group_size, config.num_group
         self.corrupt_type, self.all_patch = config.corrupt_type, config.all_patch
@@ -287,6 +288,10 @@ class PointCAE_transformer(nn.Module):
             steps = draw_corruption(self.corrupt_type, B)
         gt_nb, t_nb, t_c = corrupt_patches(neighborhood, center, steps)
 
+        if not self.masked and rows is None:        # (:717-739) nothing masked, nothing drawn
+            G0 = self.num_group
+            rows = (torch.arange(B * G0, device=pts.device), torch.zeros(0, dtype=torch.int64, device=pts.device))
+            mask = torch.zeros(B, G0, dtype=torch.bool)
         x_vis, mask, (vis_rows, mask_rows) = self.MAE_encoder(t_nb, t_c, mask=mask, rows=rows)
         C = x_vis.shape[-1]
         G = self.num_group
@@ -300,9 +305,12 @@ class PointCAE_transformer(nn.Module):
         ctr = center.reshape(B * G, 3)
         order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
         pos_full = nn_ops.pos_embed(ctr.index_select(0, order), self.decoder_pos_embed)
-        x_full = torch.cat([x_vis.reshape(B, Tvis, C), nn_ops.expand_token(self.mask_token, B, M)], dim=1)
+        if M:
+            x_full = torch.cat([x_vis.reshape(B, Tvis, C), nn_ops.expand_token(self.mask_token, B, M)], dim=1)
+        else:
+            x_full = x_vis
         x_full = x_full.reshape(B * G, C)
-        if self.all_patch == 'True':
+        if self.all_patch == 'True' or not self.masked:
             x_rec = self.MAE_decoder(x_full, pos_full, B, G)
             gt_rows, R = order, G
         else:

@@ -40,15 +40,23 @@ def gradual_weight_of(config, epoch):
     return 0
 
 
-def train_step(model, optimizer, config, points, gt, gradual_weight=0.):
-    """One optimisation step: the unit bench.py times."""
+def train_step(model, optimizer, config, points, gt, gradual_weight=0., update=True):
+    """One optimisation step: the unit bench.py times.  update=False: a gradient-accumulation
+    micro-step (runner_pretrain.py:188-197, `step_per_update`): backward only, gradients stay in the
+    flat buffer, no collective; the step that closes the group reduces and updates."""
+    sync = getattr(model, 'require_sync', True)
+    if isinstance(model, FlatDataParallel) and not update:
+        model.require_sync = False
     loss_xyz, loss_normal = model(points, gt)
     loss = mix_loss(config, loss_xyz, loss_normal.sum(), gradual_weight)
     loss.backward()
     if isinstance(model, FlatDataParallel):
-        model.finish()
-    optimizer.step()
-    model.zero_grad()
+        model.require_sync = sync
+        if update:
+            model.finish()
+    if update:
+        optimizer.step()
+        model.zero_grad()
     return loss_xyz.detach(), loss_normal.detach()
 
 
@@ -73,10 +81,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         builder.load_model(base_model, args.start_ckpts)
     if args.sync_bn and world > 1:
         base_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(base_model)
-    if config.get('step_per_update', 1) != 1:
-        # runner_pretrain.py:188-197 accumulates gradients over step_per_update batches; every shipped
-        # config uses 1 and the steps here apply the optimiser on every batch
-        raise NotImplementedError('step_per_update != 1')
+    spu = int(config.get('step_per_update', 1))     # gradient accumulation (runner_pretrain.py:188-197): eager steps
     model = FlatDataParallel(base_model)
     optimizer, scheduler = builder.build_opti_sche(model, config)
     model.zero_grad()
@@ -88,7 +93,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     bs = ds_cfg['bs']
     gw_dev = torch.zeros((), device=device)                 # gradual weight, read inside the captured graph
     if isinstance(base_model, PointCAE_transformer) and config.loss_type in ('xyz', 'xyznormal') \
-            and config.step_per_update == 1:
+            and config.step_per_update == 1 and base_model.masked:
         graphed = GraphedTrainStep(model, optimizer, config, bs, config.npoints)
         step_fn = lambda corrupted, clean: graphed(clean)   # noqa: E731  (corrupted input unused on this path)
     elif isinstance(base_model, Point_CAE_PointNetv2) and config.step_per_update == 1:
@@ -99,6 +104,25 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         step_fn = graphed
     else:
         step_fn = None
+    if spu != 1:
+        step_fn = None                                          # the captured steps update on every batch
+
+    # SVM-probe validation (runner_pretrain.py:263-270): labelled loaders, when the experiment has them
+    val = None
+    dcfg = config.dataset
+    if dcfg.get('extra_train') is not None and dcfg.get('val') is not None and hasattr(base_model, 'forward'):
+        import inspect
+        if 'return_feat' in inspect.signature(base_model.forward).parameters:
+            def _loader(node):
+                c = dict(node._base_)
+                c.update(dict(node.others))
+                c.update(device=device, seed=args.seed)
+                c.setdefault('bs', 32)
+                return DATASETS.build(c)
+            val = (_loader(dcfg.extra_train), _loader(dcfg.val))
+    from .svm_probe import Acc_Metric, validate
+    best_metrics, metrics = Acc_Metric(0.), Acc_Metric(0.)
+    num_iter = 0
 
     for epoch in range(start_epoch, config.max_epoch + 1):
         model.train()
@@ -111,7 +135,10 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
             if step_fn is not None:
                 lx, ln = step_fn(corrupted, clean)
             else:
-                lx, ln = train_step(model, optimizer, config, corrupted, clean, gw)
+                num_iter += 1
+                lx, ln = train_step(model, optimizer, config, corrupted, clean, gw, update=num_iter == spu)
+                if num_iter == spu:
+                    num_iter = 0
             acc += torch.stack([lx.reshape(()), ln.sum().reshape(())])
             n += 1
             if (idx + 1) % log_every == 0 or idx + 1 == len(train_loader):
@@ -126,5 +153,10 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
                         n * clean.shape[0] * world / dt, vals[0], vals[1], optimizer.param_groups[0]['lr']))
         if scheduler is not None:
             scheduler.step(epoch)
-        builder.save_checkpoint(model, optimizer, epoch, None, None, 'ckpt-last', args)
+        if val is not None and epoch % max(int(getattr(args, 'val_freq', 1)), 1) == 0:
+            metrics = validate(base_model, val[0], val[1], epoch, config, log=log)
+            if metrics.better_than(best_metrics):
+                best_metrics = metrics
+                builder.save_checkpoint(model, optimizer, epoch, metrics, best_metrics, 'ckpt-best', args)
+        builder.save_checkpoint(model, optimizer, epoch, metrics, best_metrics, 'ckpt-last', args)
     return model

@@ -49,3 +49,18 @@ def shapenet_like_clouds(B, N, seed=0, dense=8192):
         sel = rng.choice(pts.shape[0], N, replace=N > pts.shape[0])
         out[b] = pts[sel].astype(np.float32)
     return out
+
+
+def labelled_clouds(count, N, seed=0, classes=3):
+    """Labelled stand-in of ModelNet for the SVM probe: every cloud is ONE primitive family
+    (label 0 sphere, 1 box, 2 cylinder, ...) under a random anisotropic scale and pose, unit-sphere
+    normalised.  -> (clouds (count,N,3) f32, labels (count,) i64)."""
+    rng = np.random.default_rng(seed)
+    gens = (_sphere, _box, _cylinder)
+    out = np.empty((count, N, 3), np.float32)
+    labels = rng.integers(0, min(classes, len(gens)), count)
+    for b in range(count):
+        p = gens[labels[b]](rng, N) * rng.uniform(0.5, 1.0, 3) @ _rotation(rng).T
+        p = p - p.mean(0, keepdims=True)
+        out[b] = (p / np.sqrt((p ** 2).sum(1)).max()).astype(np.float32)
+    return out, labels.astype(np.int64)

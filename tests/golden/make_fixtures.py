@@ -60,6 +60,12 @@ def transformer_fixture(name, B, seed, overrides, cls='PointCAE_transformer'):
     R.seed_all(seed + 1)
     steps = C.draw_corruption(cfg.corrupt_type, B)
     mask, _ = draw_mask(B, cfg.num_group, cfg.transformer_config.mask_ratio, cfg.transformer_config.rand_ratio)
+    masked = 'Drop-Patch' in cfg.corrupt_type
+    if not masked:                                   # NormalTransformer: no mask is drawn, its output is the tokens
+        R.seed_all(seed + 1)
+        steps = C.draw_corruption(cfg.corrupt_type, B)
+        mask = torch.zeros(B, cfg.num_group, dtype=torch.bool)
+        ref.MAE_encoder.register_forward_hook(lambda m, i, o: cap.update(x_vis=o, mask=mask))
     R.seed_all(seed + 1)
     loss, loss2 = ref(pts, pts)
     (loss + 0.005 * loss2.sum()).backward()          # runner :165-166, normal_weight 0.005
@@ -79,7 +85,7 @@ def transformer_fixture(name, B, seed, overrides, cls='PointCAE_transformer'):
                x_rec=cap['x_rec'].detach().numpy(),
                overrides=np.array(repr(sorted(overrides.items()))))
     for pname, p in ref.named_parameters():
-        g = p.grad
+        g = p.grad if p.grad is not None else torch.zeros_like(p)      # (an unused parameter: mask_token without masking)
         key = 'grad/' + pname
         out[key + '/norm'] = np.float64(g.double().norm().item())
         if g.numel() <= 1536:
@@ -187,6 +193,12 @@ if __name__ == '__main__':
     R.cpu_cuda_noop()
     if len(sys.argv) > 1 and sys.argv[1] == 'dgcnn':
         dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'nomask':
+        # the branch without patch masking (corrupt_type without 'Drop-Patch': NormalTransformer)
+        transformer_fixture('transformer_nomask_b2.npz', 2, 14, {'transformer_config.drop_path_rate': 0.0,
+                            'corrupt_type': ['affine_r3'], 'transformer_config.depth': 2,
+                            'transformer_config.decoder_depth': 1})
         sys.exit(0)
     pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
     transformer_fixture('transformer_folding_b2.npz', 2, 13, {'transformer_config.drop_path_rate': 0.0,

@@ -45,6 +45,8 @@ def check_grads(model, fx, rtol, what, atol=2e-5):
     for name, p in model.named_parameters():
         key = 'grad/' + name
         ref_norm = float(fx[key + '/norm'])
+        if p.grad is None:                      # an unused parameter: the reference leaves it without a gradient too
+            p.grad = torch.zeros_like(p)
         got_norm = p.grad.double().norm().item()
         assert abs(got_norm - ref_norm) <= rtol * ref_norm + atol, (what, name, got_norm, ref_norm)
         if key + '/full' in fx:

