@@ -27,6 +27,7 @@
 #ifndef PDAE_H
 #define PDAE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,6 +47,20 @@ enum pdae_status {
 const char* pdae_version(void);
 /* Text for the last failing status on this thread (hipGetErrorString or arg). */
 const char* pdae_last_error(void);
+
+/* Deterministic mode.  The reference's reductions (cuDNN batch-norm statistics, cuBLAS split-K
+ * weight gradients, ATen layer_norm backward: models/PointCAE_transformer.py:37-51, 94-147) and,
+ * by default, this library's end in float atomics whose order of arrival varies from launch to
+ * launch.  With a device workspace registered here (>= 1 MiB; 64 MiB covers the pretraining step
+ * at batch 128) the batch-norm statistics, the embedder's weight / bias gradients, the LayerNorm
+ * parameter gradients and the column sums store per-block partials and add them in block order:
+ * bit-identical results from run to run and from hipGraph replay to eager launch, for one small
+ * extra launch per reduction.  The workspace is shared by all launches: one stream at a time.
+ * workspace == NULL switches the mode off.  A reduction that needs more than `bytes` fails with
+ * PDAE_ERR_UNSUPPORTED.  Not covered (LDS float atomics, kept): group_points_grad,
+ * three_interpolate_grad and the large-cloud Chamfer gradient of the PointNet++ configuration. */
+int pdae_set_deterministic(void* workspace, size_t bytes);
+int pdae_deterministic(void);   /* 1 when a workspace is registered */
 
 /* ------------------------------------------------------------------------
  * Farthest point sampling.

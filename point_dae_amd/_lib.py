@@ -70,6 +70,8 @@ _SIGNATURES = {
 _HOST = {
     "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
+    "pdae_set_deterministic": [_vp, ctypes.c_size_t],
+    "pdae_deterministic": [],
 }
 _STR = ("pdae_version", "pdae_last_error")
 
@@ -108,6 +110,37 @@ def lib():
     return _lib
 
 
+_det_ws = None
+
+
+def set_deterministic(on=True, megabytes=64):
+    """Register (or drop) the workspace of include/pdae.h's deterministic mode on the current
+    device.  `PDAE_DETERMINISTIC=1` in the environment does this at the first kernel call."""
+    global _det_ws
+    handle = lib()
+    if on:
+        _det_ws = torch.empty(megabytes << 20, dtype=torch.uint8, device='cuda')
+        _check(handle, 'pdae_set_deterministic', handle.pdae_set_deterministic(_det_ws.data_ptr(), _det_ws.numel()))
+    else:
+        torch.cuda.synchronize()
+        _check(handle, 'pdae_set_deterministic', handle.pdae_set_deterministic(None, 0))
+        _det_ws = None
+
+
+def deterministic():
+    return bool(lib().pdae_deterministic())
+
+
+_env_checked = False
+
+
+def _env_mode():
+    global _env_checked
+    _env_checked = True
+    if os.environ.get('PDAE_DETERMINISTIC', '0') not in ('', '0') and _det_ws is None:
+        set_deterministic(True, int(os.environ.get('PDAE_DETERMINISTIC_MB', '64')))
+
+
 def stream_ptr():
     """hipStream_t of torch's current stream on the current device."""
     return torch.cuda.current_stream().cuda_stream
@@ -138,6 +171,8 @@ def call(name, on, *args):
     """Invoke one C entry on torch's current stream of `on`'s device; raise on a
     non-zero status."""
     handle = lib()
+    if not _env_checked:
+        _env_mode()
     if on.device.index != torch.cuda.current_device():
         with torch.cuda.device(on.device):
             rc = getattr(handle, name)(*args, stream_ptr())

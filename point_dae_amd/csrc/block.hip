@@ -11,7 +11,6 @@
 //   rowscale            da = keep[b] * dy                (its backward)
 //   colsum              bias gradients
 // One wave per row for the LayerNorm kernels (C <= 2048), float4 everywhere.
-#include <cstdlib>
 #include "common.h"
 
 namespace pdae {
@@ -114,7 +113,9 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ keep, int T,
-    float* __restrict__ da, float* __restrict__ dbias, int dy_slabs, float* __restrict__ dacc, int dacc_mode) {
+    float* __restrict__ da, float* __restrict__ dbias, int dy_slabs, float* __restrict__ dacc, int dacc_mode,
+    float* __restrict__ part) {
+  // (part: deterministic mode -- this block's 2-3 column partials go to row blockIdx.x of it)
   // (dy_slabs > 1: dy arrives as split-K slabs [dy_slabs][M][C], added up in slab order;
   //  dacc: a second copy of dx that is written (mode 1) or added to (mode 2): the gradient of the
   //  position embedding, which every block of a stack re-adds, sums over the blocks right here)
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
     float t = 0.f;
 #pragma unroll 4
     for (int k = 0; k < NW; ++k) t += red[(size_t)k * nred * C + c];
-    atomicAdd(c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : dbias + (c - 2 * C)), t);
+    col_add(c < C ? dgamma + c : (c < 2 * C ? dbeta + (c - C) : dbias + (c - 2 * C)), part, blockIdx.x,
+            nred * C, c, t);
   }
 }
 
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(long long n4, int C4
 // the block count -- the number of global atomics -- stays small.
 constexpr int CS_NW = 16, CS_ROWS = 4 * CS_NW;
 __device__ __forceinline__ void colsum_finish(float4 s, float4 (*part)[64], float* __restrict__ out, int c,
-                                              int N) {
+                                              int N, float* __restrict__ det) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   part[w][lane] = s;
   __syncthreads();
@@ -248,8 +250,12 @@ __device__ __forceinline__ void colsum_finish(float4 s, float4 (*part)[64], floa
       const float4 u = part[k][lane];
       t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
     }
-    atomicAdd(out + c + 0, t.x), atomicAdd(out + c + 1, t.y);
-    atomicAdd(out + c + 2, t.z), atomicAdd(out + c + 3, t.w);
+    if (det) {   // deterministic mode: row blockIdx.y of the partial matrix
+      *reinterpret_cast<float4*>(det + (size_t)blockIdx.y * N + c) = t;
+    } else {
+      atomicAdd(out + c + 0, t.x), atomicAdd(out + c + 1, t.y);
+      atomicAdd(out + c + 2, t.z), atomicAdd(out + c + 3, t.w);
+    }
   }
 }
 
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(CS_NW * 64) void bias_gelu_bwd_kernel(int M, int C,
                                                             const float* __restrict__ dh,
                                                             float* __restrict__ dz,
                                                             float* __restrict__ dbias,
-                                                            int rows_per_split) {
+                                                            int rows_per_split, float* __restrict__ det) {
   __shared__ float4 part[CS_NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(CS_NW * 64) void bias_gelu_bwd_kernel(int M, int C,
       s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
     }
   }
-  colsum_finish(s, part, dbias, c, C);
+  colsum_finish(s, part, dbias, c, C, det);
 }
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(long long n4, const float4* __restrict__ z,
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(long long n4, int C
 // Narrow matrices (N <= 128): LPR = N/4 lanes span a row and a wave reads 64/LPR rows at once.
 template <int LPR>
 __global__ __launch_bounds__(CS_NW * 64) void colsum2_kernel(int M, int N, const float* __restrict__ X,
-                                                             float* __restrict__ out, int rows_per_split) {
+                                                             float* __restrict__ out, int rows_per_split,
+                                                             float* __restrict__ det) {
   __shared__ float4 part[CS_NW][64];
   constexpr int RPW = 64 / LPR;                       // rows per wave and pass
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(CS_NW * 64) void colsum2_kernel(int M, int N, const
     }
     if (lane >= LPR) s = make_float4(0.f, 0.f, 0.f, 0.f), part[w][lane] = s;
   }
-  colsum_finish(s, part, (LPR < 64 && lane >= LPR) ? nullptr : out, c, N);
+  colsum_finish(s, part, (LPR < 64 && lane >= LPR) ? nullptr : out, c, N, det);
 }
 
 // Y[m][c] = keep[m/T] * X[m][c] and out[c] += column sums of Y: the backward of
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(CS_NW * 64) void scale_colsum_kernel(int M, int N, 
                                                                   const float* __restrict__ X,
                                                                   const float* __restrict__ keep,
                                                                   float* __restrict__ Y, float* __restrict__ out,
-                                                                  int rows_per_split) {
+                                                                  int rows_per_split, float* __restrict__ det) {
   __shared__ float4 part[CS_NW][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(CS_NW * 64) void scale_colsum_kernel(int M, int N, 
       s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
   }
-  colsum_finish(s, part, out, c, N);
+  colsum_finish(s, part, out, c, N, det);
 }
 
 }  // namespace pdae
@@ -444,22 +451,28 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
   if (!dy || !x || !mean || !rstd || !gamma || !dx || ((keep || da) && !dbias) || (keep && !da))
     return bad_arg("layernorm backward: null pointer");
   const int nred = dbias ? 3 : 2;
+  int rows, blocks;
   if (C <= 512) {
     // 16-wave blocks, one row per wave (two from 6144 rows on: fewer blocks = fewer atomics);
     // measured 13 us at M = 2944 and 20 us at M = 8192 (was 24 / 29 us with LDS atomics)
-    static const int force = getenv("PDAE_LN_PER_WAVE") ? atoi(getenv("PDAE_LN_PER_WAVE")) : 0;   // lab override
-    const int per_wave = force ? force : (M >= 6144 ? 2 : 1);
-    const int rows = 16 * per_wave;
-    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3((M + rows - 1) / rows), dim3(1024),
-                       16 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias, dy_slabs, dacc, dacc_mode);
+    rows = 16 * (M >= 6144 ? 2 : 1);
   } else {
-    int rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
+    rows = 4 * ((M + 4 * 256 - 1) / (4 * 256));
     if (rows > 32) rows = 32;
-    hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3((M + rows - 1) / rows), dim3(256),
-                       4 * nred * C * sizeof(float), s, M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma,
-                       dbeta, keep, T, da, dbias, dy_slabs, dacc, dacc_mode);
   }
+  blocks = (M + rows - 1) / rows;
+  int rc = PDAE_OK;
+  float* part = static_cast<float*>(det_workspace(sizeof(float) * (size_t)blocks * nred * C, &rc));
+  if (rc) return rc;
+  if (C <= 512)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3(blocks), dim3(1024), 16 * nred * C * sizeof(float), s, M,
+                       C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, keep, T, da, dbias, dy_slabs,
+                       dacc, dacc_mode, part);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3(blocks), dim3(256), 4 * nred * C * sizeof(float), s,
+                       M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, keep, T, da, dbias, dy_slabs,
+                       dacc, dacc_mode, part);
+  if (part) return det_reduce(s, blocks, nred * C, part, dgamma, C, dbeta, C, dbias, dbias ? C : 0);
   return check_launch(what);
 }
 
@@ -524,9 +537,13 @@ extern "C" int pdae_bias_gelu_backward(int M, int C, const float* z, const float
   if (!accumulate) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s);
   if (M == 0) return check_launch("bias_gelu_backward");
   if (!z || !bias || !dh || !dz) return bad_arg("bias_gelu_backward: null pointer");
-  const int rows = cs_rows(M);
-  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((C + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64),
-                     0, s, M, C, z, bias, dh, dz, dbias, rows);
+  const int rows = cs_rows(M), P = (M + rows - 1) / rows;
+  int rc = PDAE_OK;
+  float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)P * C, &rc));
+  if (rc) return rc;
+  hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((C + 255) / 256, P), dim3(CS_NW * 64), 0, s, M, C, z, bias, dh, dz,
+                     dbias, rows, det);
+  if (det) return det_reduce(s, P, C, det, dbias, C);
   return check_launch("bias_gelu_backward");
 }
 
@@ -552,14 +569,17 @@ extern "C" int pdae_colsum(int M, int N, const float* X, float* out, int accumul
   if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("colsum");
   if (!X) return bad_arg("colsum: null pointer");
-  const int rows = cs_rows(M);
+  const int rows = cs_rows(M), P = (M + rows - 1) / rows;
+  int rc = PDAE_OK;
+  float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)P * N, &rc));
+  if (rc) return rc;
   if (N == 128)
-    hipLaunchKernelGGL(colsum2_kernel<32>, dim3(1, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N, X, out, rows);
+    hipLaunchKernelGGL(colsum2_kernel<32>, dim3(1, P), dim3(CS_NW * 64), 0, s, M, N, X, out, rows, det);
   else if (N == 64)
-    hipLaunchKernelGGL(colsum2_kernel<16>, dim3(1, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M, N, X, out, rows);
+    hipLaunchKernelGGL(colsum2_kernel<16>, dim3(1, P), dim3(CS_NW * 64), 0, s, M, N, X, out, rows, det);
   else
-    hipLaunchKernelGGL(colsum2_kernel<64>, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64), 0, s, M,
-                       N, X, out, rows);
+    hipLaunchKernelGGL(colsum2_kernel<64>, dim3((N + 255) / 256, P), dim3(CS_NW * 64), 0, s, M, N, X, out, rows, det);
+  if (det) return det_reduce(s, P, N, det, out, N);
   return check_launch("colsum");
 }
 
@@ -570,8 +590,12 @@ extern "C" int pdae_scale_colsum(int M, int N, int T, const float* X, const floa
   if (out && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
   if (M == 0) return check_launch("scale_colsum");
   if (!X || !keep || !Y) return bad_arg("scale_colsum: null pointer");
-  const int rows = cs_rows(M);
-  hipLaunchKernelGGL(scale_colsum_kernel, dim3((N + 255) / 256, (M + rows - 1) / rows), dim3(CS_NW * 64),
-                     0, s, M, N, T, X, keep, Y, out, rows);
+  const int rows = cs_rows(M), P = (M + rows - 1) / rows;
+  int rc = PDAE_OK;
+  float* det = out ? static_cast<float*>(det_workspace(sizeof(float) * (size_t)P * N, &rc)) : nullptr;
+  if (rc) return rc;
+  hipLaunchKernelGGL(scale_colsum_kernel, dim3((N + 255) / 256, P), dim3(CS_NW * 64), 0, s, M, N, T, X, keep, Y,
+                     out, rows, det);
+  if (det) return det_reduce(s, P, N, det, out, N);
   return check_launch("scale_colsum");
 }

@@ -43,6 +43,25 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
   return dx * dx + dy * dy + dz * dz;
 }
 
+// ---- deterministic mode (pdae_set_deterministic, det.hip) --------------------
+// Column reductions that normally end in device-scope float atomics (order of arrival) write
+// one partial row per block, [partition][width], into the registered workspace instead;
+// det_reduce then adds the rows in partition order.  Same arithmetic per block either way.
+bool det_on();
+// the workspace when the mode is on (nullptr when it is off); *rc = PDAE_ERR_UNSUPPORTED and
+// nullptr when the registered buffer is smaller than `bytes`
+void* det_workspace(size_t bytes, int* rc);
+// outs[k][c] += sum_p part[p][off_k + c], p ascending; up to three output segments of
+// lens[k] columns laid side by side in a partial row (null outs are skipped)
+int det_reduce(hipStream_t s, int P, int width, const float* part, float* o0, int n0, float* o1 = nullptr,
+               int n1 = 0, float* o2 = nullptr, int n2 = 0);
+int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* out);
+
+__device__ __forceinline__ void col_add(float* out, float* part, int partition, int width, int c, float t) {
+  if (part) part[(size_t)partition * width + c] = t;
+  else atomicAdd(out, t);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 // exact (erf) GELU of nn.GELU (models/PointCAE_transformer.py:94-110) and its derivative

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
     int R, int C, const float* __restrict__ dA, const float* __restrict__ X,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ S,
-    int rows_per_block, const int* __restrict__ groups) {
+    int rows_per_block, const int* __restrict__ groups, float* __restrict__ det) {
   __shared__ float4 red[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c4 = (blockIdx.x * 32 + cl) * 4;
@@ -91,11 +91,15 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
       const float4 u = red[rl][k][cl];
       t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
     }
-    float* dst = S + (size_t)rl * C + c4;
-    atomicAdd(dst + 0, t.x);
-    atomicAdd(dst + 1, t.y);
-    atomicAdd(dst + 2, t.z);
-    atomicAdd(dst + 3, t.w);
+    if (det) {   // deterministic mode: row blockIdx.y of the [by][2][C] partials
+      *reinterpret_cast<float4*>(det + ((size_t)blockIdx.y * 2 + rl) * C + c4) = t;
+    } else {
+      float* dst = S + (size_t)rl * C + c4;
+      atomicAdd(dst + 0, t.x);
+      atomicAdd(dst + 1, t.y);
+      atomicAdd(dst + 2, t.z);
+      atomicAdd(dst + 3, t.w);
+    }
   }
 }
 
@@ -148,7 +152,8 @@ constexpr int C1_ROWS = 512;   // rows per block
 __global__ __launch_bounds__(256) void conv1_stats_kernel(int R, int C, const float* __restrict__ x,
                                                           const float* __restrict__ W,
                                                           const float* __restrict__ bias,
-                                                          float* __restrict__ y, double* __restrict__ stats) {
+                                                          float* __restrict__ y, double* __restrict__ stats,
+                                                          double* __restrict__ det) {
   extern __shared__ float red[];             // [phases][2][C]
   const int q = C >> 2;                      // channel quads
   const int phases = 256 / q;                // row phases per block
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(int R, int C, const fl
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     double t = 0.0;
     for (int p = 0; p < phases; ++p) t += (double)red[p * 2 * C + i];
-    atomicAdd(stats + i, t);
+    if (det) det[(size_t)blockIdx.x * 2 * C + i] = t;
+    else atomicAdd(stats + i, t);
   }
 }
 
@@ -271,9 +277,14 @@ extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, con
     rows = (Rsum + 16383) / 16384;
     by = (Rsum + rows - 1) / rows;
   }
-  if (Rsum > 0)
+  if (Rsum > 0) {
+    int rc = PDAE_OK;
+    float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)by * 2 * C, &rc));
+    if (rc) return rc;
     hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, Rsum,
-                       C, dA, X, scale, shift, mean, invstd, S, rows, groups);
+                       C, dA, X, scale, shift, mean, invstd, S, rows, groups, det);
+    if (det && (rc = det_reduce(s, by, 2 * C, det, S, 2 * C))) return rc;
+  }
   hipLaunchKernelGGL(bnrelu_backward_apply_kernel, dim3((C / 4 + 31) / 32, (G + 7) / 8), dim3(256), 0, s,
                      G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)R, gsum, inv_group,
                      dX);
@@ -286,9 +297,13 @@ extern "C" int pdae_embed_conv1_stats(int R, int C, const float* x, const float*
     return bad_arg("embed_conv1_stats: C/4 must divide 256");
   if (R == 0) return PDAE_OK;
   if (!x || !W || !y || !stats) return bad_arg("embed_conv1_stats: null pointer");
-  const int phases = 256 / (C / 4);
-  hipLaunchKernelGGL(conv1_stats_kernel, dim3((R + C1_ROWS - 1) / C1_ROWS), dim3(256),
-                     sizeof(float) * phases * 2 * C, as_stream(stream), R, C, x, W, bias, y, stats);
+  const int phases = 256 / (C / 4), blocks = (R + C1_ROWS - 1) / C1_ROWS;
+  int rc = PDAE_OK;
+  double* det = static_cast<double*>(det_workspace(sizeof(double) * (size_t)blocks * 2 * C, &rc));
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv1_stats_kernel, dim3(blocks), dim3(256), sizeof(float) * phases * 2 * C,
+                     as_stream(stream), R, C, x, W, bias, y, stats, det);
+  if (det) return det_reduce_f64(as_stream(stream), blocks, 2 * C, det, stats);
   return check_launch("embed_conv1_stats");
 }
 

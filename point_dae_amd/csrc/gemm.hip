@@ -76,10 +76,11 @@ struct NtArgs {
   const float* pro_shift;  // [K]
   const float* gbias;      // [M/32][N]  EPI_GROUPBIAS_STATS
   float* stats;            // [8][2][N]  per-XCD-slot partial sum / sumsq
+  float* stats_det;        // deterministic mode: [tile rows][2][N] plain-store partials (else null)
   float* gmax;             // [M/32][N]  EPI_*GROUPMAX
   unsigned char* garg;     // [M/32][N]
   const int* a_groups;     // nullable: row m of A is source row a_groups[m/32]*32 + m%32
-  int tiles_n, tiles;
+  int tiles_n, tiles, tile_rows;
 };
 
 __device__ __forceinline__ float act_relu(float v) { return v > 0.f ? v : 0.f; }
@@ -329,30 +330,34 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
   else
     epilogue(std::false_type{});
   if (EPI == EPI_GROUPBIAS_STATS) {
-    // per-block column sums through LDS, then one atomic per column per block
-    // into the partial buffer of this block's XCD slot
-    float* red = lds + 2 * (BM + BN) * GLD;  // [2][BN], behind the slab buffers (which already
+    // per-tile column sums: one LDS slot per row of waves (plain stores), added in wave order,
+    // then one atomic per column into the partial buffer of this block's XCD slot -- or, in
+    // deterministic mode, a plain store into row (tile row) of p.stats_det
+    constexpr int WM = BM / 64;
+    float* red = lds + 2 * (BM + BN) * GLD;  // [WM][2][BN], behind the slab buffers (which already
                                              // hold the next tile's first slab)
-    for (int c = tid; c < 2 * BN; c += NT) red[c] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float s = csum[j] + __shfl_xor(csum[j], 32, kWave);
       float q = csq[j] + __shfl_xor(csq[j], 32, kWave);
       if (h == 0) {
-        atomicAdd(&red[wn * 64 + j * 32 + r], s);
-        atomicAdd(&red[BN + wn * 64 + j * 32 + r], q);
+        red[(wm * 2 + 0) * BN + wn * 64 + j * 32 + r] = s;
+        red[(wm * 2 + 1) * BN + wn * 64 + j * 32 + r] = q;
       }
     }
     __syncthreads();
-    float* dst = p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
-    for (int c = tid; c < BN; c += NT) {
-      if (en0 + c < N) {
-        atomicAdd(dst + en0 + c, red[c]);
-        atomicAdd(dst + N + en0 + c, red[BN + c]);
+    float* dst = p.stats_det ? p.stats_det + (size_t)(em0 / BM) * 2 * N : p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
+    for (int c = tid; c < 2 * BN; c += NT) {
+      const int half = c / BN, cc = c - half * BN;
+      if (en0 + cc < N) {
+        float t = red[half * BN + cc];
+#pragma unroll
+        for (int k = 1; k < WM; ++k) t += red[(k * 2 + half) * BN + cc];
+        if (p.stats_det) dst[half * N + en0 + cc] = t;
+        else atomicAdd(dst + half * N + en0 + cc, t);
       }
     }
-    __syncthreads();   // red is zeroed again by the next tile's epilogue
+    __syncthreads();   // red is written again by the next tile's epilogue
   }
   if (next < 0) break;
   slot += nslots;
@@ -384,6 +389,8 @@ struct TnArgs {
   float* colsum_a;         // nullable: [N] += column sums of A (the bias gradient), from the k-tile-0 blocks
   int rows_per_split;
   int tk, tn, splits;      // tiles along K and N, M-splits
+  float* part_c;           // deterministic mode: [splits][N][K] plain-store partials (else null)
+  float* part_s;           //                     [splits][N] partials of colsum_a
 };
 
 // Block tile TM (columns n of A) x TN_ (columns k of B); every wave 64x64.  Bigger
@@ -520,10 +527,28 @@ void gemm_tn_kernel(const TnArgs p) {
     __syncthreads();
     buf ^= 1;
   }
-  if (sum_a && ok) {
-    atomicAdd(p.colsum_a + gcol + 0, asum.x), atomicAdd(p.colsum_a + gcol + 1, asum.y);
-    atomicAdd(p.colsum_a + gcol + 2, asum.z), atomicAdd(p.colsum_a + gcol + 3, asum.w);
+  if (p.colsum_a != nullptr && bx == 0) {
+    // the RSTEP threads that staged the same four columns meet in LDS (free after the loop's
+    // last barrier) and are added in row-phase order
+    float4* ls = reinterpret_cast<float4*>(&lds[0][0]);   // [RSTEP][TM / 4]
+    if (!isb) ls[srow0 * (TM / 4) + scol / 4] = asum;
+    __syncthreads();
+    if (!isb && srow0 == 0 && ok) {
+      float4 t = ls[scol / 4];
+#pragma unroll
+      for (int k = 1; k < RSTEP; ++k) {
+        const float4 u = ls[k * (TM / 4) + scol / 4];
+        t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+      }
+      if (p.part_s) {
+        *reinterpret_cast<float4*>(p.part_s + (size_t)split * N + gcol) = t;
+      } else {
+        atomicAdd(p.colsum_a + gcol + 0, t.x), atomicAdd(p.colsum_a + gcol + 1, t.y);
+        atomicAdd(p.colsum_a + gcol + 2, t.z), atomicAdd(p.colsum_a + gcol + 3, t.w);
+      }
+    }
   }
+  float* pc = p.part_c ? p.part_c + (size_t)split * N * K : nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = k0 + wn * 64 + j * 32 + r;
@@ -533,7 +558,10 @@ void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < N) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][e]);
+        if (row < N) {
+          if (pc) pc[(size_t)row * K + col] = acc[i][j][e];
+          else atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][e]);
+        }
       }
     }
   }
@@ -542,10 +570,11 @@ void gemm_tn_kernel(const TnArgs p) {
 template <int BM, int BN, int PRO, int EPI>
 static void launch_nt_cfg(NtArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + BM - 1) / BM;
+  a.tile_rows = tiles_m;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.tiles = tiles_m * a.tiles_n;
   constexpr int NTH = (BM / 64) * (BN / 64) * 64;
-  const size_t lds = (2 * (size_t)(BM + BN) * GLD + 2 * BN) * sizeof(float);
+  const size_t lds = (2 * (size_t)(BM + BN) * GLD + 2 * BN * (BM / 64)) * sizeof(float);
   // persistent blocks: one residency of the chip (32 CUs per XCD x blocks that fit a CU's LDS)
   const int chunk = (a.tiles + 7) / 8;
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
@@ -612,7 +641,7 @@ extern "C" int pdae_linear_backward_data(int M, int N, int K, const float* dY, c
 }
 
 template <int TM, int TN_>
-static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
+static int launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
   const int tn = (t.N + TM - 1) / TM, tk = (t.K + TN_ - 1) / TN_;
   constexpr int NTH = (TM / 64) * (TN_ / 64) * 64;
   // M-splits so that the grid is ONE full residency of the chip (256 CUs x 3 blocks):
@@ -626,17 +655,30 @@ static void launch_tn_cfg(TnArgs& t, bool bnrelu, hipStream_t s) {
   t.rows_per_split = rows;
   t.tk = tk, t.tn = tn, t.splits = splits;
   const unsigned grid = 8u * ((splits + 7) / 8) * tk * tn;
+  // deterministic mode: the splits store their tiles side by side and one pass adds them in
+  // split order (the zero-filled dW / dbias receive the sums)
+  int rc = PDAE_OK;
+  const size_t nk = (size_t)t.N * t.K;
+  float* ws = static_cast<float*>(det_workspace(sizeof(float) * splits * (nk + t.N), &rc));
+  if (rc) return rc;
+  if (ws) t.part_c = ws, t.part_s = ws + splits * nk;
   if (bnrelu)
     hipLaunchKernelGGL((gemm_tn_kernel<TM, TN_, PRO_BNRELU>), dim3(grid), dim3(NTH), 0, s, t);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<TM, TN_, PRO_NONE>), dim3(grid), dim3(NTH), 0, s, t);
+  if (ws) {
+    if (t.ldc != t.K) return unsupported("deterministic mode: weight gradients with a dense leading dimension only");
+    if ((rc = det_reduce(s, splits, (int)nk, t.part_c, t.C, (int)nk))) return rc;
+    if (t.colsum_a && (rc = det_reduce(s, splits, t.N, t.part_s, t.colsum_a, t.N))) return rc;
+  }
+  return PDAE_OK;
 }
 
 static int launch_tn(TnArgs& t, bool bnrelu, hipStream_t s) {
   // measured on the embedder's weight gradients (M = 262144): the 128x128 tile at two
   // blocks per CU (654 us for dW4) beats 192x256 / 256x256 at one block per CU (767 us)
-  launch_tn_cfg<128, 128>(t, bnrelu, s);
-  return check_launch("gemm_tn");
+  const int rc = launch_tn_cfg<128, 128>(t, bnrelu, s);
+  return rc ? rc : check_launch("gemm_tn");
 }
 
 extern "C" int pdae_linear_backward_weight(int M, int N, int K, const float* dY, const float* X,
@@ -684,7 +726,14 @@ extern "C" int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float*
   NtArgs a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
   a.gbias = gbias, a.stats = stats;
-  return launch_nt<PRO_NONE, EPI_GROUPBIAS_STATS>(a, s);
+  // deterministic mode: one partial row per tile row (128-row tiles at the least), added in
+  // row order into slot 0 of `stats`
+  const int max_tile_rows = (M + 127) / 128;
+  a.stats_det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)max_tile_rows * 2 * N, &rc));
+  if (rc) return rc;
+  rc = launch_nt<PRO_NONE, EPI_GROUPBIAS_STATS>(a, s);
+  if (rc || !a.stats_det) return rc;
+  return det_reduce(s, a.tile_rows, 2 * N, a.stats_det, stats, 2 * N);
 }
 
 extern "C" int pdae_embed_bnrelu_conv_groupmax(int M, int N, int K, const float* X,

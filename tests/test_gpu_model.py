@@ -225,6 +225,50 @@ def test_cfg5_shape_runs():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
+def test_cfg5_full_depth_step_against_oracle_loss():
+    """BASELINE config 5 per-GPU shape at FULL depth (N=2048, G=128, k=32, encoder 12 / decoder 4, 32 clouds
+    per GPU): the loss of a B=2 slice equals the CPU oracle model's (same weights, same host RNG draws,
+    1e-5), then the B=32 optimisation step trains under hipGraph replay."""
+    import os
+    import random
+    from oracle import model as OM
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.point_cae_transformer import PointCAE_transformer
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(
+        root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_double.yaml'))
+    config.npoints = 2048
+    config.model.num_group = 128
+    assert config.model.transformer_config.depth == 12 and config.model.transformer_config.decoder_depth == 4
+    config.model.transformer_config.drop_path_rate = 0.0
+    ref = fill_state(OM.PointCAE_transformer(config.model), 11).train()
+    mine = fill_state(PointCAE_transformer(config.model), 11).cuda().train()
+    x2 = shapenet_like_clouds(2, 2048, seed=31)
+
+    def seed(s):
+        random.seed(s), np.random.seed(s), torch.manual_seed(s)
+    seed(77)
+    l_ref, _ = ref(torch.from_numpy(x2), torch.from_numpy(x2))
+    seed(77)
+    l_my, _ = mine(torch.from_numpy(x2).cuda(), torch.from_numpy(x2).cuda())
+    assert abs(l_my.item() - l_ref.item()) <= 1e-5 * abs(l_ref.item()), (l_my.item(), l_ref.item())
+
+    config.model.transformer_config.drop_path_rate = 0.1
+    torch.manual_seed(0)
+    model = FlatDataParallel(builder.model_builder(config.model).cuda().train())
+    opt, _ = builder.build_opti_sche(model, config)
+    B = 32
+    x = torch.from_numpy(shapenet_like_clouds(B, 2048, seed=1)).cuda()
+    step = GraphedTrainStep(model, opt, config, B, 2048, warmup_eager=1)
+    losses = [step(x)[0].item() for _ in range(8)]
+    assert len(step.graphs) >= 1
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
+
+
 def test_main_cli_trains_and_resumes(tmp_path):
     """python -m point_dae_amd.main with the reference's flags: one tiny epoch, checkpoint, --resume."""
     import os
