@@ -62,6 +62,8 @@ def parse():
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--cpu-steps', type=int, default=1000, help='upper bound; the sample stops after ~20 s')
     p.add_argument('--probe-steps', type=int, default=5, help='eager steps after the timed region that time the roofline kernel')
+    p.add_argument('--split', default='auto', choices=['auto', 'on', 'off'],
+                   help='two-phase graphed step with the all-reduce under the embedder backward (auto: when ranks > 1)')
     p.add_argument('--no-also', action='store_true', help='skip the geometry-kernel rooflines and the cfg2 leg')
     p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 leg')
     return p.parse_args()
@@ -308,7 +310,8 @@ def main():
         def step(x):
             return train_step(model, optimizer, config, x, x)
     else:
-        step = GraphedTrainStep(model, optimizer, config, args.batch, args.npoints)
+        step = GraphedTrainStep(model, optimizer, config, args.batch, args.npoints,
+                                split=None if args.split == 'auto' else args.split == 'on')
         # capture every graph (one per visible-token count) before the warm-up
         # and timed steps; captures are set-up, not steps
         for tvis in range(args.num_group - int(0.8 * args.num_group), args.num_group - int(0.5 * args.num_group) + 1):
@@ -398,6 +401,9 @@ def main():
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
                        'local_batch': args.batch, 'global_batch': args.batch * world, 'npoints': args.npoints,
                        'num_group': args.num_group, 'group_size': 32, 'parallelism': 'dp%d' % world, 'launch': 'eager' if args.eager else 'hipGraph replay',
+                       'grad_allreduce': ('none (1 rank)' if world == 1 else
+                                          'Transformer slice under the embedder backward (two graphs)' if getattr(step, 'split', False)
+                                          else 'one flat all-reduce after the replay'),
                        'dense_layers': 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
             'roofline': roof,
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step

@@ -9,8 +9,10 @@ random mask / affine maps with the reference's RNG calls (MaskTransformer
 ._mask_center_rand, corrupt_data) and copies them into static device buffers.
 All graphs share one memory pool (activations of one step, ~6 GB of the 288 GB).
 
-The gradient all-reduce (world > 1) and the optimiser run right after the
-replay, outside the graph.
+The gradient all-reduce (world > 1) and the optimiser run outside the graphs.  With more than
+one rank the step is TWO graphs (GraphedTrainStep.split): the all-reduce of the Transformer's
+gradients starts after the first and runs on RCCL's stream while the second -- the patch
+embedder's backward -- replays; only the embedder's 2 MB are reduced in the open.
 """
 import os
 import torch
@@ -46,31 +48,51 @@ def _warn_if_null_stream():
 _AVG_OK = {}
 
 
-def _average_gradients(model):
-    """One all-reduce of the flat gradient buffer (116 MB for the Transformer DAE).  RCCL averages
-    in the collective (ReduceOp.AVG) when the build supports it; otherwise (and with gloo in the
-    CPU-side tests) sum, then divide."""
+def _start_average(model, a, b):
+    """Start the all-reduce of flat_grad[a:b] -> (work, needs_division).  RCCL averages in the
+    collective (ReduceOp.AVG) when the build supports it; otherwise (and with gloo in the CPU-side
+    tests) the sum is divided once every slice has arrived.  The NCCL/RCCL process group runs the
+    collective on its own stream behind an event recorded on the current one, so whatever is issued
+    on the current stream afterwards overlaps with it."""
     dist = torch.distributed
+    view = model.flat_grad[a:b]
     backend = dist.get_backend(model.process_group)
     if backend == 'nccl' and _AVG_OK.get(backend, True):
         try:
-            dist.all_reduce(model.flat_grad, op=dist.ReduceOp.AVG, group=model.process_group)
+            w = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=model.process_group, async_op=True)
             _AVG_OK[backend] = True
-            return
+            return w, False
         except (RuntimeError, ValueError, NotImplementedError):     # rejected before anything ran
             _AVG_OK[backend] = False
-    dist.all_reduce(model.flat_grad, group=model.process_group)
-    model.flat_grad.div_(model.world_size)
+    return dist.all_reduce(view, group=model.process_group, async_op=True), True
+
+
+def _average_gradients(model):
+    """One all-reduce of the flat gradient buffer (116 MB for the Transformer DAE)."""
+    w, div = _start_average(model, 0, model.flat_grad.numel())
+    w.wait()
+    if div:
+        model.flat_grad.div_(model.world_size)
 
 
 class GraphedTrainStep:
     MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
     RING = int(os.environ.get("PDAE_RING", "4"))   # staging slots = how many steps the host may run ahead
 
-    def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2):
+    def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2, split=None):
+        """split: two-phase step -- graph 1 = forward + loss + the Transformer's backward, graph 2 = the
+        patch embedder's backward (2.4 of the 14 ms); the all-reduce of the Transformer's gradients
+        (model.early_range, 98 % of the bytes) is started between the two replays and runs on RCCL's
+        stream under graph 2.  Default: on when world_size > 1."""
         assert isinstance(model, FlatDataParallel)
         self.model, self.optimizer, self.config = model, optimizer, config
         self.net = model.module
+        self.split = (model.world_size > 1) if split is None else bool(split)
+        if self.split and not model.late_ranges:
+            self.split = False                     # nothing was declared late: one phase
+        e0, e1 = model.early_range
+        self.early_idx = [i for i, (off, _) in enumerate(model.offsets) if e0 <= off < e1]
+        self.late_idx = [i for i, (off, _) in enumerate(model.offsets) if not e0 <= off < e1]
         dev = model.flat_param.device
         self.B, self.G = batch_size, self.net.num_group
         self.pts = torch.zeros(batch_size, npoints, 3, device=dev)
@@ -122,25 +144,50 @@ class GraphedTrainStep:
         slot['done'].record()
         return tvis
 
-    def _fwd_bwd(self, tvis):
+    def _gather(self, idx):
+        """Gradients are produced as fresh tensors (autograd ASSIGNS them: no 203 accumulate-add
+        launches, no memset of the flat buffer) and gathered into the flat gradient buffer with one
+        multi-tensor copy."""
+        m = self.model
+        have = [(m.grad_views[i], m.params[i].grad) for i in idx if m.params[i].grad is not None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for i in idx:
+            if m.params[i].grad is None:
+                m.grad_views[i].zero_()
+            m.params[i].grad = m.grad_views[i]
+
+    def _phase1(self, tvis, cut=None):
+        """forward + loss + backward; with `cut` (a dict) the backward stops at the patch tokens."""
         nv = self.B * tvis
         nm = self.B * (self.G - tvis)
-        # gradients are produced as fresh tensors (autograd ASSIGNS them: no 203
-        # accumulate-add launches, no memset of the flat buffer) and gathered into
-        # the flat gradient buffer with one multi-tensor copy
         m = self.model
         for p in m.params:
             p.grad = None
-        lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+        enc = self.net.MAE_encoder
+        enc.grad_cut = cut
+        try:
+            lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+        finally:
+            enc.grad_cut = None
         loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
         loss.backward()
-        have = [(v, p.grad) for p, v in zip(m.params, m.grad_views) if p.grad is not None]
-        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for p, v in zip(m.params, m.grad_views):
-            if p.grad is None:
-                v.zero_()
-            p.grad = v
+        self._gather(self.early_idx if cut is not None else range(len(m.params)))
         return lx.detach(), ln.detach()
+
+    def _phase2(self, cut):
+        """the patch embedder's backward from the token gradient phase 1 left in cut['leaf'].grad"""
+        cut['tokens'].backward(cut['leaf'].grad)
+        self._gather(self.late_idx)
+        cut.clear()
+
+    def _fwd_bwd(self, tvis):
+        if not self.split:
+            return self._phase1(tvis)
+        cut = {}
+        out = self._phase1(tvis, cut)
+        self._phase2(cut)
+        return out
 
     def _capture(self, tvis):
         sync = self.model.require_sync
@@ -150,34 +197,71 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):                          # warm-up on a side stream (PyTorch recipe)
             self._fwd_bwd(tvis)
         torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         # thread_local: only this thread's calls are checked against the capture (the RCCL
         # watchdog thread of torch.distributed queries events while we capture)
-        with torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local'):
-            out = self._fwd_bwd(tvis)
+        g = torch.cuda.CUDAGraph()
+        if not self.split:
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local'):
+                out = self._phase1(tvis)
+        else:
+            # two graphs out of one pool, always replayed back to back in capture order: what
+            # graph 2 reads (the embedder's saved activations, the token gradient) stays allocated
+            # in the pool between the captures because `cut` holds it
+            cut = {}
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local'):
+                out = self._phase1(tvis, cut)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=self.pool, capture_error_mode='thread_local'):
+                self._phase2(cut)
+            g = (g, g2)
         self.model.require_sync = sync
         self.graphs[tvis], self.outputs[tvis] = g, out
         return g
+
+    def _step_split(self, run1, run2):
+        """phase 1, start the big all-reduce, phase 2 under it, the two small slices, wait."""
+        m = self.model
+        out = run1()
+        works = []
+        if m.world_size > 1:
+            works.append(_start_average(m, *m.early_range))
+        run2()
+        if m.world_size > 1:
+            works += [_start_average(m, a, b) for a, b in m.late_ranges]
+            for w, _ in works:
+                w.wait()
+            if any(div for _, div in works):
+                m.flat_grad.div_(m.world_size)
+        return out
 
     def __call__(self, points, gt=None):
         self.pts.copy_(points[:, :, :3], non_blocking=True)
         tvis = self._draw()
         self.last_tvis = tvis
-        if self.eager_left > 0:                                # first steps eager: library init, autotuning
-            self.eager_left -= 1
-            sync = self.model.require_sync
-            self.model.require_sync = False
-            out = self._fwd_bwd(tvis)
+        sync = self.model.require_sync
+        self.model.require_sync = False                        # the bucket hooks stay out of this path
+        try:
+            if self.eager_left > 0:                            # first steps eager: library init
+                self.eager_left -= 1
+                if self.split:
+                    cut = {}
+                    out = self._step_split(lambda: self._phase1(tvis, cut), lambda: self._phase2(cut))
+                else:
+                    out = self._phase1(tvis)
+            else:
+                g = self.graphs.get(tvis)
+                if g is None:
+                    g = self._capture(tvis)
+                if self.split:
+                    self._step_split(g[0].replay, g[1].replay)
+                else:
+                    g.replay()
+                out = self.outputs[tvis]
+        finally:
             self.model.require_sync = sync
-        else:
-            g = self.graphs.get(tvis)
-            if g is None:
-                g = self._capture(tvis)
-            g.replay()
-            out = self.outputs[tvis]
-        if self.model.world_size > 1:
+        if self.model.world_size > 1 and not self.split:
             _average_gradients(self.model)
         self.optimizer.step()
         return out

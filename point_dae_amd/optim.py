@@ -5,11 +5,19 @@ Same update as torch.optim.AdamW with the reference's two parameter groups
 run as two launches of the fused kernel (csrc/adamw.hip) instead of ~35
 multi-tensor launches over 203 tensors.  Exposes `param_groups` (so the
 reference's schedulers drive `lr` unchanged), `step`, `zero_grad`,
-`state_dict` / `load_state_dict`.
+`state_dict` / `load_state_dict` in torch.optim.AdamW's layout: per-parameter `step` /
+`exp_avg` / `exp_avg_sq` entries numbered the way the reference's groups number them
+(module.named_parameters() order inside each group), so a checkpoint moves between this
+optimiser and torch.optim.AdamW over tools/builder.py's groups, and does not depend on how
+FlatDataParallel lays the flat buffer out.
 """
 import torch
 
 from . import _lib
+
+
+_TORCH_GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                             fused=None, decoupled_weight_decay=True)
 
 
 class FlatAdamW:
@@ -46,13 +54,53 @@ class FlatAdamW:
     def zero_grad(self, set_to_none=False):
         self.model.zero_grad()
 
+    def _torch_order(self):
+        """[(torch id, flat offset, numel, shape)] -- ids follow the reference's groups: no-decay
+        parameters first, then the decayed ones, each in named_parameters() order."""
+        m = self.model
+        where = {n: (off, cnt, p.shape) for n, (off, cnt), p in zip(m.names, m.offsets, m.params)}
+        named = [n for n, p in m.module.named_parameters() if p.requires_grad]
+        k = len(self.param_groups[0]['params'])
+        nd_names = set(m.names[:k])
+        order = [n for n in named if n in nd_names] + [n for n in named if n not in nd_names]
+        return [(i,) + where[n] for i, n in enumerate(order)], k
+
     def state_dict(self):
-        return {'state': {'step': self.steps, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq},
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        order, k = self._torch_order()
+        state = {}
+        if self.steps > 0:
+            for i, off, cnt, shape in order:
+                state[i] = {'step': torch.tensor(float(self.steps)),
+                            'exp_avg': self.exp_avg[off:off + cnt].reshape(shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + cnt].reshape(shape).clone()}
+        groups = []
+        for gi, g in enumerate(self.param_groups):
+            d = {key: v for key, v in g.items() if key not in ('params', 'range')}
+            for key, v in _TORCH_GROUP_DEFAULTS.items():      # so torch.optim.AdamW can load the groups
+                d.setdefault(key, v)
+            d['params'] = list(range(0, k)) if gi == 0 else list(range(k, len(order)))
+            groups.append(d)
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        self.steps = int(sd['state']['step'])
-        self.exp_avg.copy_(sd['state']['exp_avg'])
-        self.exp_avg_sq.copy_(sd['state']['exp_avg_sq'])
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update({k: v for k, v in s.items() if k != 'range'})
+        order, _ = self._torch_order()
+        state = sd['state']
+        if state and 'exp_avg' in state and not isinstance(state['exp_avg'], dict):
+            raise RuntimeError('FlatAdamW.load_state_dict: flat-layout optimiser state of an earlier build; '
+                               'checkpoints now use torch.optim.AdamW\'s per-parameter layout')
+        self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+        steps = set()
+        for i, off, cnt, shape in order:
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            self.exp_avg[off:off + cnt].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + cnt].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(st['step']))
+        if len(steps) > 1:
+            raise RuntimeError('FlatAdamW.load_state_dict: parameters with different step counts %s '
+                               '(the fused update keeps one counter)' % sorted(steps))
+        self.steps = steps.pop() if steps else 0
+        for g, saved in zip(self.param_groups, sd['param_groups']):
+            g.update({key: v for key, v in saved.items()
+                      if key not in ('params', 'range') and key not in _TORCH_GROUP_DEFAULTS})

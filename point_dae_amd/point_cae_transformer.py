@@ -236,6 +236,13 @@ class MaskTransformer(nn.Module):
         # final conv + max-pool, whose output the reference computes for all groups and
         # then drops for the masked ones (:449), runs for the visible groups only
         x_vis = self.encoder(neighborhood, groups=vis_rows.to(torch.int32))
+        cut = getattr(self, 'grad_cut', None)
+        if cut is not None and x_vis.requires_grad:
+            # two-phase backward (graph_step.py): the Transformer's backward stops at a leaf copy of the
+            # tokens; the embedder's backward runs later from cut['tokens'].backward(cut['leaf'].grad)
+            cut['tokens'] = x_vis
+            x_vis = x_vis.detach().requires_grad_()
+            cut['leaf'] = x_vis
         pos = nn_ops.pos_embed(center.reshape(B * G, 3).index_select(0, vis_rows), self.pos_embed)
         x_vis = self.blocks(x_vis, pos, B, Tvis)
         return nn_ops.layer_norm(x_vis, self.norm), mask, (vis_rows, mask_rows)
@@ -244,6 +251,10 @@ class MaskTransformer(nn.Module):
 @MODELS.register_module()
 class PointCAE_transformer(nn.Module):
     """models/PointCAE_transformer.py:616-742 ('Drop-Patch' configurations)."""
+
+    # parameters whose gradients backward produces last (FlatDataParallel lays them at the ends of the
+    # flat buffer; the rest is reduced while their backward still runs)
+    late_grad_prefixes = ('MAE_encoder.encoder.',)
 
     def __init__(self, config):
         super().__init__()

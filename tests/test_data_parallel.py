@@ -98,6 +98,68 @@ def test_flat_views_and_groups():
     assert model.flat_grad.abs().sum() == 0
 
 
+def test_late_parameters_sit_at_the_ends():
+    """late_prefixes (the patch embedder in the product model): [late no-decay | early | late decay], the
+    early range contiguous across the AdamW group boundary, optimiser groups unchanged as sets."""
+    from point_dae_amd.data_parallel import FlatDataParallel
+    net = _net()
+    ref = {n: p.detach().clone() for n, p in net.named_parameters()}
+    model = FlatDataParallel(net, late_prefixes=('0.', '1.'))      # the first Linear and the LayerNorm
+    where = dict(zip(model.names, model.offsets))
+    e0, e1 = model.early_range
+    for n, (off, cnt) in where.items():
+        late = n.startswith(('0.', '1.'))
+        assert (e0 <= off and off + cnt <= e1) != late, n
+        assert any(a <= off and off + cnt <= b for a, b in model.late_ranges) == late, n
+        assert torch.equal(dict(net.named_parameters())[n], ref[n])
+    assert model.late_ranges == [(0, 64 + 64 + 64), (model.flat_param.numel() - 16 * 64, model.flat_param.numel())]
+    nd0, nd1 = model.no_decay_range
+    d0, d1 = model.decay_range
+    for n, (off, cnt) in where.items():
+        one_d = dict(net.named_parameters())[n].dim() == 1
+        assert (nd0 <= off and off + cnt <= nd1) if one_d else (d0 <= off and off + cnt <= d1), n
+    groups = model.param_groups(0.05)
+    assert all(p.dim() == 1 for p in groups[0]['params']) and all(p.dim() == 2 for p in groups[1]['params'])
+    # default: the module's own declaration
+    net2 = _net()
+    net2.late_grad_prefixes = ('5.',)
+    m2 = FlatDataParallel(net2)
+    assert sum(b - a for a, b in m2.late_ranges) == 64 * 8 + 8
+    assert FlatDataParallel(_net()).late_ranges == []
+
+
+def _slices_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import _average_gradients, _start_average
+    model = FlatDataParallel(_net(), late_prefixes=('0.',))
+    model.require_sync = False
+    x, y = _data()
+    ((model(x[0, rank * 4:(rank + 1) * 4]) - y[0, rank * 4:(rank + 1) * 4]) ** 2).mean().backward()
+    whole = model.flat_grad.clone()
+    # the split step's order: the early range first, then the late ends, one division at the end
+    works = [_start_average(model, *model.early_range)] + [_start_average(model, a, b) for a, b in model.late_ranges]
+    for w, _ in works:
+        w.wait()
+    assert all(div for _, div in works)          # gloo sums; RCCL would average in the collective
+    model.flat_grad.div_(world)
+    sliced = model.flat_grad.clone()
+    model.flat_grad.copy_(whole)
+    _average_gradients(model)
+    if rank == 0:
+        torch.save({'sliced': sliced, 'whole': model.flat_grad.clone()}, out)
+    dist.destroy_process_group()
+
+
+def test_sliced_allreduce_equals_one_flat_allreduce(tmp_path):
+    out = str(tmp_path / 's.pt')
+    mp.spawn(_slices_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert torch.equal(r['sliced'], r['whole']) and r['whole'].abs().sum() > 0
+
+
 def _accum_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

@@ -148,8 +148,30 @@ def test_flat_adamw_matches_torch():
                 g['lr'] = 3e-3
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+    # the optimiser state travels both ways in torch.optim.AdamW's layout
     sd = opt.state_dict()
-    assert sd['state']['step'] == 5 and len(sd['param_groups']) == 2
+    assert len(sd['param_groups']) == 2 and all(int(v['step']) == 5 for v in sd['state'].values())
+    rsd = ropt.state_dict()
+    assert sorted(sd['state']) == sorted(rsd['state'])
+    assert [g['params'] for g in sd['param_groups']] == [g['params'] for g in rsd['param_groups']]
+    for i in rsd['state']:
+        assert torch.allclose(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq'], rtol=1e-5, atol=1e-9)
+    net2, ref2 = copy.deepcopy(ref), copy.deepcopy(net)          # swap: torch state -> flat, flat state -> torch
+    model2 = FlatDataParallel(net2)
+    opt2 = FlatAdamW(model2, lr=1e-2, weight_decay=0.05)
+    opt2.load_state_dict(rsd)
+    ropt2 = torch.optim.AdamW([{'params': [p for p in ref2.parameters() if p.dim() <= 1], 'weight_decay': 0.},
+                               {'params': [p for p in ref2.parameters() if p.dim() > 1], 'weight_decay': 0.05}], lr=1e-2)
+    ropt2.load_state_dict(sd)
+    assert opt2.steps == 5 and opt2.param_groups[0]['lr'] == 3e-3 and ropt2.param_groups[1]['lr'] == 3e-3
+    x = torch.randn(16, 37, device='cuda')
+    for mdl, o in ((model2, opt2), (ref2, ropt2), (model, opt), (ref, ropt)):
+        (mdl(x) ** 2).mean().backward()
+        o.step()
+        o.zero_grad()
+    for a, b, c, d in zip(net2.parameters(), ref2.parameters(), net.parameters(), ref.parameters()):
+        assert torch.allclose(a, d, rtol=1e-5, atol=1e-6) and torch.allclose(b, c, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize('M,N', [(262144, 128), (8192, 64), (2944, 384), (100, 1536), (5, 4), (8192, 512)])

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, split=None, det=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK='0')
     torch.cuda.set_device(0)
@@ -35,6 +35,9 @@ def _worker(rank, world, port, out):
     from point_dae_amd.data_parallel import FlatDataParallel
     from point_dae_amd.graph_step import GraphedTrainStep, use_created_stream
     use_created_stream()
+    if det:
+        from point_dae_amd import _lib
+        _lib.set_deterministic(True)
     from point_dae_amd.misc import set_random_seed
     from point_dae_amd.synthetic import shapenet_like_clouds
     config = cfg_from_yaml_file(os.path.join(
@@ -47,7 +50,7 @@ def _worker(rank, world, port, out):
     opt, _ = builder.build_opti_sche(model, config)
     B = 8
     x = torch.from_numpy(shapenet_like_clouds(B * 2, 1024, seed=10 + rank)).cuda().split(B)
-    step = GraphedTrainStep(model, opt, config, B, 1024, warmup_eager=1)
+    step = GraphedTrainStep(model, opt, config, B, 1024, warmup_eager=1, split=split)
     losses = []
     for i in range(6):
         losses.append(step(x[i % 2])[0].item())
@@ -55,7 +58,11 @@ def _worker(rank, world, port, out):
     dist.all_gather(flat, model.flat_param)
     same = torch.equal(flat[0], flat[1])
     if rank == 0:
-        torch.save({'same': same, 'losses': losses, 'graphs': len(step.graphs)}, out)
+        # parameters by NAME: the flat layout is the same in both modes, but do not rely on it
+        torch.save({'same': same, 'losses': losses, 'graphs': len(step.graphs), 'split': step.split,
+                    'early_bytes': 4 * (model.early_range[1] - model.early_range[0]),
+                    'late_bytes': 4 * sum(b - a for a, b in model.late_ranges),
+                    'params': {n: p.detach().cpu().clone() for n, p in net.named_parameters()}}, out)
     dist.destroy_process_group()
 
 
@@ -66,6 +73,24 @@ def test_two_ranks_graphed_step_stay_in_sync(tmp_path):
     assert r['same'], 'replicas diverged'
     assert r['graphs'] >= 1
     assert r['losses'][-1] < r['losses'][0], r['losses']
+
+
+def test_two_ranks_split_step_overlapped_allreduce(tmp_path):
+    """The two-phase step (graph 1 = forward + Transformer backward, async all-reduce of the Transformer
+    slice, graph 2 = embedder backward under it, then the embedder's two small slices): replicas stay
+    bit-identical, and -- in deterministic mode -- every parameter after six updates equals the
+    single-phase step's (one flat all-reduce after one graph) bit for bit."""
+    res = {}
+    for split in (True, False):
+        out = str(tmp_path / ('r%d.pt' % split))
+        mp.spawn(_worker, args=(2, _free_port(), out, split, True), nprocs=2, join=True)
+        res[split] = torch.load(out)
+        assert res[split]['same'], 'replicas diverged (split=%s)' % split
+        assert res[split]['split'] == split and res[split]['graphs'] >= 1
+    assert res[True]['early_bytes'] > 10 * res[True]['late_bytes'] > 0   # depth 2+1 here; 58x at full depth
+    assert res[True]['losses'] == res[False]['losses'], (res[True]['losses'], res[False]['losses'])
+    for n, p in res[True]['params'].items():
+        assert torch.equal(p, res[False]['params'][n]), n
 
 
 @pytest.mark.parametrize('launcher', ['torchrun', 'self'])
