@@ -26,6 +26,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from .arena import arena
+
 
 def _no_weight_decay(name, p):
     return p.dim() == 1 or name.endswith('.bias') or 'token' in name
@@ -120,6 +122,9 @@ class FlatDataParallel(nn.Module):
         return hook
 
     def forward(self, *args, **kwargs):
+        # gradients land in (or are gathered into) the flat buffer before the next forward: the
+        # backward may hand out slices of the shared pre-zeroed arena (arena.py's contract)
+        arena.lease()
         return self.module(*args, **kwargs)
 
     def finish(self):

@@ -111,6 +111,7 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
             raise NotImplementedError(loss_type)
 
     def forward(self, corrupted_pts, pts, vis=False, return_feat=False, capture=None, **kwargs):
+        nn_ops.begin_step(pts.device)
         if return_feat:
             return self.dgcnn_encoder(pts[:, :, :3].transpose(1, 2).contiguous())
         for item in self.corrupt_type:

@@ -140,6 +140,7 @@ class Point_CAE_PointNetv2(nn.Module):
             raise NotImplementedError(loss_type)
 
     def forward(self, corrupted_pts, pts, vis=False, capture=None, **kwargs):
+        nn_ops.begin_step(pts.device)
         corrupted_pts = corrupted_pts[:, :, :3].contiguous()
         pts = pts[:, :, :3].contiguous()
         for item in self.corrupt_type:

@@ -269,6 +269,49 @@ def test_cfg5_full_depth_step_against_oracle_loss():
     assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
 
 
+def test_bare_model_with_torch_adamw_and_zeroed_grads():
+    """A bare (un-wrapped) model under torch.optim.AdamW with zero_grad(set_to_none=False): parameter
+    gradients must own their memory (arena.py's contract: the shared pre-zeroed arena is leased only to
+    FlatDataParallel forwards), so in-place zeroing + accumulation gives the same updates as
+    set_to_none=True, and .grad read after the next forward still holds the last backward's values."""
+    import copy
+    import random
+    from point_dae_amd.point_cae_transformer import PointCAE_transformer
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    fx = load_fixture(FIXTURES[0])
+    cfg = model_cfg(fx)
+    cfg.transformer_config.drop_path_rate = 0.0
+    net_a = fill_state(PointCAE_transformer(cfg), 5).cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = torch.from_numpy(shapenet_like_clouds(4, 1024, seed=3)).cuda()
+    from point_dae_amd import _lib
+    runs = []
+    _lib.set_deterministic(True)       # same bits from the same launches: the two runs may differ only
+    try:                               # through the gradient bookkeeping under test
+        for net, to_none in ((net_a, True), (net_b, False)):
+            opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+            random.seed(1), np.random.seed(1), torch.manual_seed(1)
+            for _ in range(3):
+                loss, _ = net(x, x)
+                loss.backward()
+                opt.step()
+                opt.zero_grad(set_to_none=to_none)
+            runs.append({n: p.detach().clone() for n, p in net.named_parameters()})
+    finally:
+        _lib.set_deterministic(False)
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+    # a gradient read late: still the last backward's, not the next forward's zero-fill
+    loss, _ = net_a(x, x)
+    loss.backward()
+    g = {n: p.grad.clone() for n, p in net_a.named_parameters() if p.grad is not None}
+    with torch.no_grad():
+        net_a(x, x)
+    for n, p in net_a.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g[n]), n
+
+
 def test_main_cli_trains_and_resumes(tmp_path):
     """python -m point_dae_amd.main with the reference's flags: one tiny epoch, checkpoint, --resume."""
     import os
