@@ -376,6 +376,16 @@ void rows_gemm_kernel(const Args p) {
       for (int i = 0; i < TI; ++i) {
         const int rbase = m0 + (wm * TI + i) * 32 + 4 * h;
         const size_t off = (size_t)rbase * ldc + col;
+        // the sixteen GELU'(z) factors of this lane in ONE batch of loads (C and Z may alias as far
+        // as the compiler knows: read one by one, every load would wait behind the previous store)
+        float zv[16];
+        if (EPI == EPI_MUL_GELUGRAD && !ZERO) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2);
+            zv[e] = (FULL || (colok && rbase + lr < M)) ? p.Z[off + (unsigned)lr * ldc] : 0.f;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int lr = (e & 3) + 8 * (e >> 2);
@@ -393,7 +403,7 @@ void rows_gemm_kernel(const Args p) {
             p.Z[off + (unsigned)lr * ldc] = cdf + v * pdf;
             v = v * cdf;
           }
-          if (EPI == EPI_MUL_GELUGRAD) v *= p.Z[off + (unsigned)lr * ldc];
+          if (EPI == EPI_MUL_GELUGRAD) v *= zv[e];
           Cs[off + (unsigned)lr * ldc] = v;
         }
       }
@@ -594,12 +604,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   }
 }
 
-// dW tile = sum of its partials in block order (fixed => bit-identical run to run).  One block per
-// (tile, 1/16 of it): one float4 per thread, the partials' loads eight at a time in flight (a tile
-// of a narrow weight can have 64 partials: one thread walking them one by one took 237 us).  The
-// first sixteenth also reduces the bias-gradient column sums.
+// dW tile = sum of its partials in a fixed order (=> bit-identical run to run).  A block owns
+// 256 / PL float4 of a tile and PL "partial lanes": lane l adds partials b0 + l, b0 + l + PL, ...
+// (eight loads in flight), the lanes are then added in lane order through LDS.  PL = 1 for the
+// Transformer blocks' groups (<= 16 partials per tile); a narrow weight with a long reduction has
+// hundreds (the embedder's first conv: ONE tile, 512 partials -- a single lane walking them took
+// 121 us, PL = 8 takes 15).  Elements outside the weight are skipped.  The blocks with part == 0
+// also reduce the bias-gradient column sums.
+template <int PL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
-  const int tile = blockIdx.x >> 4, part = blockIdx.x & 15;
+  constexpr int EPB = 256 / PL;              // float4 per block
+  constexpr int PARTS = WTM * WTN / 4 / EPB;  // blocks per tile
+  static_assert(EPB >= WTM / 4, "the bias sums of a tile fit one block");
+  __shared__ float4 red[PL > 1 ? PL : 1][EPB];
+  __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
+  const int tile = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < WG_MAX; ++q)
@@ -611,33 +630,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
   // blocks whose ranges meet this tile's units [tile * chunks, (tile + 1) * chunks)
   const long long u0 = (long long)tile * g.chunks, u1 = u0 + g.chunks - 1;
   const int b0 = (int)(((u0 + 1) * g.blocks - 1) / g.units), b1 = (int)(((u1 + 1) * g.blocks - 1) / g.units);
-  const int tid = threadIdx.x;
-  const int e = part * 1024 + tid * 4;                               // element of the 128 x 128 tile
-  const bool bias = part == 0 && bx == 0 && P.db && tid < WTM;
+  const int tid = threadIdx.x, pl = tid / EPB, el = tid % EPB;
+  const int e = (part * EPB + el) * 4;                               // element of the 128 x 128 tile
+  const int row = n0 + e / WTN, col = k0 + e % WTN;
+  const bool valid = row < P.N && col < P.K;
+  const bool bias = part == 0 && bx == 0 && P.db && el < WTM / 4 && n0 + el * 4 < P.N;
   // block b's slot that holds this tile: the (tile - first tile of b's range)-th
   auto src_of = [&](int b) {
     return g.partials + ((size_t)b * g.slots + (tile - (int)(wg_start(g, b) / g.chunks))) * WSLOT;
   };
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  float bs = 0.f;
-  for (int b = b0; b <= b1; b += 8) {
-    float4 v[8];
-    float w[8];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), bs = s;
+  if (valid || bias)
+    for (int b = b0 + pl; b <= b1; b += 8 * PL) {
+      float4 v[8], w[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      v[q] = make_float4(0.f, 0.f, 0.f, 0.f), w[q] = 0.f;
-      if (b + q <= b1) {
-        const float* src = src_of(b + q);
-        v[q] = *reinterpret_cast<const float4*>(src + e);
-        if (bias) w[q] = src[WTM * WTN + tid];
+      for (int q = 0; q < 8; ++q) {
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f), w[q] = v[q];
+        if (b + q * PL <= b1) {
+          const float* src = src_of(b + q * PL);
+          if (valid) v[q] = *reinterpret_cast<const float4*>(src + e);
+          if (bias) w[q] = *reinterpret_cast<const float4*>(src + WTM * WTN + el * 4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s.x += v[q].x, s.y += v[q].y, s.z += v[q].z, s.w += v[q].w;
+        bs.x += w[q].x, bs.y += w[q].y, bs.z += w[q].z, bs.w += w[q].w;
       }
     }
+  if (PL > 1) {
+    red[pl][el] = s;
+    if (el < WTM / 4) redb[pl][el] = bs;
+    __syncthreads();
+    if (pl != 0) return;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s.x += v[q].x, s.y += v[q].y, s.z += v[q].z, s.w += v[q].w, bs += w[q];
+    for (int q = 1; q < PL; ++q) {
+      const float4 t = red[q][el];
+      s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+      if (el < WTM / 4) {
+        const float4 u = redb[q][el];
+        bs.x += u.x, bs.y += u.y, bs.z += u.z, bs.w += u.w;
+      }
+    }
   }
-  const int row = n0 + e / WTN, col = k0 + e % WTN;
-  if (row < P.N && col < P.K) *reinterpret_cast<float4*>(P.dW + (size_t)row * P.K + col) = s;
-  if (bias && n0 + tid < P.N) P.db[n0 + tid] = bs;
+  if (valid) *reinterpret_cast<float4*>(P.dW + (size_t)row * P.K + col) = s;
+  if (bias) *reinterpret_cast<float4*>(P.db + n0 + el * 4) = bs;
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -880,7 +917,11 @@ extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const f
   if (!workspace) return bad_arg("rows_wgrad: null workspace");
   g.partials = workspace;
   hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g.tiles * 16), dim3(256), 0, s, g);
+  // partial lanes of the reduction by the most partials a tile can have
+  const long long most = (g.chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
+  if (most <= 16) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
+  else if (most <= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(g.tiles * 128), dim3(256), 0, s, g);
   return check_launch("rows_wgrad");
 }
 
