@@ -496,7 +496,7 @@ class _TransformerBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a_in, bias_in, keep_in, res, pos, keep1, keep2, g1, b1, wqkv, wproj, bproj, g2, b2, w1,
-                bf1, w2, B, T, H, scale, eps1, eps2, pos_grad):
+                bf1, w2, B, T, H, scale, eps1, eps2, pos_grad, tail=0):
         res = res.contiguous()
         M, C = res.shape
         if a_in is not None:
@@ -508,14 +508,24 @@ class _TransformerBlock(torch.autograd.Function):
         o = _empty((M, H * D), res)
         lse = _empty((B, H, T), res)
         _lib.call('pdae_attention_forward', qkv, B, T, H, D, float(scale), _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse))
-        a1 = rows_gemm(o, wproj, may_split=True)
-        x2, n2, mean2, rstd2 = _res_ln_forward(a1, bproj, keep1, x1, None, g2, b2, eps2, T)
-        gp = _empty((M, w1.shape[0]), res)
+        if tail:
+            # only the last `tail` rows of every sample are read downstream (the decoder returns the
+            # masked tokens, PointCAE_transformer.py:229-231): everything after the attention core is
+            # row-wise, so it runs on those rows alone.  Same values on them, zero gradient elsewhere.
+            Tt = tail
+            o_t = o.view(B, T, -1)[:, T - tail:].reshape(B * tail, -1)
+            x1_t = x1.view(B, T, C)[:, T - tail:].reshape(B * tail, C)
+        else:
+            Tt, o_t, x1_t = T, o, x1
+        a1 = rows_gemm(o_t, wproj, may_split=True)
+        x2, n2, mean2, rstd2 = _res_ln_forward(a1, bproj, keep1, x1_t, None, g2, b2, eps2, Tt)
+        gp = _empty((x2.shape[0], w1.shape[0]), res)
         h = rows_gemm(n2, w1, False, bf1, 2, gp)
         a2 = rows_gemm(h, w2, may_split=True)
         ctx.save_for_backward(x1, n1, mean1, rstd1, qkv, o, lse, x2, n2, mean2, rstd2, gp, h, keep_in, keep1,
                               g1, wqkv, wproj, g2, w1, w2)
         ctx.dims = (B, T, H, D, float(scale))
+        ctx.tail = tail
         ctx.has_in, ctx.has_pos, ctx.has_bias_in, ctx.in_slabs = a_in is not None, pos is not None, bias_in is not None, \
             (_slabs(a_in) if a_in is not None else 1)
         ctx.a2_slabs = _slabs(a2)
@@ -531,9 +541,19 @@ class _TransformerBlock(torch.autograd.Function):
         da2 = _from_slabs(da2).contiguous()
         dz = rows_gemm(da2, w2, True, None, 3, gp)                        # (M, 4C): GELU' in the epilogue
         dn2 = rows_gemm(dz, w1, True, may_split=True)
+        tail = ctx.tail
         dx1, da1, dg2, db2, dbproj = _res_ln_backward(dn2, x2, mean2, rstd2, g2,
-                                                      dx2.contiguous() if dx2 is not None else None, keep1, T)
+                                                      dx2.contiguous() if dx2 is not None else None, keep1,
+                                                      tail if tail else T)
         do = rows_gemm(da1, wproj, True)
+        o_t = o
+        if tail:                               # rows outside the tail: zero gradient from this block's second half
+            C = x1.shape[1]
+            o_t = o.view(B, T, -1)[:, T - tail:].reshape(B * tail, -1)
+            full = torch.zeros(2, B, T, C, device=x1.device, dtype=x1.dtype)
+            full[0, :, T - tail:] = do.view(B, tail, C)
+            full[1, :, T - tail:] = dx1.view(B, tail, C)
+            do, dx1 = full[0].view(B * T, C), full[1].view(B * T, C)
         dqkv = torch.empty_like(qkv)
         _lib.call('pdae_attention_backward', qkv, B, T, H, D, scale, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse),
                   _lib.ptr(do), _lib.ptr(dqkv))
@@ -547,16 +567,21 @@ class _TransformerBlock(torch.autograd.Function):
             da0 = dbias_in = None
         # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
         dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
-        (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
-                                                                [False, False, True, False])
+        if tail:                               # two row counts: two groups
+            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False])
+            (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False])
+        else:
+            (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
+                                                                    [False, False, True, False])
         return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
-                dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None)
+                dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None, None)
 
 
-def transformer_block(x, pos, B, T, blk, keeps, pending=False, pos_grad=None):
+def transformer_block(x, pos, B, T, blk, keeps, pending=False, pos_grad=None, tail=0):
     """block(x + pos): x = x + dp(attn(ln1(x))); x = x + dp(mlp(ln2(x)))
     (PointCAE_transformer.py:155-158, :174-177) as one autograd Function.  `keeps` =
-    (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path.
+    (keep_attn, keep_mlp) per-sample DropPath factors from draw_drop_path.  tail > 0: the result
+    holds only the last `tail` rows of every sample (B*tail rows; see _TransformerBlock.forward).
     x may be a Pending (the previous block's MLP branch, added here by norm1's
     kernel); with pending=True the result is one too (for the next norm).  pos_grad =
     (PosGrad of the stack, index of this block): d pos is summed inside the kernels."""
@@ -569,6 +594,6 @@ def transformer_block(x, pos, B, T, blk, keeps, pending=False, pos_grad=None):
     a2, x2 = _TransformerBlock.apply(a_in, bias_in, keep_in, res, pos, keep1, keep2, blk.norm1.weight, blk.norm1.bias,
                                      attn.qkv.weight, attn.proj.weight, attn.proj.bias, blk.norm2.weight,
                                      blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, B, T,
-                                     attn.num_heads, attn.scale, blk.norm1.eps, blk.norm2.eps, pos_grad)
-    out = Pending(a2, mlp.fc2.bias, keep2, x2, T)
+                                     attn.num_heads, attn.scale, blk.norm1.eps, blk.norm2.eps, pos_grad, tail)
+    out = Pending(a2, mlp.fc2.bias, keep2, x2, tail if tail else T)
     return out if pending else out.resolve()

@@ -96,11 +96,12 @@ class Block(nn.Module):
         self.attn = Attention(dim, num_heads)
         self.drop_prob = float(drop_path)
 
-    def forward(self, x, pos, B, T, keeps=(None, None), pending=False, pos_grad=None):
+    def forward(self, x, pos, B, T, keeps=(None, None), pending=False, pos_grad=None, tail=0):
         """x, pos: (B*T, C) rows; computes block(x + pos).  x may be, and with
         pending=True the result is, an nn_ops.Pending (a branch not yet added to the
-        residual stream: the next norm's kernel adds it)."""
-        return nn_ops.transformer_block(x, pos, B, T, self, keeps, pending, pos_grad)
+        residual stream: the next norm's kernel adds it).  tail: keep only the last `tail` rows of
+        every sample after the attention core (nn_ops.transformer_block)."""
+        return nn_ops.transformer_block(x, pos, B, T, self, keeps, pending, pos_grad, tail)
 
 
 def _stack_keeps(stack, B):
@@ -143,15 +144,16 @@ class TransformerDecoder(nn.Module):
     def forward(self, x, pos, B, T, return_token_num=-1):
         keeps = _stack_keeps(self, B)
         pg = nn_ops.PosGrad(len(self.blocks))
+        # Only the last return_token_num tokens of every sample leave the decoder (:229-231, the masked
+        # ones), and after its attention core the last block is row-wise: its projection, MLP and the final
+        # norm run on those rows only (identical values there; the dropped rows had no reader).
+        n = return_token_num if 0 < return_token_num < T else 0
+        last = len(self.blocks) - 1
         for i, (blk, k) in enumerate(zip(self.blocks, keeps)):
-            x = blk(x, pos, B, T, k, pending=True, pos_grad=(pg, i))
-        # LayerNorm is row-wise: norm(x[:, -n:]) (:229-231) == norm(x)[:, -n:]; normalising every row
-        # lets the norm's kernel also do the last block's bias + DropPath + residual add
-        y = nn_ops.layer_norm(x, self.norm)
-        if return_token_num != -1:     # the masked tokens sit last in every sample
-            C = y.shape[-1]
-            y = y.reshape(B, T, C)[:, -return_token_num:].reshape(-1, C)
-        return y
+            x = blk(x, pos, B, T, k, pending=True, pos_grad=(pg, i), tail=n if i == last else 0)
+        # LayerNorm is row-wise: norm(x[:, -n:]) == norm(x)[:, -n:]; the norm's kernel also does the last
+        # block's bias + DropPath + residual add
+        return nn_ops.layer_norm(x, self.norm)
 
 
 def _pos_embed(dim):

@@ -179,3 +179,21 @@ def test_rows_wgrad_odd_shapes(dims, flags):
             _close(dw, dy.double().t() @ x.double(), 5e-5)
             if db is not None:
                 _close(db, dy.double().sum(0), 5e-5)
+
+
+@pytest.mark.parametrize('M,dims', [(262144, [(128, 4)]), (65536, [(128, 128)]), (8192, [(96, 384)]),
+                                    (8192, [(128, 4), (384, 128)])])
+def test_rows_wgrad_long_reduction_narrow_weight(M, dims):
+    """Hundreds of partials per tile (the embedder's first conv: one tile, 512 partials): the lane-parallel
+    reduction (4 / 8 partial lanes) gives the same sums as fp64 and the same bits twice."""
+    L = _lib()
+    flags = [True] * len(dims)
+    g = torch.Generator(device='cuda').manual_seed(M)
+    dys, xs, dws, dbs, _ = _wgrad(L, M, dims, flags, g)
+    for dy, x, dw, db in zip(dys, xs, dws, dbs):
+        _close(dw, dy.double().t() @ x.double(), 5e-5)
+        _close(db, dy.double().sum(0), 5e-5)
+    g2 = torch.Generator(device='cuda').manual_seed(M)
+    again = _wgrad(L, M, dims, flags, g2)
+    for a, b in zip(dws + dbs, again[2] + again[3]):
+        assert torch.equal(a, b)
