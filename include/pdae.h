@@ -260,6 +260,9 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  *              3: Y = acc * Z                   backward of 2: X = the gradient
  *                 of fc2's output, W = fc2's weight, Z from the forward: Y is
  *                 the gradient of fc1's output                     (w_kn = 1)
+ *              4: Y = Z > 0 ? acc : 0      backward through a ReLU whose output
+ *                 Z the forward kept (epi 1, or fold_input): the data gradient
+ *                 arrives already masked, relu'(0) = 0 as ATen        (w_kn = 1)
  *       cfg    : tile shape 0..7, or -1 = planned per shape
  *       splits : 1, or S in 2..8 = split the reduction: Y is then S slabs
  *                [S][M][N] of partial products (epi 0, no bias) which the
@@ -280,9 +283,27 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  *       launch; rows_wgrad_workspace returns the workspace size in floats.
  */
 int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn,
-                   const float* bias /*nullable*/, int epi, float* Z /*epi 2,3*/,
+                   const float* bias /*nullable*/, int epi, float* Z /*epi 2,3,4*/,
                    float* Y, int cfg, int splits, int stream_blocks,
                    pdae_stream_t stream);
+/* First layer of the FoldingNet stage of Point_CAE_PointNetv2 (csrc/folding.hip;
+ * models/PointCAE_pointnetv2.py:157-167: folding2[0] over [grid(2) | coarse point(3) |
+ * global feature(1024)] for `cells` grid cells x `coarse` points x `clouds`).  The
+ * conv is linear in the three column blocks: a[clouds,C] (feature block + bias),
+ * p[clouds*coarse,C] (coarse-point block), gd[cells,C] (grid block) come from three
+ * small GEMMs and
+ *   fold_input:      h[((b*coarse + c)*cells + g), :] = ReLU((a[b] + p[b,c]) + gd[g])
+ *   fold_input_grad: dpre = the gradient of the pre-activation, already masked by the
+ *       ReLU (rows_gemm epi 4 of the next layer's data gradient):
+ *       dp[b,c] = sum_g dpre,  dgd_part[blk][g] = sum over block blk's 64 (b,c) pairs --
+ *       the caller adds the fold_input_grad_parts(clouds, coarse) partial sets in
+ *       order (no atomics) and reduces dp over c for da.  C/4 must divide 256. */
+int pdae_fold_input(int clouds, int coarse, int cells, int C, const float* a, const float* p,
+                    const float* gd, float* h, pdae_stream_t stream);
+int pdae_fold_input_grad_parts(int clouds, int coarse);
+int pdae_fold_input_grad(int clouds, int coarse, int cells, int C, const float* dpre, float* dp,
+                         float* dgd_part, pdae_stream_t stream);
+
 /* Batched Y_b[M,N] = X_b[M,K] . W_b[N,K]^T, b < batch, element strides between the
  * problems (W_b = X_b: the Gram matrices behind DGCNN's feature-space kNN,
  * models/dgcnn_util.py:7-12).                                                  */

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "pdae_embed_conv1_stats": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bn_finalize": [_i, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_adamw_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
+    "pdae_fold_input": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_fold_input_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -71,6 +73,7 @@ _HOST = {
     "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
+    "pdae_fold_input_grad_parts": [_i, _i],
     "pdae_deterministic": [],
 }
 _STR = ("pdae_version", "pdae_last_error")

@@ -1,0 +1,136 @@
+// folding.hip -- the first layer of the FoldingNet stage of Point_CAE_PointNetv2
+// (models/PointCAE_pointnetv2.py:157-167: folding2[0] on [grid(2) | coarse point(3) | global
+// feature(1024)] for every one of 16 grid cells x 1024 coarse points x B clouds).
+//
+// The reference materialises the (B, 1029, 16384) input and runs one Conv1d over it.  The conv is
+// linear in the three column blocks, so its output is a per-cloud term a[b] (global feature, bias),
+// a per-coarse-point term p[b,c] and a per-grid-cell term gd[g] -- three small GEMMs -- and the
+// (B*1024*16, 512) activation is
+//     h[(b,c,g), :] = relu((a[b] + p[b,c]) + gd[g])
+// written here in ONE pass (4.3 GB at B = 128: the pass is the HBM write).  Backward: the masked
+// gradient dpre[(b,c,g), :] arrives from the next layer's data-gradient GEMM (its epilogue applies
+// the ReLU mask); one pass over it produces dp[b,c] = sum_g dpre and per-block partials of
+// dgd[g] = sum_{b,c} dpre (added in block order by the caller: no atomics); da[b] = sum_c dp[b,c]
+// is a reduction of the small dp.
+#include "common.h"
+
+namespace pdae {
+
+// one float4 of the output per thread; consecutive threads walk a row
+__global__ __launch_bounds__(256) void fold_input_kernel(long long n4, int coarse, int cells, int C4,
+                                                         const float4* __restrict__ a,
+                                                         const float4* __restrict__ p,
+                                                         const float4* __restrict__ gd,
+                                                         float4* __restrict__ h) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long long row = i / C4;
+  const int q = (int)(i - row * C4);
+  const long long bc = row / cells;
+  const int g = (int)(row - bc * cells);
+  const long long b = bc / coarse;
+  const float4 va = a[b * C4 + q], vp = p[bc * C4 + q], vg = gd[(long long)g * C4 + q];
+  float4 o;
+  o.x = (va.x + vp.x) + vg.x, o.y = (va.y + vp.y) + vg.y;
+  o.z = (va.z + vp.z) + vg.z, o.w = (va.w + vp.w) + vg.w;
+  o.x = o.x > 0.f ? o.x : 0.f, o.y = o.y > 0.f ? o.y : 0.f;
+  o.z = o.z > 0.f ? o.z : 0.f, o.w = o.w > 0.f ? o.w : 0.f;
+  h[i] = o;
+}
+
+// block = FG_PAIRS consecutive (cloud, coarse point) pairs; thread = one channel quad x one group of
+// 256 / C4 ... rows.  Layout: tid % C4 = channel quad, tid / C4 = row phase; a phase owns the cells
+// g = phase, phase + PH, ... so its dgd accumulators stay in registers across the block's pairs.
+constexpr int FG_PAIRS = 64;
+template <int CPT>   // cells per thread
+__global__ __launch_bounds__(256) void fold_input_grad_kernel(long long pairs, int cells, int C4,
+                                                              const float4* __restrict__ dpre,
+                                                              float4* __restrict__ dp,
+                                                              float4* __restrict__ dgd_part) {
+  extern __shared__ float4 red[];                 // [phases][C4]
+  const int PH = 256 / C4;                        // row phases
+  const int q = threadIdx.x % C4, ph = threadIdx.x / C4;
+  const long long p0 = (long long)blockIdx.x * FG_PAIRS;
+  const long long p1 = p0 + FG_PAIRS < pairs ? p0 + FG_PAIRS : pairs;
+  float4 acc[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long pr = p0; pr < p1; ++pr) {
+    float4 v[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int g = ph + k * PH;
+      v[k] = g < cells ? dpre[(pr * cells + g) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s = v[0];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      acc[k].x += v[k].x, acc[k].y += v[k].y, acc[k].z += v[k].z, acc[k].w += v[k].w;
+      if (k) s.x += v[k].x, s.y += v[k].y, s.z += v[k].z, s.w += v[k].w;
+    }
+    // the pair's sum over its cells: the phases meet in LDS, added in phase order
+    red[ph * C4 + q] = s;
+    __syncthreads();
+    if (ph == 0) {
+      float4 t = red[q];
+      for (int k = 1; k < PH; ++k) {
+        const float4 u = red[k * C4 + q];
+        t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+      }
+      dp[pr * C4 + q] = t;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int g = ph + k * PH;
+    if (g < cells) dgd_part[((long long)blockIdx.x * cells + g) * C4 + q] = acc[k];
+  }
+}
+
+}  // namespace pdae
+
+using namespace pdae;
+
+extern "C" int pdae_fold_input(int clouds, int coarse, int cells, int C, const float* a, const float* p,
+                               const float* gd, float* h, pdae_stream_t stream) {
+  if (clouds < 0 || coarse <= 0 || cells <= 0 || C <= 0 || C % 4 != 0)
+    return bad_arg("fold_input: C must be a positive multiple of 4");
+  if (clouds == 0) return PDAE_OK;
+  if (!a || !p || !gd || !h) return bad_arg("fold_input: null pointer");
+  const long long n4 = (long long)clouds * coarse * cells * (C / 4);
+  if ((n4 + 255) / 256 > 0x7fffffffLL) return unsupported("fold_input: too many elements");
+  hipLaunchKernelGGL(fold_input_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), n4,
+                     coarse, cells, C / 4, reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(p),
+                     reinterpret_cast<const float4*>(gd), reinterpret_cast<float4*>(h));
+  return check_launch("fold_input");
+}
+
+extern "C" int pdae_fold_input_grad_parts(int clouds, int coarse) {
+  const long long pairs = (long long)clouds * coarse;
+  return (int)((pairs + FG_PAIRS - 1) / FG_PAIRS);
+}
+
+extern "C" int pdae_fold_input_grad(int clouds, int coarse, int cells, int C, const float* dpre, float* dp,
+                                    float* dgd_part, pdae_stream_t stream) {
+  if (clouds < 0 || coarse <= 0 || cells <= 0 || C <= 0 || C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024)
+    return bad_arg("fold_input_grad: C/4 must divide 256");
+  if (clouds == 0) return PDAE_OK;
+  if (!dpre || !dp || !dgd_part) return bad_arg("fold_input_grad: null pointer");
+  const int C4 = C / 4, PH = 256 / C4;
+  const int cpt = (cells + PH - 1) / PH;
+  const long long pairs = (long long)clouds * coarse;
+  const unsigned grid = (unsigned)((pairs + FG_PAIRS - 1) / FG_PAIRS);
+  const size_t lds = sizeof(float4) * 256;
+  hipStream_t s = as_stream(stream);
+  auto a4 = reinterpret_cast<const float4*>(dpre);
+  auto b4 = reinterpret_cast<float4*>(dp);
+  auto c4 = reinterpret_cast<float4*>(dgd_part);
+  if (cpt <= 1) hipLaunchKernelGGL(fold_input_grad_kernel<1>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else if (cpt <= 2) hipLaunchKernelGGL(fold_input_grad_kernel<2>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else if (cpt <= 4) hipLaunchKernelGGL(fold_input_grad_kernel<4>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else if (cpt <= 8) hipLaunchKernelGGL(fold_input_grad_kernel<8>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else if (cpt <= 16) hipLaunchKernelGGL(fold_input_grad_kernel<16>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else return unsupported("fold_input_grad: more than 16 cells per row phase");
+  return check_launch("fold_input_grad");
+}

@@ -35,7 +35,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32, LD = BK + 4;   // LDS rows of 36 floats: ds_read_b128 of 16 lanes hits 64 banks
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_GELU2 = 2, EPI_MUL_GELUGRAD = 3 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_GELU2 = 2, EPI_MUL_GELUGRAD = 3, EPI_MUL_POS = 4 };
 
 struct Args {
   int M, N, K;
@@ -45,7 +45,8 @@ struct Args {
   int ldb;
   float* C;
   int ldc;
-  float* Z;           // EPI_BIAS_GELU2: GELU'(z) written;  EPI_MUL_GELUGRAD: read   (leading dimension ldc)
+  float* Z;           // EPI_BIAS_GELU2: GELU'(z) written;  EPI_MUL_GELUGRAD: read;  EPI_MUL_POS: the ReLU output
+                      // whose sign masks the result (leading dimension ldc)
   const float* bias;  // [N] or null
   int tiles_n, tiles;
   int kchunk;         // reduction range of one split (blockIdx.y), a multiple of BK
@@ -379,7 +380,7 @@ void rows_gemm_kernel(const Args p) {
         // the sixteen GELU'(z) factors of this lane in ONE batch of loads (C and Z may alias as far
         // as the compiler knows: read one by one, every load would wait behind the previous store)
         float zv[16];
-        if (EPI == EPI_MUL_GELUGRAD && !ZERO) {
+        if ((EPI == EPI_MUL_GELUGRAD || EPI == EPI_MUL_POS) && !ZERO) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int lr = (e & 3) + 8 * (e >> 2);
@@ -404,6 +405,7 @@ void rows_gemm_kernel(const Args p) {
             v = v * cdf;
           }
           if (EPI == EPI_MUL_GELUGRAD) v *= zv[e];
+          if (EPI == EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;      // ReLU backward: relu'(0) = 0 as ATen's threshold
           Cs[off + (unsigned)lr * ldc] = v;
         }
       }
@@ -819,7 +821,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
                               int stream_blocks, pdae_stream_t stream) {
   if (M < 0 || N <= 0 || K <= 0) return bad_arg("rows_gemm: bad size");
   if (K % 4 != 0 || (w_kn && N % 4 != 0)) return unsupported("rows_gemm: K (and N for a [K,N] weight) must be multiples of 4");
-  if (epi < 0 || epi > 3) return bad_arg("rows_gemm: epi must be 0..3");
+  if (epi < 0 || epi > 4) return bad_arg("rows_gemm: epi must be 0..4");
   if ((long long)M * (K > N ? K : N) >= (1LL << 30) || (long long)N * K >= (1LL << 30))
     return unsupported("rows_gemm: operands of 4 GB or more (32-bit byte offsets)");
   if (cfg >= NCFG || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
@@ -842,10 +844,12 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   if (splits > 1 && (epi != EPI_STORE || bias)) return bad_arg("rows_gemm: split-K slabs take the plain store epilogue without bias");
   if (M == 0) return PDAE_OK;
   if (!X || !W || !Y) return bad_arg("rows_gemm: null pointer");
-  if ((epi == EPI_BIAS_GELU2 || epi == EPI_MUL_GELUGRAD) && !Z) return bad_arg("rows_gemm: this epilogue needs Z");
+  if ((epi == EPI_BIAS_GELU2 || epi == EPI_MUL_GELUGRAD || epi == EPI_MUL_POS) && !Z)
+    return bad_arg("rows_gemm: this epilogue needs Z");
   if (epi == EPI_BIAS_GELU2 && w_kn) return unsupported("rows_gemm: bias+GELU epilogue on a [K,N] weight");
   if (epi == EPI_BIAS_RELU && w_kn) return unsupported("rows_gemm: bias+ReLU epilogue on a [K,N] weight");
-  if (epi == EPI_MUL_GELUGRAD && !w_kn) return unsupported("rows_gemm: GELU' epilogue on an [N,K] weight");
+  if ((epi == EPI_MUL_GELUGRAD || epi == EPI_MUL_POS) && !w_kn)
+    return unsupported("rows_gemm: the masking epilogues (data gradients) take a [K,N] weight");
   Args a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = w_kn ? N : K, a.C = Y, a.ldc = N;
   a.Z = Z, a.bias = bias, a.slab = (long long)M * N;
@@ -859,6 +863,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
     else launch_rows<false, EPI_BIAS_GELU2>(a, cfg, splits, 0, s);
   } else {
     if (epi == EPI_STORE) launch_rows<true, EPI_STORE>(a, cfg, splits, stream_blocks, s);
+    else if (epi == EPI_MUL_POS) launch_rows<true, EPI_MUL_POS>(a, cfg, splits, 0, s);
     else launch_rows<true, EPI_MUL_GELUGRAD>(a, cfg, splits, 0, s);
   }
   return check_launch("rows_gemm");

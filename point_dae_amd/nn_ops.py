@@ -408,6 +408,58 @@ class _Linear(torch.autograd.Function):
         return dx, dws[0], dbs[0], None
 
 
+class _FoldMLP(torch.autograd.Function):
+    """The FoldingNet stage of Point_CAE_PointNetv2 (models/PointCAE_pointnetv2.py:157-167: folding2 =
+    Conv1d(1029,512) ReLU Conv1d(512,512) ReLU Conv1d(512,3)) on rows, given the first conv's three
+    hoisted terms a (clouds, C), p (clouds*coarse, C), gd (cells, C):
+        h1 = relu((a + p) + gd)   one write pass (csrc/folding.hip)
+        h2 = relu(h1 W2^T + b2)   bias + ReLU in the GEMM epilogue
+        y  = h2 W3^T + b3         (W3 zero-padded to 4 outputs)
+    Backward: each data-gradient GEMM masks its result with the ReLU output it flows into (rows_gemm
+    epi 4) -- no compare / multiply / threshold passes over the 4.3 GB activations -- and one pass over
+    the first layer's masked gradient yields dp and the partial sums of dgd."""
+
+    @staticmethod
+    def forward(ctx, a, p, gd, w2, b2, w3, b3, clouds, coarse, cells):
+        a, p, gd = a.contiguous(), p.contiguous(), gd.contiguous()
+        C = a.shape[1]
+        rows = clouds * coarse * cells
+        h1 = _empty((rows, C), a)
+        _lib.call('pdae_fold_input', a, clouds, coarse, cells, C, _lib.ptr(a), _lib.ptr(p), _lib.ptr(gd), _lib.ptr(h1))
+        h2 = rows_gemm(h1, w2, False, b2, 1)
+        y = rows_gemm(h2, w3, False, b3, 0)
+        ctx.save_for_backward(h1, h2, w2, w3)
+        ctx.dims = (clouds, coarse, cells, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h1, h2, w2, w3 = ctx.saved_tensors
+        clouds, coarse, cells, C = ctx.dims
+        dy = dy.contiguous()
+        d2 = rows_gemm(dy, w3, True, None, 4, h2)                   # gradient of h2's pre-activation
+        (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
+        d1 = rows_gemm(d2, w2, True, None, 4, h1)                   # gradient of h1's pre-activation
+        (dw2,), (db2,) = rows_wgrad([d2], [h1], [True])
+        del d2
+        parts = _lib.lib().pdae_fold_input_grad_parts(clouds, coarse)
+        dp = _empty((clouds * coarse, C), dy)
+        part = _empty((parts, cells, C), dy)
+        _lib.call('pdae_fold_input_grad', dy, clouds, coarse, cells, C, _lib.ptr(d1), _lib.ptr(dp), _lib.ptr(part))
+        return dp.view(clouds, coarse, C).sum(1), dp, part.sum(0), dw2, db2, dw3, db3, None, None, None
+
+
+def fold_mlp(a, p, gd, conv2, conv3, clouds, coarse, cells):
+    """-> (clouds*coarse*cells, 3) offsets; conv2 / conv3 = folding2[2] / folding2[4] (Conv1d, kernel 1)."""
+    w3, b3 = conv3.weight.squeeze(-1), conv3.bias
+    n = w3.shape[0]
+    pn = (-n) % 4
+    if pn:                                              # 3 output coordinates: a zero fourth row
+        w3, b3 = F.pad(w3, (0, 0, 0, pn)), F.pad(b3, (0, pn))
+    y = _FoldMLP.apply(a, p, gd, conv2.weight.squeeze(-1), conv2.bias, w3, b3, clouds, coarse, cells)
+    return y[:, :n] if pn else y
+
+
 def _linear_rows(x, w, b, relu=False):
     return linear_any(x, w, b, relu)
 

@@ -157,9 +157,8 @@ class Point_CAE_PointNetv2(nn.Module):
         a = nn_ops.linear_any(feature, w[:, 5:].contiguous(), self.folding2[0].bias)        # (B, 512)  once per cloud
         p = nn_ops.linear_any(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
         gd = F.linear(self.grid, w[:, :2])                                     # (16, 512)     once per grid cell
-        h = F.relu(a.view(B, 1, 1, -1) + p + gd.view(1, 1, g2, -1)).reshape(B * self.num_fine, -1)
-        h = nn_ops.linear_any(h, self.folding2[2].weight.squeeze(-1), self.folding2[2].bias, relu=True)
-        off = nn_ops.linear_any(h, self.folding2[4].weight.squeeze(-1), self.folding2[4].bias)
+        off = nn_ops.fold_mlp(a, p.reshape(B * self.num_coarse, -1), gd, self.folding2[2], self.folding2[4],
+                              B, self.num_coarse, g2)
         fine = off.reshape(B, self.num_coarse, g2, 3) + coarse.unsqueeze(2)
         fine = fine.reshape(B, self.num_fine, 3)
         if capture is not None:

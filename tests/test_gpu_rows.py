@@ -197,3 +197,50 @@ def test_rows_wgrad_long_reduction_narrow_weight(M, dims):
     again = _wgrad(L, M, dims, flags, g2)
     for a, b in zip(dws + dbs, again[2] + again[3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1000, 512, 4), (333, 64, 128)])
+def test_rows_gemm_relu_mask_epilogue(M, N, K):
+    """epi 4: dX = (dY . W) masked by the sign of the ReLU output the gradient flows into."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    dy = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(K, N, device='cuda', generator=g) * 0.1          # (out=K, in=N): the [K,N] operand
+    h = torch.relu(torch.randn(M, N, device='cuda', generator=g))
+    h[0, :8] = 0.0                                                   # exact zeros: relu'(0) = 0
+    y = torch.full((M, N), float('nan'), device='cuda')
+    L.call('pdae_rows_gemm', dy, M, N, K, dy.data_ptr(), w.data_ptr(), 1, None, 4, h.data_ptr(), y.data_ptr(), -1, 1, 0)
+    want = (dy.double() @ w.double()) * (h > 0)
+    _close(y, want, 2e-5)
+    assert (y[h == 0] == 0).all()
+
+
+@pytest.mark.parametrize('clouds,coarse,cells,C', [(3, 40, 16, 512), (2, 7, 16, 128), (1, 5, 9, 64), (5, 129, 4, 256)])
+def test_fold_input_and_grad(clouds, coarse, cells, C):
+    """fold_input / fold_input_grad (csrc/folding.hip) against the broadcast formulation in torch:
+    forward bit for bit (same association (a + p) + gd), the sums to fp32 accuracy, partial sets
+    reproducible."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(clouds * 100 + coarse)
+    a = torch.randn(clouds, C, device='cuda', generator=g)
+    p = torch.randn(clouds * coarse, C, device='cuda', generator=g)
+    gd = torch.randn(cells, C, device='cuda', generator=g)
+    rows = clouds * coarse * cells
+    h = torch.full((rows, C), float('nan'), device='cuda')
+    L.call('pdae_fold_input', a, clouds, coarse, cells, C, a.data_ptr(), p.data_ptr(), gd.data_ptr(), h.data_ptr())
+    want = torch.relu((a.view(clouds, 1, 1, C) + p.view(clouds, coarse, 1, C)) + gd.view(1, 1, cells, C)).reshape(rows, C)
+    assert torch.equal(h, want)
+    d = torch.randn(rows, C, device='cuda', generator=g) * (h > 0)
+    parts = L.lib().pdae_fold_input_grad_parts(clouds, coarse)
+    assert parts == (clouds * coarse + 63) // 64
+    outs = []
+    for _ in range(2):
+        dp = torch.full((clouds * coarse, C), float('nan'), device='cuda')
+        part = torch.full((parts, cells, C), float('nan'), device='cuda')
+        L.call('pdae_fold_input_grad', d, clouds, coarse, cells, C, d.data_ptr(), dp.data_ptr(), part.data_ptr())
+        outs.append((dp, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dp, part = outs[0]
+    d4 = d.double().view(clouds, coarse, cells, C)
+    _close(dp, d4.sum(2).reshape(-1, C), 1e-5)
+    _close(part.sum(0), d4.sum((0, 1)), 1e-5)

@@ -13,7 +13,7 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 filt = sys.argv[4] if len(sys.argv) > 4 else None
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start").fetchall()
-ad = [i for i, r in enumerate(rows) if 'adamw' in r[0]]
+ad = [i for i, r in enumerate(rows) if 'adamw_kernel' in r[0]]
 sel = rows[ad[-(2 * steps + 1)] + 1:]
 span = (sel[-1][2] - sel[0][1]) / 1e6
 

@@ -11,7 +11,7 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((r['Kernel_Name'], int(r['Start_Timestamp']), int(r['End_Timestamp'])))
 rows.sort(key=lambda r: r[1])
-ad = [i for i, r in enumerate(rows) if 'adamw' in r[0]]
+ad = [i for i, r in enumerate(rows) if 'adamw_kernel' in r[0]]
 sel = rows[ad[-(2 * steps + 1)] + 1:]
 span = (sel[-1][2] - sel[0][1]) / 1e6
 
