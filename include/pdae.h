@@ -286,6 +286,27 @@ int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn
                    const float* bias /*nullable*/, int epi, float* Z /*epi 2,3,4*/,
                    float* Y, int cfg, int splits, int stream_blocks,
                    pdae_stream_t stream);
+/* Set-abstraction levels of the PointNet++ encoder (Point_CAE_PointNetv2;
+ * extensions/pointnet2/pointnet2_modules.py PointnetSAModule: SharedMLP of
+ * Conv2d 1x1 (no bias) -> BatchNorm2d -> ReLU layers, then F.max_pool2d over nsample)
+ * on rows = (cloud, centre, sample):
+ *   conv_stats: Y[M,N] = act(X[M,K]) . W[N,K]^T and this layer's batch statistics
+ *       (stats [8][2][N] partial sums / sums of squares for bn_finalize); act = the
+ *       previous layer's BatchNorm + ReLU, relu(x*scale[k] + shift[k]), applied while
+ *       X is staged (scale = shift = NULL: X as is).  The normalised activations are
+ *       never stored.  Backward of a layer: bnrelu_backward, then
+ *       bnrelu_linear_backward_weight / rows_gemm (w_kn) as in the patch embedder.
+ *   bnrelu_group_max: out[g][c] = max_j relu(y[g*ns+j][c]*scale[c] + shift[c]),
+ *       arg[g][c] = the first j attaining it (ns <= 256).
+ *   group_max_scatter_n: dense[g*ns+j][c] = (j == arg[g][c]) ? grad[g][c] : 0. */
+int pdae_conv_stats(int M, int N, int K, const float* X, const float* scale /*nullable*/,
+                    const float* shift /*nullable*/, const float* W, float* Y, float* stats,
+                    pdae_stream_t stream);
+int pdae_bnrelu_group_max(long long G, int ns, int C, const float* y, const float* scale,
+                          const float* shift, float* out, unsigned char* arg, pdae_stream_t stream);
+int pdae_group_max_scatter_n(long long G, int ns, int C, const float* grad, const unsigned char* arg,
+                             float* dense, pdae_stream_t stream);
+
 /* First layer of the FoldingNet stage of Point_CAE_PointNetv2 (csrc/folding.hip;
  * models/PointCAE_pointnetv2.py:157-167: folding2[0] over [grid(2) | coarse point(3) |
  * global feature(1024)] for `cells` grid cells x `coarse` points x `clouds`).  The

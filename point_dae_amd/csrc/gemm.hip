@@ -60,7 +60,8 @@ enum {
   EPI_BIAS_GELU = 2,
   EPI_GROUPBIAS_STATS = 3,
   EPI_GROUPMAX = 4,
-  EPI_STORE_GROUPMAX = 5
+  EPI_STORE_GROUPMAX = 5,
+  EPI_STATS = 6            // C = acc (+ bias); per-column sum / sum of squares like EPI_GROUPBIAS_STATS
 };
 
 struct NtArgs {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
           float v = acc[i][j][e] + add;
           if (EPI == EPI_BIAS_RELU) v = act_relu(v);
           if (EPI == EPI_BIAS_GELU) v = act_gelu(v);
-          if (EPI == EPI_GROUPBIAS_STATS && (FULL || row < M)) {
+          if ((EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) && (FULL || row < M)) {
             csum[j] += v;
             csq[j] += v * v;
           }
@@ -329,7 +330,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
     epilogue(std::true_type{});
   else
     epilogue(std::false_type{});
-  if (EPI == EPI_GROUPBIAS_STATS) {
+  if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) {
     // per-tile column sums: one LDS slot per row of waves (plain stores), added in wave order,
     // then one atomic per column into the partial buffer of this block's XCD slot -- or, in
     // deterministic mode, a plain store into row (tile row) of p.stats_det
@@ -732,6 +733,39 @@ extern "C" int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float*
   a.stats_det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)max_tile_rows * 2 * N, &rc));
   if (rc) return rc;
   rc = launch_nt<PRO_NONE, EPI_GROUPBIAS_STATS>(a, s);
+  if (rc || !a.stats_det) return rc;
+  return det_reduce(s, a.tile_rows, 2 * N, a.stats_det, stats, 2 * N);
+}
+
+// ---- one layer of a shared MLP (Conv 1x1, no bias -> BatchNorm -> ReLU; pointnet2_modules'
+// SharedMLP): Y = act(X) . W^T with act = the PREVIOUS layer's BatchNorm + ReLU applied while X
+// is staged (scale == null: X as is), and this layer's BatchNorm statistics from the epilogue.
+extern "C" int pdae_conv_stats(int M, int N, int K, const float* X, const float* scale, const float* shift,
+                               const float* W, float* Y, float* stats, pdae_stream_t stream) {
+  int rc = check_nt("conv_stats: bad size", M, N, K);
+  if (rc) return rc;
+  if (!stats) return bad_arg("conv_stats: null pointer");
+  if ((scale == nullptr) != (shift == nullptr)) return bad_arg("conv_stats: scale and shift go together");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(stats, 0, sizeof(float) * 16 * (size_t)N, s);
+  if (M == 0) return check_launch("conv_stats");
+  if (!X || !W || !Y) return bad_arg("conv_stats: null pointer");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
+  a.pro_scale = scale, a.pro_shift = shift, a.stats = stats;
+  const int max_tile_rows = (M + 127) / 128;
+  a.stats_det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)max_tile_rows * 2 * N, &rc));
+  if (rc) return rc;
+  // narrow outputs (the first set-abstraction level: 64 / 128 channels): the 128-wide tile
+  const bool narrow = N <= 128;
+  if (scale) {
+    if (narrow) launch_nt_cfg<128, 128, PRO_BNRELU, EPI_STATS>(a, s);
+    else launch_nt_cfg<256, 256, PRO_BNRELU, EPI_STATS>(a, s);
+  } else {
+    if (narrow) launch_nt_cfg<128, 128, PRO_NONE, EPI_STATS>(a, s);
+    else launch_nt_cfg<256, 256, PRO_NONE, EPI_STATS>(a, s);
+  }
+  rc = check_launch("conv_stats");
   if (rc || !a.stats_det) return rc;
   return det_reduce(s, a.tile_rows, 2 * N, a.stats_det, stats, 2 * N);
 }

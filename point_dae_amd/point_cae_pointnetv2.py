@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import nn_ops
+from . import nn_ops, sa_mlp
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from .pointnet2_utils import ball_query, furthest_point_sample_with_centres
 from .registry import MODELS
@@ -93,7 +93,11 @@ class PointnetSAModule(nn.Module):
             g = xyz.reshape(B * N, 3)
             g = torch.cat([g, g.new_zeros(g.shape[0], 1)] + ([features] if features is not None else []), dim=1)
             groups, per = B, N
-        for i, layer in enumerate(self.mlps[0]):
+        layers = list(self.mlps[0])
+        if self.training and per <= 256 and g.shape[0] % 32 == 0 and not any(
+                isinstance(layer.bn.bn, nn.SyncBatchNorm) for layer in layers):
+            return new_xyz, sa_mlp.shared_mlp_max(g, layers, per, pad_at=3)      # fused (sa_mlp.py)
+        for i, layer in enumerate(layers):
             g = layer.rows(g, pad_at=3 if i == 0 else None)
         return new_xyz, g.reshape(groups, per, -1).max(dim=1)[0]
 

@@ -1,0 +1,85 @@
+"""Set-abstraction shared MLP + max-pool (point_dae_amd/sa_mlp.py: conv_stats, bnrelu_group_max,
+group_max_scatter_n + the embedder's BatchNorm-backward kernels) against the reference's layer stack
+(pointnet2_modules SharedMLP: Conv2d 1x1 no bias -> BatchNorm2d -> ReLU, then max over nsample) run by
+PyTorch in fp64: outputs, every parameter gradient, the input gradient, running statistics."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    scale = b.abs().max().item() + 1e-12
+    err = (a.double() - b.double()).abs().max().item() / scale
+    assert err <= tol, err
+
+
+def _level(spec, seed):
+    from point_dae_amd.point_cae_pointnetv2 import SharedMLP
+    torch.manual_seed(seed)
+    mlp = SharedMLP(spec).cuda().train()
+    with torch.no_grad():
+        for layer in mlp:
+            layer.bn.bn.weight.uniform_(0.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    return mlp
+
+
+def _reference(x64, mlp64, groups, ns):
+    """(R, K) rows -> the reference's (B=1, C, groups, ns) tensor through Conv2d / BatchNorm2d / ReLU / max."""
+    t = x64.reshape(1, groups, ns, -1).permute(0, 3, 1, 2)
+    for layer in mlp64:
+        t = layer(t)
+    return t.max(dim=3)[0][0].t()                               # (groups, C)
+
+
+@pytest.mark.parametrize('groups,ns,spec', [(512, 32, [4, 64, 64, 128]), (96, 64, [132, 128, 128, 256]),
+                                            (3, 128, [260, 256, 512, 1024]), (40, 16, [8, 32, 64])])
+def test_shared_mlp_max_matches_torch_fp64(groups, ns, spec):
+    from point_dae_amd import sa_mlp
+    mlp = _level(spec, groups)
+    mlp64 = copy.deepcopy(mlp).double()
+    g = torch.Generator(device='cuda').manual_seed(ns)
+    x = torch.randn(groups * ns, spec[0], device='cuda', generator=g).requires_grad_()
+    x64 = x.detach().double().requires_grad_()
+    go = torch.randn(groups, spec[-1], device='cuda', generator=g)
+    out = sa_mlp.shared_mlp_max(x, list(mlp), ns)
+    out.backward(go)
+    ref = _reference(x64, mlp64, groups, ns)
+    ref.backward(go.double())
+    _close(out, ref, 2e-5)
+    _close(x.grad, x64.grad, 2e-4)
+    for (n, a), (_, b) in zip(mlp.named_parameters(), mlp64.named_parameters()):
+        _close(a.grad, b.grad, 2e-4)
+    for (n, a), (_, b) in zip(mlp.named_buffers(), mlp64.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a.double(), b, rtol=1e-4, atol=1e-6), n
+        else:
+            assert int(a) == int(b), n
+
+
+def test_group_max_kernels():
+    from point_dae_amd import _lib
+    G, ns, C = 37, 64, 128
+    g = torch.Generator(device='cuda').manual_seed(1)
+    y = torch.randn(G * ns, C, device='cuda', generator=g)
+    sc = torch.randn(C, device='cuda', generator=g)              # both signs
+    sh = torch.randn(C, device='cuda', generator=g) * 0.2
+    out = torch.empty(G, C, device='cuda')
+    arg = torch.empty(G, C, device='cuda', dtype=torch.uint8)
+    _lib.call('pdae_bnrelu_group_max', y, G, ns, C, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(),
+              arg.data_ptr())
+    a = torch.relu(y * sc + sh).view(G, ns, C)
+    want, widx = a.max(dim=1)
+    assert torch.equal(out, want)
+    # ties (rows clamped to 0): the first index wins
+    first = (a == want.unsqueeze(1)).float().argmax(dim=1)
+    assert torch.equal(arg.long(), first)
+    go = torch.randn(G, C, device='cuda', generator=g)
+    dense = torch.full((G * ns, C), float('nan'), device='cuda')
+    _lib.call('pdae_group_max_scatter_n', y, G, ns, C, go.data_ptr(), arg.data_ptr(), dense.data_ptr())
+    want_d = torch.zeros(G, ns, C, device='cuda').scatter_(1, arg.long().unsqueeze(1), go.unsqueeze(1))
+    assert torch.equal(dense.view(G, ns, C), want_d)
