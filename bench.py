@@ -65,7 +65,7 @@ def parse():
     p.add_argument('--split', default='auto', choices=['auto', 'on', 'off'],
                    help='two-phase graphed step with the all-reduce under the embedder backward (auto: when ranks > 1)')
     p.add_argument('--no-also', action='store_true', help='skip the geometry-kernel rooflines and the cfg2 leg')
-    p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 leg')
+    p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 and published-variant legs')
     return p.parse_args()
 
 
@@ -169,6 +169,48 @@ def cfg2_leg(args, device, rank):
                          'achieved': pairs * 9 / (us * 1e-6) / 1e12, 'peak': VALU_F32_PEAK_TOPS, 'unit': 'T op/s',
                          'frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),
                          'hbm_frac': B * (12 * (16384 + N) + 8 * (16384 + N)) / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)}}
+
+
+def published_leg(args, device, rank):
+    """The published Transformer variant (`--model_name PointCAE_transformer_fc_global_folding_local`, SURVEY F5 /
+    row a13: global feature -> FC coarse + two FoldingNet stages per masked token, two Chamfer losses) on the
+    cfg3 YAML, B=128, as a short timed leg -> {value, ms_per_step}."""
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG3))
+    config.model.NAME = 'PointCAE_transformer_fc_global_folding_local'
+    model = FlatDataParallel(builder.model_builder(config.model).to(device), broadcast=False, process_group=None)
+    model.world_size = 1                         # a local leg on rank 0: no collective
+    optimizer, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+    B, N, G = 128, 1024, config.model.num_group
+    x = torch.from_numpy(shapenet_like_clouds(2 * B, N, seed=500 + rank)).to(device).split(B)
+    step = GraphedTrainStep(model, optimizer, config, B, N, split=False)
+    for tvis in range(G - int(0.8 * G), G - int(0.5 * G) + 1):
+        step.pts.copy_(x[0])
+        step._draw()
+        if tvis not in step.graphs:
+            step._capture(tvis)
+    step.eager_left = 0
+    model.zero_grad()
+    for i in range(4):
+        step(x[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.also_steps):
+        out = step(x[i % 2])
+    loss = out[0].detach().clone()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del model, optimizer, step
+    return {'workload': 'cfg3 YAML with --model_name PointCAE_transformer_fc_global_folding_local (the published '
+                        'runs\' model), B=128, N=1024, G=64, full train step, hipGraph replay',
+            'value': B * args.also_steps / dt, 'unit': 'clouds/s', 'ms_per_step': dt / args.also_steps * 1e3,
+            'steps': args.also_steps, 'loss_last_step': float(loss)}
 
 
 def cpu_baseline(config, args):
@@ -414,6 +456,7 @@ def main():
             if world == 1:
                 del step
                 line['also'] = {'cfg2': cfg2_leg(args, device, rank)}
+                line['also']['published_variant'] = published_leg(args, device, rank)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
         print(json.dumps(line), flush=True)

@@ -193,8 +193,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         del d3c
         dbe2, dg2 = S2[0], S2[1]
         # ---- conv3 (split weight)
-        dwl = _empty((c3, c2), x)
-        _lib.call('pdae_linear_backward_weight', x, R, c3, c2, _lib.ptr(d3), _lib.ptr(f), _lib.ptr(dwl), None)
+        dwl = _wgrad(d3, f)          # stream-K grouped kernel, ordered reduction (no atomics)
         dwg = _wgrad(dgb, g)
         db3 = _colsum(dgb)
         dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
