@@ -26,6 +26,9 @@
 //                      bit-identical run to run
 #include <type_traits>
 #include <utility>
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pdae {
@@ -741,6 +744,12 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
   static const int order[] = {3, 1, 2, 6, 4, 0, 5, 7};           // ties go to the smaller tile
   double best = 1e300;
   *cfg = 3, *splits = 1, *stream_blocks = 0;
+#ifdef PDAE_LAB_PLAN
+  // lab: PDAE_ROWS_FORCE="cfg,splits,stream" (-1 = planned) overrides the plan of every call
+  static const char* force = getenv("PDAE_ROWS_FORCE");
+  int fc = -1, fs = -1, fb = -1;
+  if (force) sscanf(force, "%d,%d,%d", &fc, &fs, &fb);
+#endif
   for (int c : order)
     for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
       if (s > 1 && K / s < 128) continue;
@@ -762,6 +771,10 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
       break;
     }
   }
+#ifdef PDAE_LAB_PLAN
+  if (fc >= 0) *cfg = fc, *splits = 1, *stream_blocks = 0;
+  if (fs == 0) *splits = 1, *stream_blocks = 0;      // "x,0,x": no split / stream-K anywhere
+#endif
 }
 
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
