@@ -306,6 +306,17 @@ int pdae_bnrelu_group_max(long long G, int ns, int C, const float* y, const floa
                           const float* shift, float* out, unsigned char* arg, pdae_stream_t stream);
 int pdae_group_max_scatter_n(long long G, int ns, int C, const float* grad, const unsigned char* arg,
                              float* dense, pdae_stream_t stream);
+/* pool_bn_backward: ReLU + BatchNorm backward of a level's LAST layer straight through the max-pool:
+ * grad[G][C] = gradient of the pooled output `out`, arg from bnrelu_group_max, y the raw conv output;
+ * -> dy[G*ns][C] = gradient of y, S[2][C] = (dbeta, dgamma).  The gradient of relu(bn(y)) is non-zero
+ * only at the arg-max rows, so the sums gather one y element per (group, channel) and the dense
+ * scatter + two sweeps over it (group_max_scatter_n, bnrelu_backward) are replaced by one read of y
+ * and one write of dy.  Fixed summation order (per-block partials in `workspace`, C/4 must divide 256;
+ * pool_bn_backward_workspace gives its size in floats). */
+long long pdae_pool_bn_backward_workspace(long long G, int C);
+int pdae_pool_bn_backward(long long G, int ns, int C, const float* grad, const unsigned char* arg,
+                          const float* out, const float* y, const float* mean, const float* invstd,
+                          const float* gamma, float* S, float* workspace, float* dy, pdae_stream_t stream);
 
 /* First layer of the FoldingNet stage of Point_CAE_PointNetv2 (csrc/folding.hip;
  * models/PointCAE_pointnetv2.py:157-167: folding2[0] over [grid(2) | coarse point(3) |

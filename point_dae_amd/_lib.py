@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pdae_conv_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_group_max": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_group_max_scatter_n": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_pool_bn_backward": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -77,6 +78,7 @@ _HOST = {
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
     "pdae_fold_input_grad_parts": [_i, _i],
+    "pdae_pool_bn_backward_workspace": [ctypes.c_longlong, _i],
     "pdae_deterministic": [],
 }
 _STR = ("pdae_version", "pdae_last_error")
@@ -109,7 +111,7 @@ def lib():
         for name, argtypes in _HOST.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith('_workspace') and 'wgrad' not in name else ctypes.c_int
         for name in _STR:
             getattr(handle, name).restype = ctypes.c_char_p
         _lib = handle

@@ -95,3 +95,142 @@ extern "C" int pdae_group_max_scatter_n(long long G, int ns, int C, const float*
                      reinterpret_cast<float4*>(dense));
   return check_launch("group_max_scatter_n");
 }
+
+// ---- BatchNorm + ReLU backward THROUGH the max-pool (the last layer of a level) ----------------
+// The gradient of a = relu(bn(y)) is non-zero only at the arg-max row of every (group, channel), so
+// the dense form (scatter G*ns x C, then two sweeps over it) reads and writes mostly zeros.  Here
+//   pool_bn_reduce : S1[c] = sum_g t, S2[c] = sum_g t * xhat(y[g*ns + arg][c]),  t = grad[g][c] * (a > 0)
+//                    -- reads grad / arg / out and gathers ONE y element per (g, c); block partials
+//                    in fixed order, then plain stores of the per-block sums (no atomics)
+//   pool_bn_apply  : dy[g*ns + j][c] = gamma*invstd * ((j == arg) ? t : 0 - S1/R - xhat * S2/R)
+//                    -- one read of y, one write of dy
+namespace pdae {
+
+constexpr int PB_GROUPS = 256;   // groups per block of the reduction
+
+__global__ __launch_bounds__(256) void pool_bn_reduce_kernel(long long G, int ns, int C4,
+                                                             const float4* __restrict__ grad,
+                                                             const uchar4* __restrict__ arg,
+                                                             const float4* __restrict__ out,
+                                                             const float* __restrict__ y,
+                                                             const float4* __restrict__ mean,
+                                                             const float4* __restrict__ invstd,
+                                                             float4* __restrict__ part) {
+  extern __shared__ float4 pb_red[];                 // [phases][2][C4]
+  const int PH = 256 / C4;
+  const int q = threadIdx.x % C4, ph = threadIdx.x / C4;
+  const long long g0 = (long long)blockIdx.x * PB_GROUPS;
+  const long long g1 = g0 + PB_GROUPS < G ? g0 + PB_GROUPS : G;
+  const float4 mu = mean[q], is = invstd[q];
+  const int C = C4 * 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (long long g = g0 + ph; g < g1; g += PH) {
+    const float4 d = grad[g * C4 + q];
+    const float4 o = out[g * C4 + q];                // the pooled relu(bn(y)): > 0 <=> the ReLU passed
+    const uchar4 a = arg[g * C4 + q];
+    const float* base = y + (size_t)g * ns * C + q * 4;
+    const float yx = base[(size_t)a.x * C + 0], yy = base[(size_t)a.y * C + 1];
+    const float yz = base[(size_t)a.z * C + 2], yw = base[(size_t)a.w * C + 3];
+    const float tx = o.x > 0.f ? d.x : 0.f, ty = o.y > 0.f ? d.y : 0.f;
+    const float tz = o.z > 0.f ? d.z : 0.f, tw = o.w > 0.f ? d.w : 0.f;
+    s1.x += tx, s1.y += ty, s1.z += tz, s1.w += tw;
+    s2.x += tx * ((yx - mu.x) * is.x), s2.y += ty * ((yy - mu.y) * is.y);
+    s2.z += tz * ((yz - mu.z) * is.z), s2.w += tw * ((yw - mu.w) * is.w);
+  }
+  pb_red[(ph * 2 + 0) * C4 + q] = s1;
+  pb_red[(ph * 2 + 1) * C4 + q] = s2;
+  __syncthreads();
+  if (ph == 0) {
+    for (int k = 1; k < PH; ++k) {
+      const float4 u = pb_red[(k * 2 + 0) * C4 + q], v = pb_red[(k * 2 + 1) * C4 + q];
+      s1.x += u.x, s1.y += u.y, s1.z += u.z, s1.w += u.w;
+      s2.x += v.x, s2.y += v.y, s2.z += v.z, s2.w += v.w;
+    }
+    part[((size_t)blockIdx.x * 2 + 0) * C4 + q] = s1;
+    part[((size_t)blockIdx.x * 2 + 1) * C4 + q] = s2;
+  }
+}
+
+// S[2][C] = sum of the P partial sets, in order
+__global__ __launch_bounds__(256) void pool_bn_finish_kernel(int P, int n, const float* __restrict__ part,
+                                                             float* __restrict__ S) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.f;
+  for (int p = 0; p < P; ++p) t += part[(size_t)p * n + i];
+  S[i] = t;
+}
+
+__global__ __launch_bounds__(256) void pool_bn_apply_kernel(long long G, int ns, int C4, float inv_rows,
+                                                            const float4* __restrict__ grad,
+                                                            const uchar4* __restrict__ arg,
+                                                            const float4* __restrict__ out,
+                                                            const float4* __restrict__ y,
+                                                            const float4* __restrict__ mean,
+                                                            const float4* __restrict__ invstd,
+                                                            const float4* __restrict__ gamma,
+                                                            const float4* __restrict__ S,
+                                                            float4* __restrict__ dy) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * C4) return;
+  const long long g = i / C4;
+  const int q = (int)(i - g * C4);
+  const float4 mu = mean[q], is = invstd[q], ga = gamma[q], s1 = S[q], s2 = S[C4 + q];
+  const float4 d = grad[i], o = out[i];
+  const uchar4 a = arg[i];
+  const float tx = o.x > 0.f ? d.x : 0.f, ty = o.y > 0.f ? d.y : 0.f;
+  const float tz = o.z > 0.f ? d.z : 0.f, tw = o.w > 0.f ? d.w : 0.f;
+  const float kx = ga.x * is.x, ky = ga.y * is.y, kz = ga.z * is.z, kw = ga.w * is.w;
+  const float m1x = s1.x * inv_rows, m1y = s1.y * inv_rows, m1z = s1.z * inv_rows, m1w = s1.w * inv_rows;
+  const float m2x = s2.x * inv_rows, m2y = s2.y * inv_rows, m2z = s2.z * inv_rows, m2w = s2.w * inv_rows;
+  const float4* row = y + g * ns * C4 + q;
+  float4* drow = dy + g * ns * C4 + q;
+#pragma unroll 8
+  for (int j = 0; j < ns; ++j) {
+    const float4 v = row[(long long)j * C4];
+    float4 r;
+    r.x = kx * ((a.x == j ? tx : 0.f) - m1x - ((v.x - mu.x) * is.x) * m2x);
+    r.y = ky * ((a.y == j ? ty : 0.f) - m1y - ((v.y - mu.y) * is.y) * m2y);
+    r.z = kz * ((a.z == j ? tz : 0.f) - m1z - ((v.z - mu.z) * is.z) * m2z);
+    r.w = kw * ((a.w == j ? tw : 0.f) - m1w - ((v.w - mu.w) * is.w) * m2w);
+    drow[(long long)j * C4] = r;
+  }
+}
+
+}  // namespace pdae
+
+extern "C" long long pdae_pool_bn_backward_workspace(long long G, int C) {
+  return ((G + pdae::PB_GROUPS - 1) / pdae::PB_GROUPS) * 2 * (long long)C;
+}
+
+extern "C" int pdae_pool_bn_backward(long long G, int ns, int C, const float* grad, const unsigned char* arg,
+                                     const float* out, const float* y, const float* mean, const float* invstd,
+                                     const float* gamma, float* S, float* workspace, float* dy,
+                                     pdae_stream_t stream) {
+  int rc = check_sa("pool_bn_backward: 1 <= nsample <= 256, C a positive multiple of 4", G, ns, C);
+  if (rc) return rc;
+  if (256 % (C / 4) != 0 || C > 1024) return unsupported("pool_bn_backward: C/4 must divide 256");
+  if (!S) return bad_arg("pool_bn_backward: null pointer");
+  hipStream_t s = as_stream(stream);
+  if (G == 0) {
+    (void)hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)C, s);
+    return check_launch("pool_bn_backward");
+  }
+  if (!grad || !arg || !out || !y || !mean || !invstd || !gamma || !workspace || !dy)
+    return bad_arg("pool_bn_backward: null pointer");
+  const int C4 = C / 4;
+  const int P = (int)((G + PB_GROUPS - 1) / PB_GROUPS);
+  hipLaunchKernelGGL(pool_bn_reduce_kernel, dim3(P), dim3(256), sizeof(float4) * 2 * 256, s, G, ns, C4,
+                     reinterpret_cast<const float4*>(grad), reinterpret_cast<const uchar4*>(arg),
+                     reinterpret_cast<const float4*>(out), y, reinterpret_cast<const float4*>(mean),
+                     reinterpret_cast<const float4*>(invstd), reinterpret_cast<float4*>(workspace));
+  hipLaunchKernelGGL(pool_bn_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, P, 2 * C, workspace, S);
+  const long long n = G * C4;
+  hipLaunchKernelGGL(pool_bn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, ns, C4,
+                     1.0f / (float)(G * ns), reinterpret_cast<const float4*>(grad),
+                     reinterpret_cast<const uchar4*>(arg), reinterpret_cast<const float4*>(out),
+                     reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(mean),
+                     reinterpret_cast<const float4*>(invstd), reinterpret_cast<const float4*>(gamma),
+                     reinterpret_cast<const float4*>(S), reinterpret_cast<float4*>(dy));
+  return check_launch("pool_bn_backward");
+}

@@ -52,7 +52,7 @@ class SharedMLPMaxFunction(torch.autograd.Function):
         arg = _empty((G, C), x, torch.uint8)
         _lib.call('pdae_bnrelu_group_max', x, G, ns, C, _lib.ptr(inp), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(out),
                   _lib.ptr(arg))
-        ctx.save_for_backward(x, arg, *ws, *gammas, *ys, *[t for a in affs for t in a])
+        ctx.save_for_backward(x, arg, out, *ws, *gammas, *ys, *[t for a in affs for t in a])
         ctx.ns, ctx.nl = ns, len(ws)
         return out
 
@@ -60,24 +60,35 @@ class SharedMLPMaxFunction(torch.autograd.Function):
     def backward(ctx, dout):
         t = ctx.saved_tensors
         nl, ns = ctx.nl, ctx.ns
-        x, arg = t[0], t[1]
+        x, arg, out = t[0], t[1], t[2]
+        t = t[1:]
         ws, gammas, ys = t[2:2 + nl], t[2 + nl:2 + 2 * nl], t[2 + 2 * nl:2 + 3 * nl]
         flat = t[2 + 3 * nl:]
         affs = [flat[4 * i:4 * i + 4] for i in range(nl)]
         R = x.shape[0]
         G, C = R // ns, ws[-1].shape[0]
-        d = _empty((R, C), x)
-        _lib.call('pdae_group_max_scatter_n', x, G, ns, C, _lib.ptr(dout.contiguous()), _lib.ptr(arg), _lib.ptr(d))
         grads = [None] * (3 * nl)
         dx = None
+        d = _empty((R, C), x)
+        dout = dout.contiguous()
+        fused_pool = 256 % (C // 4) == 0 and C <= 1024
+        if not fused_pool:
+            _lib.call('pdae_group_max_scatter_n', x, G, ns, C, _lib.ptr(dout), _lib.ptr(arg), _lib.ptr(d))
         for l in range(nl - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
             N = ws[l].shape[0]
             S = _empty((2, N), x)
-            # d <- gradient of the raw conv output y_l (ReLU mask, BatchNorm backward), in place
-            _lib.call('pdae_bnrelu_backward', x, R // 32, N, _lib.ptr(d), _lib.ptr(ys[l]), _lib.ptr(sc), _lib.ptr(sh),
-                      _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gammas[l]), _lib.ptr(S), None, R // 32, None, None,
-                      None)
+            if l == nl - 1 and fused_pool:
+                # straight through the max-pool: the gradient is non-zero only at the arg-max rows
+                wsp = _empty((max(_lib.lib().pdae_pool_bn_backward_workspace(G, C), 1),), x)
+                _lib.call('pdae_pool_bn_backward', x, G, ns, C, _lib.ptr(dout), _lib.ptr(arg), _lib.ptr(out),
+                          _lib.ptr(ys[l]), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gammas[l]), _lib.ptr(S),
+                          _lib.ptr(wsp), _lib.ptr(d))
+            else:
+                # d <- gradient of the raw conv output y_l (ReLU mask, BatchNorm backward), in place
+                _lib.call('pdae_bnrelu_backward', x, R // 32, N, _lib.ptr(d), _lib.ptr(ys[l]), _lib.ptr(sc),
+                          _lib.ptr(sh), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gammas[l]), _lib.ptr(S), None,
+                          R // 32, None, None, None)
             grads[3 * l + 1], grads[3 * l + 2] = S[1], S[0]                   # dgamma, dbeta
             if l > 0:
                 psc, psh = affs[l - 1][0], affs[l - 1][1]

@@ -423,7 +423,7 @@ def test_graphed_static_step_equals_eager_step():
     assert step.graph is not None
     # the first steps see (almost) identical parameters; AdamW then amplifies the fp32 atomics-order noise
     for i, ((a0, a1), (b0, b1)) in enumerate(zip(eager, graphed)):
-        tol = 1e-4 if i < 2 else 1e-2
+        tol = 5e-4 if i < 2 else 1e-2      # (max-pool ties: one re-routed gradient element moves the loss by ~2e-4)
         assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (i, eager, graphed)
     assert (model_a.flat_param - model_b.flat_param).abs().max().item() < 2e-2
 

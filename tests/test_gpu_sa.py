@@ -83,3 +83,42 @@ def test_group_max_kernels():
     _lib.call('pdae_group_max_scatter_n', y, G, ns, C, go.data_ptr(), arg.data_ptr(), dense.data_ptr())
     want_d = torch.zeros(G, ns, C, device='cuda').scatter_(1, arg.long().unsqueeze(1), go.unsqueeze(1))
     assert torch.equal(dense.view(G, ns, C), want_d)
+
+
+@pytest.mark.parametrize('G,ns,C', [(300, 32, 128), (70, 64, 256), (5, 128, 1024), (1000, 16, 64)])
+def test_pool_bn_backward_equals_dense_form(G, ns, C):
+    """pool_bn_backward (through the max-pool) == group_max_scatter_n + bnrelu_backward (dense), and twice the
+    same bits."""
+    from point_dae_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(G)
+    R = G * ns
+    y = torch.randn(R, C, device='cuda', generator=g)
+    gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+    gamma[::7] *= -1                                               # negative scales too
+    beta = torch.randn(C, device='cuda', generator=g) * 0.3
+    mean = y.mean(0)
+    invstd = torch.rsqrt(y.var(0, unbiased=False) + 1e-5)
+    sc = (gamma * invstd).contiguous()
+    sh = (beta - mean * sc).contiguous()
+    out = torch.empty(G, C, device='cuda')
+    arg = torch.empty(G, C, device='cuda', dtype=torch.uint8)
+    _lib.call('pdae_bnrelu_group_max', y, G, ns, C, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(),
+              arg.data_ptr())
+    go = torch.randn(G, C, device='cuda', generator=g)
+    # dense form
+    d = torch.empty(R, C, device='cuda')
+    _lib.call('pdae_group_max_scatter_n', y, G, ns, C, go.data_ptr(), arg.data_ptr(), d.data_ptr())
+    S_d = torch.empty(2, C, device='cuda')
+    _lib.call('pdae_bnrelu_backward', y, R // 32, C, d.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+              mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), S_d.data_ptr(), None, R // 32, None, None, None)
+    res = []
+    for _ in range(2):
+        S = torch.full((2, C), float('nan'), device='cuda')
+        dy = torch.full((R, C), float('nan'), device='cuda')
+        ws = torch.empty(max(_lib.lib().pdae_pool_bn_backward_workspace(G, C), 1), device='cuda')
+        _lib.call('pdae_pool_bn_backward', y, G, ns, C, go.data_ptr(), arg.data_ptr(), out.data_ptr(), y.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), S.data_ptr(), ws.data_ptr(), dy.data_ptr())
+        res.append((S, dy))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    _close(res[0][0], S_d, 2e-5)
+    _close(res[0][1], d, 2e-5)
