@@ -423,7 +423,10 @@ def test_graphed_static_step_equals_eager_step():
     assert step.graph is not None
     # the first steps see (almost) identical parameters; AdamW then amplifies the fp32 atomics-order noise
     for i, ((a0, a1), (b0, b1)) in enumerate(zip(eager, graphed)):
-        tol = 5e-4 if i < 2 else 1e-2      # (max-pool ties: one re-routed gradient element moves the loss by ~2e-4)
+        # step 0 sees identical parameters (forward only: 1e-5); from step 1 on the runs differ by what the
+        # set-abstraction max-pool ties do to one step's gradients (tie sensitivity: an LDS-atomic
+        # order flips a tied arg-max and re-routes a gradient element; measured 2e-4..6e-4 on the next loss)
+        tol = 1e-5 if i == 0 else (2e-3 if i < 2 else 1e-2)
         assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (i, eager, graphed)
     assert (model_a.flat_param - model_b.flat_param).abs().max().item() < 2e-2
 
