@@ -405,10 +405,20 @@ def main():
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
                       'timed hipGraph region' % args.probe_steps)
     nn_ops.set_probe(None)
+    in_sync = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # data-parallel sanity after the timed steps: every replica must hold bit-identical parameters
+        # (same broadcast start, same averaged gradients, same update) -- max and min over ranks of a
+        # checksum pair agree exactly or the collective path is broken
+        flat = model.flat_param
+        chk = torch.stack([flat.double().sum(), flat.double().abs().sum(), flat[::1009].double().pow(2).sum()])
+        hi, lo = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool(torch.equal(hi, lo)) and bool(torch.isfinite(chk).all())
 
     if rank == 0:
         clouds_per_s = args.batch * world * args.steps / elapsed
@@ -451,6 +461,8 @@ def main():
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
+        if world > 1:
+            line['replicas_in_sync'] = in_sync          # parameters bit-identical on all ranks after the timed steps
         if args.workload == 'cfg3' and not args.no_also:
             line['roofline_geometry'] = geometry_rooflines(args, clouds)
             if world == 1:

@@ -118,6 +118,7 @@ def test_bench_two_ranks_code_path(launcher):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 16 and d['scaling'] == 'weak'
+    assert d['replicas_in_sync'] is True and d['config']['grad_allreduce'].startswith('Transformer slice')
     assert d['value'] > 0 and d['roofline'] is not None and 'cpu_baseline' not in d
     assert d['rccl_ranks'] == 0          # gloo ranks: not an RCCL measurement, and the line says so
 
