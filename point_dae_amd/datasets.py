@@ -31,6 +31,9 @@ from .synthetic import labelled_clouds, shapenet_like_clouds
 
 AFFINE = ('translate', 'scale_nonorm', 'rotate', 'reflection', 'shear')
 _PASS = ('clean', 'dropout_patch_pointmae', 'Drop-Patch')
+_AUGS = ('clean', 'norm', 'scale', 'translate', 'rotate_z', 'rotate')          # corrupt_util.augment_data :1155-1175
+_CORRUPTIONS = ('affine_r3', 'dropout_local') + AFFINE + ('rotate_z', 'scale', 'jitter', 'add_global',
+                                                          'nonuniform_density')
 
 
 def pc_normalize(x):
@@ -40,37 +43,77 @@ def pc_normalize(x):
     return x / m.view(-1, 1, 1)
 
 
-def draw_affine_r3(rng, B):
-    """'affine_r3' of corrupt_util.corrupt_data (:1062-1070) for B clouds: per cloud 1-3 distinct maps of
-    AFFINE in random order, each x -> x A (+ t) with the numpy versions' parameters (translate ADDS
-    U(-.5,.5)^3 :130-141, scale U(.5,2)^3 :82-93, rotate Rz Ry Rx with angles U(-pi,pi) :241-263,
-    reflection diag(+-1) :390-409, shear U(-.5,.5) off-diagonals :412-428).  -> A (B,3,3), t (B,3)
-    with y = x @ A + t (the composition of the chosen maps)."""
+def _rot(a):
+    Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+    Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+    Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def draw_affine_map(rng, name):
+    """One map x -> x M + tr with the numpy versions' parameters (corrupt_util.py): 'translate' ADDS
+    U(-.5,.5)^3 (:130-141), 'scale_nonorm' U(.5,2)^3 (:82-93), 'rotate' Rz Ry Rx with angles U(-pi,pi)
+    (:241-263), 'rotate_z' (:537-570), 'reflection' diag(+-1) (:390-409), 'shear' U(-.5,.5) off-diagonals
+    (:412-428); the augmentations 'aug_scale' U(2/3,3/2)^3 (:1105-1108), 'aug_translate' U(-.2,.2)^3
+    (:1110-1112)."""
+    M, tr = np.eye(3), np.zeros(3)
+    if name == 'translate':
+        tr = rng.uniform(-0.5, 0.5, 3)
+    elif name == 'aug_translate':
+        tr = rng.uniform(-0.2, 0.2, 3)
+    elif name == 'scale_nonorm':
+        M = np.diag(rng.uniform(0.5, 2.0, 3))
+    elif name == 'aug_scale':
+        M = np.diag(rng.uniform(2.0 / 3.0, 1.5, 3))
+    elif name == 'rotate':
+        M = _rot(rng.uniform(-math.pi, math.pi, 3))
+    elif name == 'rotate_z':
+        a = rng.uniform(-math.pi, math.pi)
+        M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    elif name == 'reflection':
+        M = np.diag(rng.choice(np.array([1.0, -1.0]), 3))
+    elif name == 'shear':
+        s = rng.uniform(-0.5, 0.5, 6)
+        M = np.array([[1, s[0], s[1]], [s[2], 1, s[3]], [s[4], s[5], 1]])
+    else:
+        raise NotImplementedError(name)
+    return M, tr
+
+
+def draw_affine(rng, B, names_of):
+    """Per cloud the composition of the maps `names_of(rng)` lists -> A (B,3,3), t (B,3), y = x @ A + t."""
     A = np.tile(np.eye(3), (B, 1, 1))
     t = np.zeros((B, 3))
     for b in range(B):
-        number = int(rng.integers(1, 4))
-        for name in rng.choice(len(AFFINE), size=number, replace=False):
-            name = AFFINE[int(name)]
-            M, tr = np.eye(3), np.zeros(3)
-            if name == 'translate':
-                tr = rng.uniform(-0.5, 0.5, 3)
-            elif name == 'scale_nonorm':
-                M = np.diag(rng.uniform(0.5, 2.0, 3))
-            elif name == 'rotate':
-                a = rng.uniform(-math.pi, math.pi, 3)
-                Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
-                Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
-                Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
-                M = Rz @ Ry @ Rx
-            elif name == 'reflection':
-                M = np.diag(rng.choice(np.array([1.0, -1.0]), 3))
-            else:
-                s = rng.uniform(-0.5, 0.5, 6)
-                M = np.array([[1, s[0], s[1]], [s[2], 1, s[3]], [s[4], s[5], 1]])
+        for name in names_of(rng):
+            M, tr = draw_affine_map(rng, name)
             A[b] = A[b] @ M                  # y = (x A + t) M + tr
             t[b] = t[b] @ M + tr
     return A.astype(np.float32), t.astype(np.float32)
+
+
+def draw_affine_r3(rng, B):
+    """'affine_r3' of corrupt_util.corrupt_data (:1062-1070) for B clouds: per cloud 1-3 distinct maps of
+    AFFINE in random order."""
+    def names(r):
+        number = int(r.integers(1, 4))
+        return [AFFINE[int(i)] for i in r.choice(len(AFFINE), size=number, replace=False)]
+    return draw_affine(rng, B, names)
+
+
+def apply_affine(x, A, t):
+    """y = x A + t per cloud without a batched GEMM: three broadcast multiply-adds."""
+    A, t = torch.from_numpy(A).to(x.device), torch.from_numpy(t).to(x.device)
+    return (x[..., 0:1] * A[:, None, 0, :] + x[..., 1:2] * A[:, None, 1, :]) + (x[..., 2:3] * A[:, None, 2, :] + t[:, None, :])
+
+
+def sphere_points(rng, B, n):
+    """n points uniform in the unit ball per cloud (corrupt_util._sample_points_inside_unit_sphere :42-56)."""
+    r = np.power(rng.uniform(0.0, 1.0, (B, n, 1)), 1.0 / 3.0)
+    theta = np.arccos(rng.uniform(-1.0, 1.0, (B, n, 1)))
+    phi = rng.uniform(0.0, 2.0 * np.pi, (B, n, 1))
+    return np.concatenate([r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta)],
+                          axis=2).astype(np.float32)
 
 
 def draw_dropout_local(rng, B, P):
@@ -154,11 +197,11 @@ class ShapeNet:
         self.pc_path, self.data_path = config.get('PC_PATH'), config.get('DATA_PATH')
         self.whole = bool(config.get('whole', False))
         for item in self.corrupt_type:
-            if not (item in _PASS or 'dropout_global' in item or item in ('affine_r3', 'dropout_local')):
-                raise NotImplementedError('loader-side corruption %r (implemented: affine_r3, dropout_local)' % item)
+            if not (item in _PASS or 'dropout_global' in item or item in _CORRUPTIONS):
+                raise NotImplementedError('loader-side corruption %r (implemented: %s)' % (item, ', '.join(_CORRUPTIONS)))
         for item in self.aug_type:
-            if item not in ('clean', 'norm'):
-                raise NotImplementedError('augmentation %r (implemented: norm)' % item)
+            if item not in _AUGS:
+                raise NotImplementedError('augmentation %r (implemented: %s)' % (item, ', '.join(_AUGS)))
         self.rng = np.random.default_rng(self.seed)
         self.gen = None
         self._clouds, self.ids = None, None
@@ -182,21 +225,45 @@ class ShapeNet:
     def batch(self, index):
         """-> (corrupted (B,npoints,3), clean (B,npoints,3)) on the device."""
         x = self._clouds.index_select(0, index)
-        if 'norm' in self.aug_type:
-            x = pc_normalize(x)
+        B = x.shape[0]
+        for item in self.aug_type:                                  # in the configured order (:1157-1173)
+            if item == 'norm':
+                x = pc_normalize(x)
+            elif item in ('scale', 'translate'):
+                x = apply_affine(x, *draw_affine(self.rng, B, lambda r, n='aug_' + item: [n]))
+            elif item in ('rotate_z', 'rotate'):
+                x = apply_affine(x, *draw_affine(self.rng, B, lambda r, n=item: [n]))
         B, P, _ = x.shape
         clean = random_subset(x, self.npoints, generator=self.gen)
         y, alive, touched = x, None, False
         for item in self.corrupt_type:
+            if item in _PASS or 'dropout_global' in item:
+                continue                                            # applied in the model's forward
+            touched = True
             if item == 'affine_r3':
-                A, t = draw_affine_r3(self.rng, B)
-                A, t = torch.from_numpy(A).to(x.device), torch.from_numpy(t).to(x.device)
-                # y = x A + t without a batched GEMM: three broadcast multiply-adds
-                y = (y[..., 0:1] * A[:, None, 0, :] + y[..., 1:2] * A[:, None, 1, :]) + (y[..., 2:3] * A[:, None, 2, :] + t[:, None, :])
-                touched = True
+                y = apply_affine(y, *draw_affine_r3(self.rng, B))
+            elif item in AFFINE or item == 'rotate_z':
+                y = apply_affine(y, *draw_affine(self.rng, B, lambda r, n=item: [n]))
+            elif item == 'scale':                                   # U(.5,2)^3 then re-normalised (:59-69)
+                y = pc_normalize(apply_affine(y, *draw_affine(self.rng, B, lambda r: ['scale_nonorm'])))
+            elif item == 'jitter':                                  # sigma = 0.01 (level + 1), level U(0,4) (:179-191)
+                sigma = torch.from_numpy((0.01 * (self.rng.uniform(0.0, 4.0, (B, 1, 1)) + 1.0)).astype(np.float32))
+                y = y + sigma.to(y.device) * torch.randn(y.shape, device=y.device, generator=self.gen)
+            elif item == 'add_global':                              # +50 % points uniform in the unit ball (:830-841, level 4)
+                extra = torch.from_numpy(sphere_points(self.rng, B, int(y.shape[1] * 0.5))).to(y.device)
+                y = torch.cat([y, extra], dim=1)
+                if alive is not None:
+                    alive = torch.cat([alive, torch.ones(extra.shape[:2], dtype=torch.bool, device=y.device)], dim=1)
+            elif item == 'nonuniform_density':                      # distance-gated drop from a random viewpoint (:875-897)
+                gate = torch.from_numpy((self.rng.uniform(0.0, 4.0, (B, 1)) / 4.0 + 0.1).astype(np.float32)).to(y.device)
+                v = self.rng.normal(0.0, 1.0, (B, 3))
+                v = torch.from_numpy((v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)).to(y.device)
+                dist = (y - v[:, None, :]).square().sum(-1).sqrt() / 2.0        # (d - (|v| - 1)) / 2 with |v| = 1
+                keep = dist * gate < torch.rand(dist.shape, device=y.device, generator=self.gen)
+                alive = keep if alive is None else (alive & keep)
             elif item == 'dropout_local':
-                alive = dropout_local(y.contiguous(), *draw_dropout_local(self.rng, B, P))
-                touched = True
+                keep = dropout_local(y.contiguous(), *draw_dropout_local(self.rng, B, y.shape[1]))
+                alive = keep if alive is None else (alive & keep)
         corrupted = random_subset(y, self.npoints, alive, self.gen) if touched else clean
         return corrupted, clean
 

@@ -40,9 +40,29 @@ def test_unimplemented_loader_corruption_is_refused():
     """A corrupt_type the device pipeline does not implement must raise, never train on clean == corrupted."""
     from point_dae_amd.datasets import ShapeNet
     with pytest.raises(NotImplementedError):
-        ShapeNet({'corrupt_type': ['jitter'], 'device': 'cpu'})
+        ShapeNet({'corrupt_type': ['add_local'], 'device': 'cpu'})
     with pytest.raises(NotImplementedError):
-        ShapeNet({'aug_type': ['rotate'], 'device': 'cpu'})
+        ShapeNet({'aug_type': ['jitter'], 'device': 'cpu'})
+
+
+def test_single_map_draws():
+    """the parameter ranges of corrupt_util.py's single maps and of the scale / translate augmentations"""
+    from point_dae_amd.datasets import draw_affine, sphere_points
+    rng = np.random.default_rng(1)
+    for name, check in [
+            ('aug_scale', lambda A, t: (np.diagonal(A, axis1=1, axis2=2) >= 2 / 3 - 1e-6).all() and (np.diagonal(A, axis1=1, axis2=2) <= 1.5 + 1e-6).all() and (t == 0).all()),
+            ('aug_translate', lambda A, t: (np.abs(t) <= 0.2 + 1e-6).all() and np.allclose(A, np.eye(3))),
+            ('translate', lambda A, t: (np.abs(t) <= 0.5 + 1e-6).all() and np.abs(t).max() > 0.2),
+            ('scale_nonorm', lambda A, t: (np.diagonal(A, axis1=1, axis2=2) >= 0.5 - 1e-6).all() and (np.diagonal(A, axis1=1, axis2=2) <= 2 + 1e-6).all()),
+            ('rotate', lambda A, t: np.allclose(A @ A.transpose(0, 2, 1), np.eye(3), atol=1e-5) and np.allclose(np.linalg.det(A), 1, atol=1e-5)),
+            ('rotate_z', lambda A, t: np.allclose(A[:, 2, 2], 1) and np.allclose(A @ A.transpose(0, 2, 1), np.eye(3), atol=1e-5)),
+            ('reflection', lambda A, t: np.allclose(np.abs(A), np.eye(3))),
+            ('shear', lambda A, t: np.allclose(np.diagonal(A, axis1=1, axis2=2), 1) and np.abs(A - np.eye(3)).max() <= 0.5 + 1e-6)]:
+        A, t = draw_affine(rng, 200, lambda r, n=name: [n])
+        assert check(A, t), name
+    pts = sphere_points(rng, 4, 2000)
+    r = np.linalg.norm(pts, axis=2)
+    assert r.max() <= 1 + 1e-6 and abs((r < 0.5 ** (1 / 3)).mean() - 0.5) < 0.05        # uniform in the ball
 
 
 @pytest.mark.gpu
@@ -90,3 +110,36 @@ def test_device_dataset_end_to_end(tmp_path):
                            'corrupt_type': ['clean']})
     for _, _, corrupted, clean in clean_only:
         assert torch.equal(corrupted, clean)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('aug,cor', [(['norm', 'scale', 'translate'], ['clean']), (['norm'], ['affine_r3', 'jitter']),
+                                     (['norm', 'rotate'], ['dropout_local']), (['norm'], ['add_global']),
+                                     (['norm', 'rotate_z'], ['nonuniform_density']), (['norm'], ['shear']),
+                                     (['norm'], ['scale']), (['norm'], ['add_global', 'dropout_local'])])
+def test_device_dataset_augmentations_and_corruptions(aug, cor):
+    """every loader-side augmentation / corruption the device pipeline implements (the reference's pretrain YAMLs
+    use these names: aug ['norm','scale','translate'] in 25 of them) -> finite (B, npoints, 3) batches with the
+    property the map promises"""
+    import torch
+    from point_dae_amd.datasets import ShapeNet
+    ds = ShapeNet({'npoints': 512, 'N_POINTS': 2048, 'bs': 6, 'steps_per_epoch': 2, 'device': 'cuda', 'seed': 3,
+                   'aug_type': aug, 'corrupt_type': cor})
+    for _, _, corrupted, clean in ds:
+        assert corrupted.shape == (6, 512, 3) and clean.shape == (6, 512, 3)
+        assert torch.isfinite(corrupted).all() and torch.isfinite(clean).all()
+        r = clean.norm(dim=-1).amax(dim=1)
+        if aug == ['norm']:
+            assert (r <= 1 + 1e-5).all()
+        if 'scale' in aug:
+            assert (r <= 1.5 * 1.001 + 0.2 * 3 ** 0.5).all() and (r >= 2 / 3 - 0.2 * 3 ** 0.5 - 1e-3).all()
+        if 'rotate' in aug or 'rotate_z' in aug:
+            assert (r <= 1 + 1e-4).all() and (r >= 0.8).all()                 # rotations keep the unit sphere
+        if cor == ['clean']:
+            assert torch.equal(corrupted, clean)
+        else:
+            assert not torch.equal(corrupted, clean)
+        if cor == ['scale']:
+            assert (corrupted.norm(dim=-1).amax(dim=1) <= 1 + 1e-5).all()       # re-normalised (corrupt_scale)
+        if cor == ['add_global']:
+            assert (corrupted.norm(dim=-1) <= 1 + 1e-5).all()
