@@ -188,3 +188,37 @@ def test_graphed_step_equals_eager_step_exactly(det):
         assert abs(a - b) <= 1e-6 * abs(a), (eager, graphed)
     diff = (model_a.flat_param - model_b.flat_param).abs().max().item()
     assert diff <= 1e-6 * model_a.flat_param.abs().max().item(), diff
+
+
+@pytest.mark.parametrize('name', ['PointCAE_transformer', 'PointCAE_transformer_fc_global_folding_local'])
+def test_two_phase_step_equals_single_phase(det, name):
+    """GraphedTrainStep(split=True) -- graph 1 stops at a leaf copy of the patch tokens, graph 2 is the
+    embedder's backward -- gives the same parameters as the one-graph step, bit for bit, for both
+    Transformer model classes (one rank: the collectives in between are skipped)."""
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(
+        ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.NAME = name
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 2
+    torch.manual_seed(0)
+    net_a = builder.model_builder(config.model).cuda().train()
+    net_b = copy.deepcopy(net_a)
+    B = 8
+    x = torch.from_numpy(shapenet_like_clouds(B * 2, 1024, seed=9)).cuda().split(B)
+    out = []
+    for net, split in ((net_a, False), (net_b, True)):
+        model = FlatDataParallel(net)
+        assert model.late_ranges and model.early_range[1] - model.early_range[0] > 0
+        opt, _ = builder.build_opti_sche(model, config)
+        step = GraphedTrainStep(model, opt, config, B, 1024, warmup_eager=1, split=split)
+        assert step.split == split
+        random.seed(5), np.random.seed(5), torch.manual_seed(5)
+        losses = [step(x[i % 2])[0].item() for i in range(5)]
+        out.append((losses, model.flat_param.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
