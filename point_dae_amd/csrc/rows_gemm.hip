@@ -896,7 +896,12 @@ static int wgrad_layout(int M, int nprob, const int* Ns, const int* Ks, WgradArg
   g->chunks = M > 0 ? (M + WCH - 1) / WCH : 1;
   g->units = (long long)tiles * g->chunks;
   // one residency of the chip: 256 CUs x 2 blocks (32 KB of LDS, 122 registers each)
-  g->blocks = (int)(g->units < 512 ? g->units : 512);
+#ifdef PDAE_LAB_PLAN
+  static const int wg_blocks = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 512;
+#else
+  constexpr int wg_blocks = 512;
+#endif
+  g->blocks = (int)(g->units < wg_blocks ? g->units : wg_blocks);
   const long long len = (g->units + g->blocks - 1) / g->blocks;       // longest range
   g->slots = (int)((len + g->chunks - 2) / g->chunks) + 1;            // tiles a range of `len` units can touch
   return PDAE_OK;
