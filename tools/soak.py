@@ -24,10 +24,10 @@ opt, _ = builder.build_opti_sche(model, cfg)
 model.train()
 model.zero_grad()
 pool = torch.from_numpy(shapenet_like_clouds(B * 16, 1024, seed=7)).to(dev).split(B)
-step = GraphedTrainStep(model, opt, cfg, B, 1024) if mode == 'graph' else None
 if not os.environ.get('SOAK_NULL'):          # SOAK_NULL=1 reproduces the NULL-stream failure
     from point_dae_amd.graph_step import use_created_stream
     use_created_stream()
+step = GraphedTrainStep(model, opt, cfg, B, 1024) if mode == 'graph' else None
 acc = torch.zeros((), device=dev)
 POKE = os.environ.get('SOAK_POKE', '')
 for i in range(steps):
