@@ -122,3 +122,42 @@ def test_pool_bn_backward_equals_dense_form(G, ns, C):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     _close(res[0][0], S_d, 2e-5)
     _close(res[0][1], d, 2e-5)
+
+
+def test_entries_refuse_bad_arguments():
+    """error behaviour of the round-2 entries: status + message, never a launch on bad sizes / null pointers"""
+    from point_dae_amd import _lib
+    x = torch.zeros(64, 8, device='cuda')
+    w = torch.zeros(16, 8, device='cuda')
+    y = torch.zeros(64, 16, device='cuda')
+    st = torch.zeros(8, 2, 16, device='cuda')
+    sc = torch.ones(8, device='cuda')
+    with pytest.raises(RuntimeError, match='multiple of 4'):          # K % 4 != 0
+        _lib.call('pdae_conv_stats', x, 64, 16, 6, x.data_ptr(), None, None, w.data_ptr(), y.data_ptr(), st.data_ptr())
+    with pytest.raises(RuntimeError, match='scale and shift'):
+        _lib.call('pdae_conv_stats', x, 64, 16, 8, x.data_ptr(), sc.data_ptr(), None, w.data_ptr(), y.data_ptr(), st.data_ptr())
+    with pytest.raises(RuntimeError, match='null pointer'):
+        _lib.call('pdae_conv_stats', x, 64, 16, 8, x.data_ptr(), None, None, w.data_ptr(), y.data_ptr(), None)
+    _lib.call('pdae_conv_stats', x, 0, 16, 8, None, None, None, None, None, st.data_ptr())        # M = 0: zeroed statistics
+    assert float(st.abs().sum()) == 0.0
+    out = torch.zeros(2, 16, device='cuda')
+    arg = torch.zeros(2, 16, device='cuda', dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match='nsample'):
+        _lib.call('pdae_bnrelu_group_max', y, 2, 300, 16, y.data_ptr(), sc.data_ptr(), sc.data_ptr(), out.data_ptr(), arg.data_ptr())
+    with pytest.raises(RuntimeError, match='multiple of 4'):
+        _lib.call('pdae_bnrelu_group_max', y, 2, 32, 6, y.data_ptr(), sc.data_ptr(), sc.data_ptr(), out.data_ptr(), arg.data_ptr())
+    with pytest.raises(RuntimeError, match='C/4 must divide 256'):
+        _lib.call('pdae_pool_bn_backward', y, 2, 32, 24, out.data_ptr(), arg.data_ptr(), out.data_ptr(), y.data_ptr(),
+                  sc.data_ptr(), sc.data_ptr(), sc.data_ptr(), st.data_ptr(), st.data_ptr(), y.data_ptr())
+    with pytest.raises(RuntimeError, match='C/4 must divide 256'):
+        _lib.call('pdae_fold_input_grad', y, 1, 2, 4, 24, y.data_ptr(), y.data_ptr(), y.data_ptr())
+    with pytest.raises(RuntimeError, match='positive multiple of 4'):
+        _lib.call('pdae_fold_input', y, 1, 2, 4, 6, y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr())
+    with pytest.raises(RuntimeError, match='needs Z'):                # masking epilogue without the kept output
+        _lib.call('pdae_rows_gemm', x, 64, 16, 8, x.data_ptr(), torch.zeros(8, 16, device='cuda').data_ptr(), 1, None, 4,
+                  None, y.data_ptr(), -1, 1, 0)
+    with pytest.raises(RuntimeError, match=r'\[K,N\] weight'):         # masking epilogue on a forward-layout weight
+        _lib.call('pdae_rows_gemm', x, 64, 16, 8, x.data_ptr(), w.data_ptr(), 0, None, 4, y.data_ptr(), y.data_ptr(), -1, 1, 0)
+    with pytest.raises(RuntimeError, match='1 MiB'):
+        _lib._check(_lib.lib(), 'pdae_set_deterministic', _lib.lib().pdae_set_deterministic(x.data_ptr(), 1024))
+    assert not _lib.deterministic()
