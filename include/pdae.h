@@ -262,7 +262,7 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  *                 the gradient of fc1's output                     (w_kn = 1)
  *              4: Y = Z > 0 ? acc : 0      backward through a ReLU whose output
  *                 Z the forward kept (epi 1, or fold_input): the data gradient
- *                 arrives already masked, relu'(0) = 0 as ATen        (w_kn = 1)
+ *                 arrives already masked, relu'(0) = 0 as ATen  (either layout)
  *       cfg    : tile shape 0..7, or -1 = planned per shape
  *       splits : 1, or S in 2..8 = split the reduction: Y is then S slabs
  *                [S][M][N] of partial products (epi 0, no bias) which the

@@ -861,8 +861,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
     return bad_arg("rows_gemm: this epilogue needs Z");
   if (epi == EPI_BIAS_GELU2 && w_kn) return unsupported("rows_gemm: bias+GELU epilogue on a [K,N] weight");
   if (epi == EPI_BIAS_RELU && w_kn) return unsupported("rows_gemm: bias+ReLU epilogue on a [K,N] weight");
-  if ((epi == EPI_MUL_GELUGRAD || epi == EPI_MUL_POS) && !w_kn)
-    return unsupported("rows_gemm: the masking epilogues (data gradients) take a [K,N] weight");
+  if (epi == EPI_MUL_GELUGRAD && !w_kn) return unsupported("rows_gemm: GELU' epilogue on an [N,K] weight");
   Args a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = w_kn ? N : K, a.C = Y, a.ldc = N;
   a.Z = Z, a.bias = bias, a.slab = (long long)M * N;
@@ -873,6 +872,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   if (!w_kn) {
     if (epi == EPI_STORE) launch_rows<false, EPI_STORE>(a, cfg, splits, stream_blocks, s);
     else if (epi == EPI_BIAS_RELU) launch_rows<false, EPI_BIAS_RELU>(a, cfg, splits, 0, s);
+    else if (epi == EPI_MUL_POS) launch_rows<false, EPI_MUL_POS>(a, cfg, splits, 0, s);
     else launch_rows<false, EPI_BIAS_GELU2>(a, cfg, splits, 0, s);
   } else {
     if (epi == EPI_STORE) launch_rows<true, EPI_STORE>(a, cfg, splits, stream_blocks, s);

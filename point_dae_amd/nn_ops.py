@@ -439,7 +439,9 @@ class _FoldMLP(torch.autograd.Function):
         dy = dy.contiguous()
         d2 = rows_gemm(dy, w3, True, None, 4, h2)                   # gradient of h2's pre-activation
         (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
-        d1 = rows_gemm(d2, w2, True, None, 4, h1)                   # gradient of h1's pre-activation
+        # (the 1.1 TFLOP product of the stage: the [N,K] form of the kernel is 8 % faster than the [K,N] form at
+        #  this size, and transposing the 1 MB weight costs nothing)
+        d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1)  # gradient of h1's pre-activation
         (dw2,), (db2,) = rows_wgrad([d2], [h1], [True])
         del d2
         parts = _lib.lib().pdae_fold_input_grad_parts(clouds, coarse)

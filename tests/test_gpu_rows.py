@@ -213,6 +213,11 @@ def test_rows_gemm_relu_mask_epilogue(M, N, K):
     want = (dy.double() @ w.double()) * (h > 0)
     _close(y, want, 2e-5)
     assert (y[h == 0] == 0).all()
+    y2 = torch.full((M, N), float('nan'), device='cuda')              # the same product from the [N,K] layout
+    wt = w.t().contiguous()
+    L.call('pdae_rows_gemm', dy, M, N, K, dy.data_ptr(), wt.data_ptr(), 0, None, 4, h.data_ptr(), y2.data_ptr(), -1, 1, 0)
+    _close(y2, want, 2e-5)
+    assert (y2[h == 0] == 0).all()
 
 
 @pytest.mark.parametrize('clouds,coarse,cells,C', [(3, 40, 16, 512), (2, 7, 16, 128), (1, 5, 9, 64), (5, 129, 4, 256)])
