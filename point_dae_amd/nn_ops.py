@@ -472,8 +472,7 @@ def linear_any(x, w, b=None, relu=False):
     (the weight is small; an activation is padded only when it is narrow -- wide ones should be built
     padded by the caller, as the set-abstraction grouping does)."""
     if not (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32):
-        y = F.linear(x, w, b)
-        return F.relu(y) if relu else y
+        raise RuntimeError('linear_any: rows must be a 2-D fp32 tensor on the GPU (there is no CPU / library path)')
     N, K = w.shape
     pk, pn = (-K) % 4, (-N) % 4
     if pk:

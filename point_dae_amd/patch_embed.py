@@ -120,7 +120,10 @@ class PatchEmbedFunction(torch.autograd.Function):
                       _lib.ptr(y1), _lib.ptr(st1))
             sc1, sh1, mean1, is1 = _bn_finalize(first_conv[1], R, x, stats64=st1)
         else:
-            y1 = F.linear(x, w1m, b1)
+            y1 = _empty((R, c1), x)                                  # same kernel; its sums go unused in eval mode
+            st1 = torch.zeros(2 * c1, dtype=torch.float64, device=x.device)
+            _lib.call('pdae_embed_conv1_stats', x, R, c1, _lib.ptr(x), _lib.ptr(w1m.contiguous()), _lib.ptr(b1),
+                      _lib.ptr(y1), _lib.ptr(st1))
             sc1, sh1, mean1, is1 = _bn_affine(first_conv[1], None, None, R, False)
         # conv2: BN1+ReLU producer, store f, group max
         f = _empty((R, c2), x)

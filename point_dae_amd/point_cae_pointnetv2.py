@@ -160,7 +160,7 @@ class Point_CAE_PointNetv2(nn.Module):
         g2 = self.grid_size ** 2
         a = nn_ops.linear_any(feature, w[:, 5:].contiguous(), self.folding2[0].bias)        # (B, 512)  once per cloud
         p = nn_ops.linear_any(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
-        gd = F.linear(self.grid, w[:, :2])                                     # (16, 512)     once per grid cell
+        gd = nn_ops.linear_any(self.grid, w[:, :2])                            # (16, 512)     once per grid cell
         off = nn_ops.fold_mlp(a, p.reshape(B * self.num_coarse, -1), gd, self.folding2[2], self.folding2[4],
                               B, self.num_coarse, g2)
         fine = off.reshape(B, self.num_coarse, g2, 3) + coarse.unsqueeze(2)

@@ -384,7 +384,8 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
         C = tok.shape[1]
         w = stage[0].weight.squeeze(-1)
         a = nn_ops.linear_any(tok, w[:, :C].contiguous(), stage[0].bias).unsqueeze(1)   # (P, 1, C)
-        h = F.relu(a + F.linear(extra, w[:, C:C + extra_w_cols]))                  # (P, 36, C)
+        e = nn_ops.linear_any(extra.reshape(-1, extra.shape[-1]), w[:, C:C + extra_w_cols])
+        h = F.relu(a + e.reshape(extra.shape[:-1] + (C,)))                         # (P, 36, C)
         h = nn_ops.linear_any(h.reshape(-1, C), stage[2].weight.squeeze(-1), stage[2].bias, relu=True)
         return nn_ops.linear_any(h, stage[4].weight.squeeze(-1), stage[4].bias)
 

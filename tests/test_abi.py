@@ -59,3 +59,22 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "pdae_oracle" not in src or f.endswith((".hip", ".h", ".cpp")) , f
+
+
+def test_product_has_no_library_gemm_call_sites():
+    """Every dense layer of the product models runs on the hand-written kernels: no F.linear / torch.mm /
+    matmul / bmm / addmm call on device tensors in the package (host-side 3x3 composition of the drawn affine
+    maps in corrupt_util_tensor.py / datasets.py / synthetic.py is numpy or CPU torch)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'point_dae_amd')
+    host_side = {'corrupt_util_tensor.py', 'datasets.py', 'synthetic.py', 'svm_probe.py'}
+    pat = re.compile(r'F\.linear\(|torch\.(mm|bmm|addmm|matmul|einsum)\(|\.matmul\(|F\.conv1d\(|F\.conv2d\(')
+    hits = []
+    for name in sorted(os.listdir(root)):
+        if name.endswith('.py') and name not in host_side:
+            for i, line in enumerate(open(os.path.join(root, name)), 1):
+                code = line.split('#')[0]
+                if pat.search(code) or re.search(r'[\w\)\]] @ [\w\(]', code):
+                    hits.append('%s:%d %s' % (name, i, line.strip()))
+    assert not hits, hits
