@@ -192,9 +192,18 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      // EPI_GROUPBIAS_STATS: the accumulators START at the group's bias (a 32-row MFMA tile is one group,
+      // a lane holds one column of it: one value for its 16 registers) -- the epilogue then has no add and
+      // four live registers fewer at the kernel's 128-VGPR limit
+      float init = 0.f;
+      if (EPI == EPI_GROUPBIAS_STATS) {
+        const int gr = m0 + wm * 64 + i * 32, gc = n0 + wn * 64 + j * 32 + r;
+        if (gr < M && gc < N) init = p.gbias[(size_t)(gr >> 5) * N + gc];
+      }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = init;
+    }
   int em0 = m0, en0 = n0, next = -1;   // the tile being multiplied (m0/n0 move on to the next one early)
   for (int kt = 0; kt < KT; ++kt) {
     bool more = kt + 1 < KT;
@@ -283,9 +292,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rbase = em0 + wm * 64 + i * 32;  // one 32-row group per MFMA tile
-        float add = bv;
-        if (EPI == EPI_GROUPBIAS_STATS)
-          add = (colok && (FULL || rbase < M)) ? p.gbias[(size_t)(rbase >> 5) * N + col] : 0.f;
+        const float add = EPI == EPI_GROUPBIAS_STATS ? 0.f : bv;
         float vmax = -__builtin_huge_valf();
         int amax = 0;
         float* cbase = (EPI != EPI_GROUPMAX) ? p.C + (size_t)(rbase + 4 * h) * ldc + col : nullptr;
