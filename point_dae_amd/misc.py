@@ -24,5 +24,11 @@ def set_random_seed(seed, deterministic=False):
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
     if deterministic:
+        # the reference's --deterministic pins cuDNN (utils/misc.py:56-62); here the hand-written kernels'
+        # atomic reductions become ordered ones (include/pdae.h: pdae_set_deterministic)
         torch.backends.cudnn.deterministic = True
         torch.backends.cudnn.benchmark = False
+        if torch.cuda.is_available():
+            from . import _lib
+            if not _lib.deterministic():
+                _lib.set_deterministic(True)

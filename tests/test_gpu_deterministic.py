@@ -222,3 +222,16 @@ def test_two_phase_step_equals_single_phase(det, name):
         out.append((losses, model.flat_param.clone()))
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_deterministic_flag_of_the_cli_switches_the_library_mode():
+    """`--deterministic` (main.py -> misc.set_random_seed) registers the ordered-reduction workspace."""
+    from point_dae_amd import _lib
+    from point_dae_amd.misc import set_random_seed
+    assert not _lib.deterministic()
+    try:
+        set_random_seed(3, deterministic=True)
+        assert _lib.deterministic()
+    finally:
+        _lib.set_deterministic(False)
+        torch.backends.cudnn.deterministic = False
