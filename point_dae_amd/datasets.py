@@ -32,7 +32,7 @@ from .synthetic import labelled_clouds, shapenet_like_clouds
 AFFINE = ('translate', 'scale_nonorm', 'rotate', 'reflection', 'shear')
 _PASS = ('clean', 'dropout_patch_pointmae', 'Drop-Patch')
 _AUGS = ('clean', 'norm', 'scale', 'translate', 'rotate_z', 'rotate')          # corrupt_util.augment_data :1155-1175
-_CORRUPTIONS = ('affine_r3', 'dropout_local') + AFFINE + ('rotate_z', 'scale', 'jitter', 'add_global',
+_CORRUPTIONS = ('affine_r3', 'dropout_local') + AFFINE + ('rotate_z', 'scale', 'jitter', 'add_global', 'add_local',
                                                           'nonuniform_density')
 
 
@@ -254,6 +254,25 @@ class ShapeNet:
                 y = torch.cat([y, extra], dim=1)
                 if alive is not None:
                     alive = torch.cat([alive, torch.ones(extra.shape[:2], dtype=torch.bool, device=y.device)], dim=1)
+            elif item == 'add_local':                               # +50 % points in 1-7 Gaussian clusters around random
+                P2 = y.shape[1]                                     # points of the cloud (:844-870, level 4)
+                total = int(P2 * 0.5)
+                seeds = np.zeros((B, total), np.int64)              # per added point: which cloud point it sits on
+                sig = np.zeros((B, total, 1), np.float32)
+                for b in range(B):
+                    n = int(self.rng.integers(1, 8))
+                    counts = np.bincount(self.rng.integers(0, n, total), minlength=n)
+                    pts = self.rng.integers(0, P2, n)               # (the reference shuffles and takes the first n)
+                    seeds[b] = np.repeat(pts, counts)
+                    sig[b, :, 0] = np.repeat(self.rng.uniform(0.075, 0.125, n), counts)
+                centre = y.gather(1, torch.from_numpy(seeds).to(y.device).unsqueeze(-1).expand(B, total, 3))
+                extra = centre + torch.from_numpy(sig).to(y.device) * torch.randn((B, total, 3), device=y.device,
+                                                                                   generator=self.gen)
+                d2 = extra.square().sum(-1, keepdim=True)
+                extra = torch.where(d2 > 1, extra / d2, extra)      # pulled back inside the unit sphere as the reference
+                y = torch.cat([y, extra], dim=1)
+                if alive is not None:
+                    alive = torch.cat([alive, torch.ones((B, total), dtype=torch.bool, device=y.device)], dim=1)
             elif item == 'nonuniform_density':                      # distance-gated drop from a random viewpoint (:875-897)
                 gate = torch.from_numpy((self.rng.uniform(0.0, 4.0, (B, 1)) / 4.0 + 0.1).astype(np.float32)).to(y.device)
                 v = self.rng.normal(0.0, 1.0, (B, 3))

@@ -40,7 +40,7 @@ def test_unimplemented_loader_corruption_is_refused():
     """A corrupt_type the device pipeline does not implement must raise, never train on clean == corrupted."""
     from point_dae_amd.datasets import ShapeNet
     with pytest.raises(NotImplementedError):
-        ShapeNet({'corrupt_type': ['add_local'], 'device': 'cpu'})
+        ShapeNet({'corrupt_type': ['scan'], 'device': 'cpu'})
     with pytest.raises(NotImplementedError):
         ShapeNet({'aug_type': ['jitter'], 'device': 'cpu'})
 
@@ -116,7 +116,7 @@ def test_device_dataset_end_to_end(tmp_path):
 @pytest.mark.parametrize('aug,cor', [(['norm', 'scale', 'translate'], ['clean']), (['norm'], ['affine_r3', 'jitter']),
                                      (['norm', 'rotate'], ['dropout_local']), (['norm'], ['add_global']),
                                      (['norm', 'rotate_z'], ['nonuniform_density']), (['norm'], ['shear']),
-                                     (['norm'], ['scale']), (['norm'], ['add_global', 'dropout_local'])])
+                                     (['norm'], ['scale']), (['norm'], ['add_global', 'dropout_local']), (['norm'], ['add_local'])])
 def test_device_dataset_augmentations_and_corruptions(aug, cor):
     """every loader-side augmentation / corruption the device pipeline implements (the reference's pretrain YAMLs
     use these names: aug ['norm','scale','translate'] in 25 of them) -> finite (B, npoints, 3) batches with the
