@@ -286,6 +286,30 @@ int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn
                    const float* bias /*nullable*/, int epi, float* Z /*epi 2,3,4*/,
                    float* Y, int cfg, int splits, int stream_blocks,
                    pdae_stream_t stream);
+/* The masked patches' share of the embedder backward by algebra (point_dae_amd/patch_embed.py; Encoder,
+ * models/PointCAE_transformer.py:37-51, behind MaskTransformer.forward :424-469 which drops the masked tokens).
+ * Rows of a group whose token is dropped carry no activation gradient into BatchNorm-2's backward, so their
+ * conv-output gradient is the correction alone, dh = u + v * h (u, v per channel).  Entries:
+ *   bnrelu_backward_listed: S (the sums = dbeta, dgamma) from the listed groups' compact dA, dA overwritten
+ *       in place with the listed groups' conv-output gradient, gsum[n_listed][C] their row sums, uv[2][C].
+ *   group_sum_listed: out[cg] = sum of the 32 rows of X's group groups[cg].
+ *   linear_backward_weight_listed: dW[N,K] = sum_m dY[rowA(m)]^T X[rowB(m)], whole 32-row groups gathered on
+ *       either operand (lists nullable = compact operand); dY = X with one list = a Gram matrix.
+ *   group_gemm_scatter: Y[c_groups[m/32]*32 + m%32] = X[a_groups[m/32]*32 + m%32] . W[N,K]^T + gbias[m/32]
+ *       (a_groups, gbias nullable); rows of Y outside the listed groups are not touched. */
+int pdae_bnrelu_backward_listed(int G, int C, float* dA, const float* X, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* gamma, float* S,
+                                float* gsum /*nullable*/, float* uv /*nullable*/, int n_listed,
+                                const int32_t* groups, pdae_stream_t stream);
+int pdae_group_sum_listed(int n_listed, int C, const float* X, const int32_t* groups, float* out,
+                          pdae_stream_t stream);
+int pdae_linear_backward_weight_listed(int M, int N, int K, const float* dY, const int32_t* a_groups,
+                                       const float* X, const int32_t* b_groups, float* dW,
+                                       float* dbias /*nullable*/, pdae_stream_t stream);
+int pdae_group_gemm_scatter(int M, int N, int K, const float* X, const int32_t* a_groups, const float* W,
+                            const float* gbias, float* Y, int ldy, const int32_t* c_groups,
+                            pdae_stream_t stream);
+
 /* Set-abstraction levels of the PointNet++ encoder (Point_CAE_PointNetv2;
  * extensions/pointnet2/pointnet2_modules.py PointnetSAModule: SharedMLP of
  * Conv2d 1x1 (no bias) -> BatchNorm2d -> ReLU layers, then F.max_pool2d over nsample)

@@ -143,6 +143,78 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_kernel(
   if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)g * C + c4) = acc;
 }
 
+// The listed (visible) groups' share of bnrelu_backward_apply: dA holds ONLY the listed groups (compact) and
+// is overwritten in place with the gradient of the conv output for those groups; gsum is compact too.  The
+// other groups' gradient is BatchNorm's correction alone, dh = u + v * h with the two vectors written by
+// bn_correction_kernel -- the caller folds it into small products instead of sweeping those rows
+// (patch_embed.py, "masked groups by algebra").
+__global__ __launch_bounds__(256) void bnrelu_backward_apply_listed_kernel(
+    int n_listed, int C, float* __restrict__ dA, const float* __restrict__ X,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ S, float inv_rows,
+    float* __restrict__ gsum, const int* __restrict__ groups) {
+  const int c4 = (blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
+  const int cg = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (c4 >= C || cg >= n_listed) return;
+  const int g = groups[cg];
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c4);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + c4);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c4);
+  const float4 s1 = *reinterpret_cast<const float4*>(S + c4);
+  const float4 s2 = *reinterpret_cast<const float4*>(S + C + c4);
+  const float kx = ga.x * is.x, ky = ga.y * is.y, kz = ga.z * is.z, kw = ga.w * is.w;
+  const float m1x = s1.x * inv_rows, m1y = s1.y * inv_rows, m1z = s1.z * inv_rows, m1w = s1.w * inv_rows;
+  const float m2x = s2.x * inv_rows, m2y = s2.y * inv_rows, m2z = s2.z * inv_rows, m2w = s2.w * inv_rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < 32; ++r) {
+    float* dp = dA + ((size_t)cg * 32 + r) * C + c4;
+    const float4 d = *reinterpret_cast<const float4*>(dp);
+    const float4 x = *reinterpret_cast<const float4*>(X + ((size_t)g * 32 + r) * C + c4);
+    float4 y;
+    y.x = kx * (((x.x * sc.x + sh.x > 0.f) ? d.x : 0.f) - m1x - ((x.x - mu.x) * is.x) * m2x);
+    y.y = ky * (((x.y * sc.y + sh.y > 0.f) ? d.y : 0.f) - m1y - ((x.y - mu.y) * is.y) * m2y);
+    y.z = kz * (((x.z * sc.z + sh.z > 0.f) ? d.z : 0.f) - m1z - ((x.z - mu.z) * is.z) * m2z);
+    y.w = kw * (((x.w * sc.w + sh.w > 0.f) ? d.w : 0.f) - m1w - ((x.w - mu.w) * is.w) * m2w);
+    *reinterpret_cast<float4*>(dp) = y;
+    acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
+  }
+  if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)cg * C + c4) = acc;
+}
+
+// uv[0][c] = u = -k m1 + k m2 s mu,  uv[1][c] = v = -k m2 s   (k = gamma s, m = S / rows):
+// for a row whose activation gradient is zero, dh = u + v * h.
+__global__ void bn_correction_kernel(int C, const float* __restrict__ S, float inv_rows,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, float* __restrict__ uv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float k = gamma[c] * invstd[c];
+  const float m1 = S[c] * inv_rows, m2 = S[C + c] * inv_rows;
+  const float v = -(k * m2) * invstd[c];
+  uv[c] = -(k * m1) - v * mean[c];
+  uv[C + c] = v;
+}
+
+// out[cg][c] = sum over the 32 rows of group groups[cg] of X (thread = 4 channels of one listed group)
+__global__ __launch_bounds__(256) void group_sum_listed_kernel(int n_listed, int C4, const float4* __restrict__ X,
+                                                               const int* __restrict__ groups,
+                                                               float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_listed * C4) return;
+  const int cg = (int)(i / C4), q = (int)(i - (long long)cg * C4);
+  const float4* row = X + (size_t)groups[cg] * 32 * C4 + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int r = 0; r < 32; ++r) {
+    const float4 v = row[(size_t)r * C4];
+    a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+  }
+  out[i] = a;
+}
+
 // First conv of the embedder (K = 3, first_conv[0]) with BatchNorm's batch statistics:
 //   y[m][c] = ((x0*w[c][0] + x1*w[c][1]) + x2*w[c][2]) + b[c];  stats[0][c] += sum_m y,
 //   stats[1][c] += sum_m y*y  (fp32 per-thread partials over 64 rows, then fp64 atomics).
@@ -319,4 +391,51 @@ extern "C" int pdae_bn_finalize(int C, long long rows, const double* stats64, co
                      (double)rows, stats64, partials, P, gamma, beta, eps, momentum, running_mean,
                      running_var, num_batches_tracked, scale, shift, mean, invstd);
   return check_launch("bn_finalize");
+}
+
+extern "C" int pdae_bnrelu_backward_listed(int G, int C, float* dA, const float* X, const float* scale,
+                                           const float* shift, const float* mean, const float* invstd,
+                                           const float* gamma, float* S, float* gsum, float* uv, int n_listed,
+                                           const int32_t* groups, pdae_stream_t stream) {
+  if (G < 0 || n_listed < 0 || n_listed > G || C <= 0 || C % 4 != 0)
+    return bad_arg("bnrelu_backward_listed: C must be a positive multiple of 4, n_listed <= G");
+  if (!S) return bad_arg("bnrelu_backward_listed: null pointer");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)C, s);
+  if (!scale || !shift || !mean || !invstd || !gamma || (n_listed && (!dA || !X || !groups)))
+    return bad_arg("bnrelu_backward_listed: null pointer");
+  const int Rsum = n_listed * 32;
+  int rc = PDAE_OK;
+  if (Rsum > 0) {
+    int rows = 512;
+    int by = (Rsum + rows - 1) / rows;
+    if (by > 16384) {
+      rows = (Rsum + 16383) / 16384;
+      by = (Rsum + rows - 1) / rows;
+    }
+    float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)by * 2 * C, &rc));
+    if (rc) return rc;
+    hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, Rsum, C, dA, X,
+                       scale, shift, mean, invstd, S, rows, groups, det);
+    if (det && (rc = det_reduce(s, by, 2 * C, det, S, 2 * C))) return rc;
+  }
+  const float inv_rows = G > 0 ? 1.0f / (float)((long long)G * 32) : 0.f;
+  if (n_listed > 0)
+    hipLaunchKernelGGL(bnrelu_backward_apply_listed_kernel, dim3((C / 4 + 31) / 32, (n_listed + 7) / 8), dim3(256), 0,
+                       s, n_listed, C, dA, X, scale, shift, mean, invstd, gamma, S, inv_rows, gsum, groups);
+  if (uv)
+    hipLaunchKernelGGL(bn_correction_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, S, inv_rows, gamma, mean,
+                       invstd, uv);
+  return check_launch("bnrelu_backward_listed");
+}
+
+extern "C" int pdae_group_sum_listed(int n_listed, int C, const float* X, const int32_t* groups, float* out,
+                                     pdae_stream_t stream) {
+  if (n_listed < 0 || C <= 0 || C % 4 != 0) return bad_arg("group_sum_listed: C must be a positive multiple of 4");
+  if (n_listed == 0) return PDAE_OK;
+  if (!X || !groups || !out) return bad_arg("group_sum_listed: null pointer");
+  const long long n = (long long)n_listed * (C / 4);
+  hipLaunchKernelGGL(group_sum_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     n_listed, C / 4, reinterpret_cast<const float4*>(X), groups, reinterpret_cast<float4*>(out));
+  return check_launch("group_sum_listed");
 }

@@ -61,7 +61,9 @@ enum {
   EPI_GROUPBIAS_STATS = 3,
   EPI_GROUPMAX = 4,
   EPI_STORE_GROUPMAX = 5,
-  EPI_STATS = 6            // C = acc (+ bias); per-column sum / sum of squares like EPI_GROUPBIAS_STATS
+  EPI_STATS = 6,           // C = acc (+ bias); per-column sum / sum of squares like EPI_GROUPBIAS_STATS
+  EPI_GROUP_SCATTER = 7    // C[c_groups[m/32]*32 + m%32] = acc + gbias[m/32] (gbias nullable): whole 32-row groups
+                           // of a compact product land at listed groups of a larger matrix
 };
 
 struct NtArgs {
@@ -81,6 +83,7 @@ struct NtArgs {
   float* gmax;             // [M/32][N]  EPI_*GROUPMAX
   unsigned char* garg;     // [M/32][N]
   const int* a_groups;     // nullable: row m of A is source row a_groups[m/32]*32 + m%32
+  const int* c_groups;     // EPI_GROUP_SCATTER: destination group of tile-row group m/32
   int tiles_n, tiles, tile_rows;
 };
 
@@ -197,9 +200,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
       // a lane holds one column of it: one value for its 16 registers) -- the epilogue then has no add and
       // four live registers fewer at the kernel's 128-VGPR limit
       float init = 0.f;
-      if (EPI == EPI_GROUPBIAS_STATS) {
+      if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) {
         const int gr = m0 + wm * 64 + i * 32, gc = n0 + wn * 64 + j * 32 + r;
-        if (gr < M && gc < N) init = p.gbias[(size_t)(gr >> 5) * N + gc];
+        if (gr < M && gc < N && (EPI == EPI_GROUPBIAS_STATS || p.gbias)) init = p.gbias[(size_t)(gr >> 5) * N + gc];
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = init;
@@ -292,10 +295,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rbase = em0 + wm * 64 + i * 32;  // one 32-row group per MFMA tile
-        const float add = EPI == EPI_GROUPBIAS_STATS ? 0.f : bv;
+        const float add = (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) ? 0.f : bv;
         float vmax = -__builtin_huge_valf();
         int amax = 0;
         float* cbase = (EPI != EPI_GROUPMAX) ? p.C + (size_t)(rbase + 4 * h) * ldc + col : nullptr;
+        if (EPI == EPI_GROUP_SCATTER && (FULL || rbase < M))      // the 32-row MFMA tile is one group: one id
+          cbase = p.C + (size_t)(p.c_groups[rbase >> 5] * 32 + 4 * h) * ldc + col;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -394,6 +399,7 @@ struct TnArgs {
   const float* pro_scale;  // [K]
   const float* pro_shift;
   const int* b_groups;     // nullable: row m of B is source row b_groups[m/32]*32 + m%32
+  const int* a_groups;     // nullable: the same for A
   float* colsum_a;         // nullable: [N] += column sums of A (the bias gradient), from the k-tile-0 blocks
   int rows_per_split;
   int tk, tn, splits;      // tiles along K and N, M-splits
@@ -453,12 +459,13 @@ void gemm_tn_kernel(const TnArgs p) {
     // a slab is TBK consecutive rows starting at a multiple of TBK: inside ONE group of the
     // list -> one uniform (scalar) id load per slab instead of a dependent load per slot
     const int shift = p.b_groups ? (__builtin_amdgcn_readfirstlane(p.b_groups[mt >> 5]) * 32 - (mt & ~31)) : 0;
+    const int shift_a = p.a_groups ? (__builtin_amdgcn_readfirstlane(p.a_groups[mt >> 5]) * 32 - (mt & ~31)) : 0;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int gm = mt + srow0 + i * RSTEP;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok && gm < mend) {
-        const int sm = isb ? gm + shift : gm;
+        const int sm = isb ? gm + shift : gm + shift_a;
         v = *reinterpret_cast<const float4*>(src + (size_t)sm * ld);
       }
       rg[i] = v;
@@ -811,6 +818,44 @@ extern "C" int pdae_bnrelu_linear_backward_weight(int M, int N, int K, const flo
   t.pro_scale = scale, t.pro_shift = shift, t.b_groups = groups, t.colsum_a = dbias;
   if (groups && M % 32 != 0) return bad_arg("bnrelu_linear_backward_weight: M must be a multiple of 32 with a group list");
   return launch_tn(t, true, s);
+}
+
+// dW[N,K] = sum over listed rows of dY[rowA(m)]^T X[rowB(m)]: the TN kernel with whole 32-row groups gathered
+// on either operand (a_groups / b_groups nullable: that operand is compact).  dY = X = f with the same list on
+// both sides is the Gram matrix of the listed rows.
+extern "C" int pdae_linear_backward_weight_listed(int M, int N, int K, const float* dY, const int32_t* a_groups,
+                                                  const float* X, const int32_t* b_groups, float* dW,
+                                                  float* dbias, pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0) return bad_arg("linear_backward_weight_listed: bad size");
+  if (!dW) return bad_arg("linear_backward_weight_listed: null pointer");
+  if (M % 32 != 0) return bad_arg("linear_backward_weight_listed: M must be a multiple of 32 (whole groups)");
+  hipStream_t s = as_stream(stream);
+  (void)hipMemsetAsync(dW, 0, sizeof(float) * (size_t)N * K, s);
+  if (dbias) (void)hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)N, s);
+  if (M == 0) return check_launch("linear_backward_weight_listed");
+  if (!dY || !X) return bad_arg("linear_backward_weight_listed: null pointer");
+  if (N % 4 != 0 || K % 4 != 0) return unsupported("linear_backward_weight_listed: N, K multiples of 4");
+  TnArgs t = {};
+  t.M = M, t.N = N, t.K = K, t.A = dY, t.lda = N, t.B = X, t.ldb = K, t.C = dW, t.ldc = K;
+  t.a_groups = a_groups, t.b_groups = b_groups, t.colsum_a = dbias;
+  return launch_tn(t, false, s);
+}
+
+// Y[c_groups[m/32]*32 + m%32, :] = X[a_groups[m/32]*32 + m%32, :] . W[N,K]^T + gbias[m/32, :] for the M rows
+// (whole 32-row groups) of a compact product: gather on the way in (a_groups nullable: X is compact), one bias
+// row per group (nullable), scatter on the way out.  The other rows of Y are not touched.
+extern "C" int pdae_group_gemm_scatter(int M, int N, int K, const float* X, const int32_t* a_groups,
+                                       const float* W, const float* gbias, float* Y, int ldy,
+                                       const int32_t* c_groups, pdae_stream_t stream) {
+  int rc = check_nt("group_gemm_scatter: bad size", M, N, K);
+  if (rc) return rc;
+  if (M % 32 != 0) return bad_arg("group_gemm_scatter: M must be a multiple of 32 (whole groups)");
+  if (M == 0) return PDAE_OK;
+  if (!X || !W || !Y || !c_groups || ldy < N) return bad_arg("group_gemm_scatter: null pointer / bad ldy");
+  NtArgs a = {};
+  a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = ldy;
+  a.gbias = gbias, a.a_groups = a_groups, a.c_groups = c_groups;
+  return launch_nt<PRO_NONE, EPI_GROUP_SCATTER>(a, as_stream(stream));
 }
 
 extern "C" int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,

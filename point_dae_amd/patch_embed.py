@@ -26,12 +26,17 @@ cuDNN convs and separate BatchNorm / ReLU / max / concat / add passes:
 Training-mode BatchNorm semantics are PyTorch's: biased batch variance for the
 normalisation, unbiased for the running estimate, momentum 0.1.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 from . import _lib
 from .arena import arena
 from .probe import probed
+
+
+ALGEBRA = os.environ.get('PDAE_EMBED_ALGEBRA', '1') != '0'
 
 
 def _empty(shape, like, dtype=torch.float32):
@@ -105,7 +110,7 @@ class PatchEmbedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, first_conv, second_conv, training,
-                groups):
+                groups, masked=None):
         R = x.shape[0]
         BG = R // 32
         x = x.contiguous()
@@ -164,7 +169,57 @@ class PatchEmbedFunction(torch.autograd.Function):
         ctx.save_for_backward(x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
                               w1m, w2m, wg, wl, w4m, g1, g2, groups, inv)
         ctx.training = training
+        # masked groups by algebra (backward): needs the complementary list and the per-group bias term
+        ctx.algebra = ALGEBRA and groups is not None and masked is not None and masked.numel() > 0 and training
+        if ctx.algebra:
+            ctx.masked, ctx.gb = masked.contiguous(), gb
         return tok
+
+    @staticmethod
+    def _masked_by_algebra(ctx, d3c, f, h3, sc2, sh2, mean2, is2, g2, wl, groups, BG):
+        """conv3 + BatchNorm-2 backward with the masked groups handled by algebra.  A group whose token is
+        dropped sends no activation gradient into BatchNorm-2, so on its rows the conv-output gradient is the
+        correction alone, dh_r = u + v * h_r, with h_r = f_r W^T + gb_g (W = the local half of conv3's weight):
+            df_r  = f_r (W^T diag(v) W) + (gb_g * v + u) W                       a 256x256 product, not 512x256
+            dW    = dW_visible + diag(v) (W Gram + gb_m^T fsum_m) + u (x) sum f_r,   Gram = sum f_r^T f_r
+            dgb_g = 32 u + v * (fsum_g W^T + 32 gb_g),                              fsum_g = sum_{r in g} f_r
+        and the dense sweep + the two R x 512 x 256 GEMMs run on the visible rows only.  Same arithmetic error
+        as the direct form (both 7e-7 of fp64 on a 32 k-row case).  -> dwl, dgb, df, dbeta2, dgamma2."""
+        x = f
+        c3, c2 = wl.shape
+        masked, gb = ctx.masked, ctx.gb
+        Gv, Gm = groups.numel(), masked.numel()
+        Rv, Rm, R = Gv * 32, Gm * 32, BG * 32
+        S2, uv, gsum_v = _empty((2, c3), x), _empty((2, c3), x), _empty((Gv, c3), x)
+        _lib.call('pdae_bnrelu_backward_listed', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(gsum_v), _lib.ptr(uv), Gv,
+                  _lib.ptr(groups))                                   # d3c <- dh of the visible rows
+        u, v = uv[0], uv[1]
+        fsum_m = _empty((Gm, c2), x)
+        _lib.call('pdae_group_sum_listed', x, Gm, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(fsum_m))
+        gb_m = gb.index_select(0, masked.long())
+        # ---- weight gradient
+        dwl, gram = _empty((c3, c2), x), _empty((c2, c2), x)
+        _lib.call('pdae_linear_backward_weight_listed', x, Rv, c3, c2, _lib.ptr(d3c), None, _lib.ptr(f),
+                  _lib.ptr(groups), _lib.ptr(dwl), None)
+        _lib.call('pdae_linear_backward_weight_listed', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(f),
+                  _lib.ptr(masked), _lib.ptr(gram), None)
+        corr = _gemm(wl, gram).add_(_wgrad(gb_m, fsum_m))             # W Gram (Gram is symmetric) + gb_m^T fsum_m
+        dwl.addcmul_(v.unsqueeze(1), corr).add_(u.unsqueeze(1) * fsum_m.sum(0, keepdim=True))
+        # ---- per-group sums (the global half of the split concat weight)
+        dgb = _empty((BG, c3), x)
+        dgb.index_copy_(0, groups.long(), gsum_v)
+        hs = _gemm(fsum_m, wl).add_(gb_m, alpha=32.0)                 # sum_{r in g} h_r
+        dgb.index_copy_(0, masked.long(), torch.addcmul(32.0 * u, v, hs))
+        # ---- data gradient
+        q = _wgrad(wl * v.unsqueeze(1), wl)                           # W^T diag(v) W  (symmetric)
+        e = _gemm(torch.addcmul(u, gb_m, v), wl, True)                # (gb_g * v + u) W   (Gm, 256)
+        df = _empty((R, c2), x)
+        _lib.call('pdae_group_gemm_scatter', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(q), _lib.ptr(e),
+                  _lib.ptr(df), c2, _lib.ptr(masked))
+        _lib.call('pdae_group_gemm_scatter', x, Rv, c2, c3, _lib.ptr(d3c), None, _lib.ptr(wl.t().contiguous()), None,
+                  _lib.ptr(df), c2, _lib.ptr(groups))
+        return dwl, dgb, df, S2[0], S2[1]
 
     @staticmethod
     def backward(ctx, dtok):
@@ -186,25 +241,30 @@ class PatchEmbedFunction(torch.autograd.Function):
                   _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), None, _lib.ptr(groups))
         d3c = _gemm(dy4, w4m, True)                               # (Rv, 512) grad of relu(bn2(h3)) rows
         del dy4
-        # ---- ReLU + BN2 backward + per-group sums for the global half
-        S2 = _empty((2, c3), x)
-        dgb = _empty((BG, c3), x)
-        d3 = _empty((R, c3), x) if groups is not None else d3c
-        _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
-                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), Gv,
-                  _lib.ptr(groups), _lib.ptr(inv), _lib.ptr(d3) if groups is not None else None)
-        del d3c
-        dbe2, dg2 = S2[0], S2[1]
-        # ---- conv3 (split weight)
-        dwl = _wgrad(d3, f)          # stream-K grouped kernel, ordered reduction (no atomics)
+        if ctx.algebra:
+            dwl, dgb, df, dbe2, dg2 = PatchEmbedFunction._masked_by_algebra(ctx, d3c, f, h3, sc2, sh2, mean2, is2, g2,
+                                                                             wl, groups, BG)
+            del d3c
+        else:
+            # ---- ReLU + BN2 backward + per-group sums for the global half
+            S2 = _empty((2, c3), x)
+            dgb = _empty((BG, c3), x)
+            d3 = _empty((R, c3), x) if groups is not None else d3c
+            _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+                      _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), Gv,
+                      _lib.ptr(groups), _lib.ptr(inv), _lib.ptr(d3) if groups is not None else None)
+            del d3c
+            dbe2, dg2 = S2[0], S2[1]
+            # ---- conv3 (split weight)
+            dwl = _wgrad(d3, f)          # stream-K grouped kernel, ordered reduction (no atomics)
+            df = _gemm(d3, wl, True)                                  # (R, 256)
+            del d3
         dwg = _wgrad(dgb, g)
         # conv3's bias feeds a training-mode BatchNorm: its gradient, sum_r dy3_r, is EXACTLY zero (BatchNorm's
         # backward removes the batch mean of the gradient); the column-sum pass over dgb would only measure
         # its own rounding (the reference's value is ~1e-6 of the other gradients, noise of either sign)
         db3 = arena.take(c3, x)[0]
         dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
-        df = _gemm(d3, wl, True)                                  # (R, 256)
-        del d3
         dg = _gemm(dgb, wg, True)                                 # (BG, 256) -> arg-max rows of f
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
@@ -224,13 +284,15 @@ class PatchEmbedFunction(torch.autograd.Function):
         dw1 = _wgrad(d1, xp)[:, :3].unsqueeze(-1)
         db1 = arena.take(c1, x)[0]                                   # exactly zero, as db3 (saves a 134 MB pass)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
-                dw4.unsqueeze(-1), db4, None, None, None, None)
+                dw4.unsqueeze(-1), db4, None, None, None, None, None)
 
 
-def patch_embed(points, first_conv, second_conv, training, groups=None):
+def patch_embed(points, first_conv, second_conv, training, groups=None, masked=None):
     """points (BG, n=32, 3) -> tokens (BG, C), or -- with `groups`, an int32 device
     tensor of group ids -- the tokens of just those groups (len(groups), C) in list
-    order; BatchNorm statistics always cover all BG groups."""
+    order; BatchNorm statistics always cover all BG groups.  masked: the complementary
+    list (the groups whose tokens the caller drops): their share of the backward is then
+    done by algebra (PatchEmbedFunction._masked_by_algebra)."""
     BG, n, _ = points.shape
     if n != 32:
         raise NotImplementedError('the fused embedder is written for group_size 32')
@@ -242,4 +304,4 @@ def patch_embed(points, first_conv, second_conv, training, groups=None):
         points.reshape(BG * n, 3), first_conv[0].weight, first_conv[0].bias, first_conv[1].weight,
         first_conv[1].bias, first_conv[3].weight, first_conv[3].bias, second_conv[0].weight,
         second_conv[0].bias, second_conv[1].weight, second_conv[1].bias, second_conv[3].weight,
-        second_conv[3].bias, first_conv, second_conv, training, groups)
+        second_conv[3].bias, first_conv, second_conv, training, groups, masked)

@@ -59,12 +59,12 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, encoder_channel, 1))
 
-    def forward(self, point_groups, groups=None):
+    def forward(self, point_groups, groups=None, masked=None):
         """(B,G,n,3) -> tokens (B,G,C); with `groups` (int32 flat group ids) only their
-        tokens, as rows (len(groups), C)."""
+        tokens, as rows (len(groups), C); `masked` = the complementary list."""
         bs, g, n, _ = point_groups.shape
         tok = nn_ops.patch_embed(point_groups.reshape(bs * g, n, 3), self.first_conv, self.second_conv,
-                                 self.training, groups)
+                                 self.training, groups, masked)
         return tok if groups is not None else tok.reshape(bs, g, self.encoder_channel)
 
 
@@ -237,7 +237,7 @@ class MaskTransformer(nn.Module):
         # every group goes through the embedder up to its last BatchNorm (:437); the
         # final conv + max-pool, whose output the reference computes for all groups and
         # then drops for the masked ones (:449), runs for the visible groups only
-        x_vis = self.encoder(neighborhood, groups=vis_rows.to(torch.int32))
+        x_vis = self.encoder(neighborhood, groups=vis_rows.to(torch.int32), masked=mask_rows.to(torch.int32))
         cut = getattr(self, 'grad_cut', None)
         if cut is not None and x_vis.requires_grad:
             # two-phase backward (graph_step.py): the Transformer's backward stops at a leaf copy of the

@@ -36,12 +36,16 @@ def grad_sample(g, n=256):
     return flat[idx].numpy()
 
 
-def check_grads(model, fx, rtol, what, atol=2e-5):
+def check_grads(model, fx, rtol, what, atol=2e-5, spike=None, max_spikes=0):
     """Every parameter gradient against the reference's: L2 norm, plus the full
     tensor (small parameters) or 256 evenly spaced entries (large ones).  `atol`
     covers gradients that are analytically zero (a conv bias feeding a training
-    mode BatchNorm) and therefore pure rounding noise on both sides."""
-    worst = 0.0
+    mode BatchNorm) and therefore pure rounding noise on both sides.
+    spike / max_spikes: models whose max-pools sit on exact ties (the set-abstraction levels: ReLU clamps
+    many rows of a group to 0) re-route one gradient element when a last-bit difference flips a tied
+    arg-max -- in the reference as much as here.  Up to `max_spikes` tensors may then miss `rtol` in the
+    max norm as long as they stay within `spike`; the L2 norms keep `rtol`."""
+    worst, spikes = 0.0, []
     for name, p in model.named_parameters():
         key = 'grad/' + name
         ref_norm = float(fx[key + '/norm'])
@@ -56,5 +60,9 @@ def check_grads(model, fx, rtol, what, atol=2e-5):
         scale = np.abs(ref).max()
         diff = np.abs(got - ref).max()
         worst = max(worst, diff / max(scale, atol))
+        if diff > rtol * scale + atol and spike is not None and diff <= spike * scale + atol:
+            spikes.append((name, float(diff / scale)))
+            continue
         assert diff <= rtol * scale + atol, (what, name, diff, scale)
+    assert len(spikes) <= max_spikes, (what, spikes)
     return worst

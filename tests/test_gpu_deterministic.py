@@ -107,12 +107,27 @@ def test_visible_groups_equal_all_groups(det):
     out_a, g_a = _embed_run(pts, first, second, go_all)
     out_b, g_b = _embed_run(pts, f2, s2, gsel, sel)
     assert torch.equal(out_a[sel.long()], out_b)          # the forward statistics are the same sums
+    # ... and with the masked groups' share of the backward done by algebra (patch_embed's `masked` list)
+    from point_dae_amd.patch_embed import patch_embed
+    f3, s3 = copy.deepcopy(first), copy.deepcopy(second)
+    for m in (f3, s3):
+        m.zero_grad()
+    rest = torch.tensor([i for i in range(BG) if i % 3 != 0], device='cuda', dtype=torch.int32)
+    out_c = patch_embed(pts, f3, s3, True, sel, rest)
+    out_c.backward(gsel)
+    assert torch.equal(out_c.detach(), out_b)
+    g_c = [p.grad.clone() for p in list(f3.parameters()) + list(s3.parameters())]
     gmax = max(g.abs().max().item() for g in g_a)
     for a, b in zip(g_a, g_b):
         if a.abs().max().item() < 1e-4 * gmax:     # conv bias feeding a training-mode BatchNorm: exactly zero
             continue                               # gradient, rounding residue on both paths
         scale = a.abs().max().item()
         assert (a - b).abs().max().item() <= 1e-5 * scale, (tuple(a.shape), (a - b).abs().max().item(), scale)
+    for a, c in zip(g_a, g_c):
+        if a.abs().max().item() < 1e-4 * gmax:
+            continue
+        scale = a.abs().max().item()
+        assert (a - c).abs().max().item() <= 1e-5 * scale, ('algebra', tuple(a.shape), (a - c).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize('M,C', [(2944, 384), (8192, 384), (777, 1024)])

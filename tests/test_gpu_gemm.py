@@ -216,6 +216,19 @@ def test_fused_patch_embed_matches_pytorch(BG):
     out_a.backward(gsel)
     out_b = patch_embed(pts, fb, sb, True, sel)
     out_b.backward(gsel)
+    # the same with the complementary list given: the masked groups' share of the backward by algebra
+    fc, sc_ = _copy.deepcopy(first_r), _copy.deepcopy(second_r)
+    for mm in (fc, sc_):
+        mm.zero_grad()
+    rest = torch.tensor([i for i in range(BG) if i % 3 != 0], device='cuda', dtype=torch.int32)
+    out_c = patch_embed(pts, fc, sc_, True, sel, rest)
+    out_c.backward(gsel)
+    _close(out_c, out_b.detach(), 1e-5)
+    for pb_, pc_ in zip(list(fb.parameters()) + list(sb.parameters()), list(fc.parameters()) + list(sc_.parameters())):
+        if pb_.grad.abs().max().item() < 1e-4 * gmax:
+            continue
+        rel = (pb_.grad - pc_.grad).norm().item() / (pb_.grad.norm().item() + 1e-12)
+        assert rel <= 5e-3, ('algebra', tuple(pb_.shape), rel)
     _close(out_b, out_a.detach(), 1e-5)      # BatchNorm sums use atomics: last-bit run-to-run noise
     # The two runs draw BatchNorm sums through atomics (last-bit differences), which can flip
     # a near-tied arg-max row and reroute that element's gradient: compare in the L2 sense.
