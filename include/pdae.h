@@ -291,7 +291,10 @@ int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn
  * Rows of a group whose token is dropped carry no activation gradient into BatchNorm-2's backward, so their
  * conv-output gradient is the correction alone, dh = u + v * h (u, v per channel).  Entries:
  *   bnrelu_backward_listed: S (the sums = dbeta, dgamma) from the listed groups' compact dA, dA overwritten
- *       in place with the listed groups' conv-output gradient, gsum[n_listed][C] their row sums, uv[2][C].
+ *       in place with the listed groups' conv-output gradient, gsum their row sums (row = position in the
+ *       list, or the group id when gsum_by_group), uv[2][C].
+ *   masked_group_sums: dgb[groups[cg]] = v * hs[cg] + 32 * xe[cg]: the row sums of dh over a masked group
+ *       (hs = the group's summed conv output without its bias term, xe = u + v * gb).
  *   group_sum_listed: out[cg] = sum of the 32 rows of X's group groups[cg].
  *   linear_backward_weight_listed: dW[N,K] = sum_m dY[rowA(m)]^T X[rowB(m)], whole 32-row groups gathered on
  *       either operand (lists nullable = compact operand); dY = X with one list = a Gram matrix.
@@ -299,8 +302,10 @@ int pdae_rows_gemm(int M, int N, int K, const float* X, const float* W, int w_kn
  *       (a_groups, gbias nullable); rows of Y outside the listed groups are not touched. */
 int pdae_bnrelu_backward_listed(int G, int C, float* dA, const float* X, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* gamma, float* S,
-                                float* gsum /*nullable*/, float* uv /*nullable*/, int n_listed,
-                                const int32_t* groups, pdae_stream_t stream);
+                                float* gsum /*nullable*/, int gsum_by_group, float* uv /*nullable*/,
+                                int n_listed, const int32_t* groups, pdae_stream_t stream);
+int pdae_masked_group_sums(int n_listed, int C, const float* hs, const float* xe, const float* v,
+                           const int32_t* groups, float* dgb, pdae_stream_t stream);
 int pdae_group_sum_listed(int n_listed, int C, const float* X, const int32_t* groups, float* out,
                           pdae_stream_t stream);
 int pdae_linear_backward_weight_listed(int M, int N, int K, const float* dY, const int32_t* a_groups,

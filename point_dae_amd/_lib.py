@@ -62,7 +62,8 @@ _SIGNATURES = {
     "pdae_embed_conv1_stats": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bn_finalize": [_i, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_adamw_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
-    "pdae_bnrelu_backward_listed": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "pdae_bnrelu_backward_listed": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
+    "pdae_masked_group_sums": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_group_sum_listed": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_linear_backward_weight_listed": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_group_gemm_scatter": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],

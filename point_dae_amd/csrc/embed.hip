@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_listed_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ S, float inv_rows,
-    float* __restrict__ gsum, const int* __restrict__ groups) {
+    float* __restrict__ gsum, const int* __restrict__ groups, int gsum_by_group) {
   const int c4 = (blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
   const int cg = blockIdx.y * 8 + (threadIdx.x >> 5);
   if (c4 >= C || cg >= n_listed) return;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void bnrelu_backward_apply_listed_kernel(
     *reinterpret_cast<float4*>(dp) = y;
     acc.x += y.x, acc.y += y.y, acc.z += y.z, acc.w += y.w;
   }
-  if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)cg * C + c4) = acc;
+  if (gsum) *reinterpret_cast<float4*>(gsum + (size_t)(gsum_by_group ? g : cg) * C + c4) = acc;
 }
 
 // uv[0][c] = u = -k m1 + k m2 s mu,  uv[1][c] = v = -k m2 s   (k = gamma s, m = S / rows):
@@ -196,6 +196,24 @@ __global__ void bn_correction_kernel(int C, const float* __restrict__ S, float i
   const float v = -(k * m2) * invstd[c];
   uv[c] = -(k * m1) - v * mean[c];
   uv[C + c] = v;
+}
+
+// row sums of the conv-output gradient of the MASKED groups (dh = u + v * h on all 32 rows):
+// dgb[groups[cg]] = v * hs[cg] + 32 * xe[cg], hs = sum of the group's 32 conv outputs without the group bias
+// term (fsum W^T), xe = u + v * gb  (so that 32 u + v (hs + 32 gb) = v hs + 32 xe)
+__global__ __launch_bounds__(256) void masked_group_sums_kernel(int n_listed, int C4, const float4* __restrict__ hs,
+                                                                const float4* __restrict__ xe,
+                                                                const float4* __restrict__ v,
+                                                                const int* __restrict__ groups,
+                                                                float4* __restrict__ dgb) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_listed * C4) return;
+  const int cg = (int)(i / C4), q = (int)(i - (long long)cg * C4);
+  const float4 h = hs[i], x = xe[i], vv = v[q];
+  float4 o;
+  o.x = vv.x * h.x + 32.f * x.x, o.y = vv.y * h.y + 32.f * x.y;
+  o.z = vv.z * h.z + 32.f * x.z, o.w = vv.w * h.w + 32.f * x.w;
+  dgb[(size_t)groups[cg] * C4 + q] = o;
 }
 
 // out[cg][c] = sum over the 32 rows of group groups[cg] of X (thread = 4 channels of one listed group)
@@ -395,8 +413,9 @@ extern "C" int pdae_bn_finalize(int C, long long rows, const double* stats64, co
 
 extern "C" int pdae_bnrelu_backward_listed(int G, int C, float* dA, const float* X, const float* scale,
                                            const float* shift, const float* mean, const float* invstd,
-                                           const float* gamma, float* S, float* gsum, float* uv, int n_listed,
-                                           const int32_t* groups, pdae_stream_t stream) {
+                                           const float* gamma, float* S, float* gsum, int gsum_by_group,
+                                           float* uv, int n_listed, const int32_t* groups,
+                                           pdae_stream_t stream) {
   if (G < 0 || n_listed < 0 || n_listed > G || C <= 0 || C % 4 != 0)
     return bad_arg("bnrelu_backward_listed: C must be a positive multiple of 4, n_listed <= G");
   if (!S) return bad_arg("bnrelu_backward_listed: null pointer");
@@ -422,7 +441,7 @@ extern "C" int pdae_bnrelu_backward_listed(int G, int C, float* dA, const float*
   const float inv_rows = G > 0 ? 1.0f / (float)((long long)G * 32) : 0.f;
   if (n_listed > 0)
     hipLaunchKernelGGL(bnrelu_backward_apply_listed_kernel, dim3((C / 4 + 31) / 32, (n_listed + 7) / 8), dim3(256), 0,
-                       s, n_listed, C, dA, X, scale, shift, mean, invstd, gamma, S, inv_rows, gsum, groups);
+                       s, n_listed, C, dA, X, scale, shift, mean, invstd, gamma, S, inv_rows, gsum, groups, gsum_by_group);
   if (uv)
     hipLaunchKernelGGL(bn_correction_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, S, inv_rows, gamma, mean,
                        invstd, uv);
@@ -438,4 +457,16 @@ extern "C" int pdae_group_sum_listed(int n_listed, int C, const float* X, const 
   hipLaunchKernelGGL(group_sum_listed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                      n_listed, C / 4, reinterpret_cast<const float4*>(X), groups, reinterpret_cast<float4*>(out));
   return check_launch("group_sum_listed");
+}
+
+extern "C" int pdae_masked_group_sums(int n_listed, int C, const float* hs, const float* xe, const float* v,
+                                      const int32_t* groups, float* dgb, pdae_stream_t stream) {
+  if (n_listed < 0 || C <= 0 || C % 4 != 0) return bad_arg("masked_group_sums: C must be a positive multiple of 4");
+  if (n_listed == 0) return PDAE_OK;
+  if (!hs || !xe || !v || !groups || !dgb) return bad_arg("masked_group_sums: null pointer");
+  const long long n = (long long)n_listed * (C / 4);
+  hipLaunchKernelGGL(masked_group_sums_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     n_listed, C / 4, reinterpret_cast<const float4*>(hs), reinterpret_cast<const float4*>(xe),
+                     reinterpret_cast<const float4*>(v), groups, reinterpret_cast<float4*>(dgb));
+  return check_launch("masked_group_sums");
 }

@@ -181,8 +181,8 @@ class PatchEmbedFunction(torch.autograd.Function):
         dropped sends no activation gradient into BatchNorm-2, so on its rows the conv-output gradient is the
         correction alone, dh_r = u + v * h_r, with h_r = f_r W^T + gb_g (W = the local half of conv3's weight):
             df_r  = f_r (W^T diag(v) W) + (gb_g * v + u) W                       a 256x256 product, not 512x256
-            dW    = dW_visible + diag(v) (W Gram + gb_m^T fsum_m) + u (x) sum f_r,   Gram = sum f_r^T f_r
-            dgb_g = 32 u + v * (fsum_g W^T + 32 gb_g),                              fsum_g = sum_{r in g} f_r
+            dW    = dW_visible + diag(v) W Gram + xe^T fsum,   Gram = sum f_r^T f_r,  xe_g = u + v * gb_g
+            dgb_g = v * (fsum_g W^T) + 32 xe_g,                                     fsum_g = sum_{r in g} f_r
         and the dense sweep + the two R x 512 x 256 GEMMs run on the visible rows only.  Same arithmetic error
         as the direct form (both 7e-7 of fp64 on a 32 k-row case).  -> dwl, dgb, df, dbeta2, dgamma2."""
         x = f
@@ -190,30 +190,28 @@ class PatchEmbedFunction(torch.autograd.Function):
         masked, gb = ctx.masked, ctx.gb
         Gv, Gm = groups.numel(), masked.numel()
         Rv, Rm, R = Gv * 32, Gm * 32, BG * 32
-        S2, uv, gsum_v = _empty((2, c3), x), _empty((2, c3), x), _empty((Gv, c3), x)
+        S2, uv, dgb = _empty((2, c3), x), _empty((2, c3), x), _empty((BG, c3), x)
         _lib.call('pdae_bnrelu_backward_listed', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
-                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(gsum_v), _lib.ptr(uv), Gv,
-                  _lib.ptr(groups))                                   # d3c <- dh of the visible rows
+                  _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), 1, _lib.ptr(uv), Gv,
+                  _lib.ptr(groups))              # d3c <- dh of the visible rows; dgb[visible groups] <- their row sums
         u, v = uv[0], uv[1]
         fsum_m = _empty((Gm, c2), x)
         _lib.call('pdae_group_sum_listed', x, Gm, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(fsum_m))
-        gb_m = gb.index_select(0, masked.long())
-        # ---- weight gradient
+        xe = torch.addcmul(u, gb.index_select(0, masked.long()), v)   # u + v * gb_g  (Gm, 512)
+        # ---- weight gradient: dW_visible + diag(v) W Gram + xe^T fsum   (u (x) sum f rides in xe)
         dwl, gram = _empty((c3, c2), x), _empty((c2, c2), x)
         _lib.call('pdae_linear_backward_weight_listed', x, Rv, c3, c2, _lib.ptr(d3c), None, _lib.ptr(f),
                   _lib.ptr(groups), _lib.ptr(dwl), None)
         _lib.call('pdae_linear_backward_weight_listed', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(f),
                   _lib.ptr(masked), _lib.ptr(gram), None)
-        corr = _gemm(wl, gram).add_(_wgrad(gb_m, fsum_m))             # W Gram (Gram is symmetric) + gb_m^T fsum_m
-        dwl.addcmul_(v.unsqueeze(1), corr).add_(u.unsqueeze(1) * fsum_m.sum(0, keepdim=True))
-        # ---- per-group sums (the global half of the split concat weight)
-        dgb = _empty((BG, c3), x)
-        dgb.index_copy_(0, groups.long(), gsum_v)
-        hs = _gemm(fsum_m, wl).add_(gb_m, alpha=32.0)                 # sum_{r in g} h_r
-        dgb.index_copy_(0, masked.long(), torch.addcmul(32.0 * u, v, hs))
+        dwl.addcmul_(v.unsqueeze(1), _gemm(wl, gram)).add_(_wgrad(xe, fsum_m))      # (Gram is symmetric)
+        # ---- per-group sums of the masked groups (the global half of the split concat weight)
+        hs = _gemm(fsum_m, wl)                                        # the group's summed conv output, bias term apart
+        _lib.call('pdae_masked_group_sums', x, Gm, c3, _lib.ptr(hs), _lib.ptr(xe), _lib.ptr(v), _lib.ptr(masked),
+                  _lib.ptr(dgb))
         # ---- data gradient
         q = _wgrad(wl * v.unsqueeze(1), wl)                           # W^T diag(v) W  (symmetric)
-        e = _gemm(torch.addcmul(u, gb_m, v), wl, True)                # (gb_g * v + u) W   (Gm, 256)
+        e = _gemm(xe, wl, True)                                       # (gb_g * v + u) W   (Gm, 256)
         df = _empty((R, c2), x)
         _lib.call('pdae_group_gemm_scatter', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(q), _lib.ptr(e),
                   _lib.ptr(df), c2, _lib.ptr(masked))
