@@ -154,10 +154,13 @@ class PatchEmbedFunction(torch.autograd.Function):
         # conv4: BN2+ReLU producer, only the group max leaves the kernel.  It comes after the
         # last BatchNorm, so it is evaluated only for the groups whose tokens are used
         # (`groups`: the visible patches; masked tokens are discarded by the caller).
+        algebra = ALGEBRA and groups is not None and masked is not None and masked.numel() > 0 and training
         if groups is not None:
             Gv = groups.numel()
-            inv = torch.full((BG,), -1, dtype=torch.int32, device=x.device)
-            inv[groups.long()] = torch.arange(Gv, dtype=torch.int32, device=x.device)
+            inv = None
+            if not algebra:          # the dense BatchNorm backward wants group -> position in the list
+                inv = torch.full((BG,), -1, dtype=torch.int32, device=x.device)
+                inv[groups.long()] = torch.arange(Gv, dtype=torch.int32, device=x.device)
         else:
             Gv, inv = BG, None
         Rv = Gv * 32
@@ -170,7 +173,7 @@ class PatchEmbedFunction(torch.autograd.Function):
                               w1m, w2m, wg, wl, w4m, g1, g2, groups, inv)
         ctx.training = training
         # masked groups by algebra (backward): needs the complementary list and the per-group bias term
-        ctx.algebra = ALGEBRA and groups is not None and masked is not None and masked.numel() > 0 and training
+        ctx.algebra = algebra
         if ctx.algebra:
             ctx.masked, ctx.gb = masked.contiguous(), gb
         return tok
