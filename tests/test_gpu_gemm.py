@@ -290,3 +290,61 @@ def test_conv1_stats_and_bn_finalize(R, C):
            float(bn.eps), 0.1, None, None, None, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
            invstd.data_ptr())
     _close(mean, y64.mean(0).float(), 1e-5)
+
+
+def test_listed_group_entries():
+    """The group-list entries of the algebraic embedder backward against torch on gathered rows:
+    linear_backward_weight_listed (gathers on either operand; Gram matrix), group_gemm_scatter (gather, per-group
+    bias, scatter; untouched rows stay), group_sum_listed, masked_group_sums, and their argument checks."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    G, C, K = 40, 256, 128
+    f = torch.randn(G * 32, C, device='cuda', generator=g)
+    lst = torch.tensor([3, 0, 17, 39, 8, 21], device='cuda', dtype=torch.int32)
+    rows = (lst.long().unsqueeze(1) * 32 + torch.arange(32, device='cuda')).reshape(-1)
+    M = rows.numel()
+    # Gram matrix of the listed rows
+    gram = torch.full((C, C), float('nan'), device='cuda')
+    L.call('pdae_linear_backward_weight_listed', f, M, C, C, f.data_ptr(), lst.data_ptr(), f.data_ptr(), lst.data_ptr(),
+           gram.data_ptr(), None)
+    _close(gram, f[rows].double().t() @ f[rows].double(), 2e-5)
+    # compact dY against gathered X, with the bias-gradient column sums
+    dy = torch.randn(M, K, device='cuda', generator=g)
+    dw, db = torch.empty(K, C, device='cuda'), torch.empty(K, device='cuda')
+    L.call('pdae_linear_backward_weight_listed', f, M, K, C, dy.data_ptr(), None, f.data_ptr(), lst.data_ptr(),
+           dw.data_ptr(), db.data_ptr())
+    _close(dw, dy.double().t() @ f[rows].double(), 2e-5)
+    _close(db, dy.double().sum(0), 2e-5)
+    # gather -> product -> per-group bias -> scatter
+    w = torch.randn(K, C, device='cuda', generator=g) * 0.1
+    gbias = torch.randn(lst.numel(), K, device='cuda', generator=g)
+    y = torch.full((G * 32, K), 7.0, device='cuda')
+    L.call('pdae_group_gemm_scatter', f, M, K, C, f.data_ptr(), lst.data_ptr(), w.data_ptr(), gbias.data_ptr(),
+           y.data_ptr(), K, lst.data_ptr())
+    want = torch.full((G * 32, K), 7.0, device='cuda', dtype=torch.float64)
+    want[rows] = f[rows].double() @ w.double().t() + gbias.double().repeat_interleave(32, 0)
+    _close(y, want, 2e-5)
+    assert (y[torch.ones(G * 32, dtype=torch.bool, device='cuda').index_fill_(0, rows, False)] == 7.0).all()
+    # compact input, no bias
+    y2 = torch.zeros(G * 32, K, device='cuda')
+    xc = f[rows].contiguous()
+    L.call('pdae_group_gemm_scatter', f, M, K, C, xc.data_ptr(), None, w.data_ptr(), None, y2.data_ptr(), K, lst.data_ptr())
+    _close(y2[rows], xc.double() @ w.double().t(), 2e-5)
+    # group sums
+    gs = torch.empty(lst.numel(), C, device='cuda')
+    L.call('pdae_group_sum_listed', f, lst.numel(), C, f.data_ptr(), lst.data_ptr(), gs.data_ptr())
+    _close(gs, f.view(G, 32, C)[lst.long()].double().sum(1), 1e-5)
+    hs, xe, v = (torch.randn(lst.numel(), C, device='cuda', generator=g), torch.randn(lst.numel(), C, device='cuda', generator=g),
+                 torch.randn(C, device='cuda', generator=g))
+    dgb = torch.zeros(G, C, device='cuda')
+    L.call('pdae_masked_group_sums', f, lst.numel(), C, hs.data_ptr(), xe.data_ptr(), v.data_ptr(), lst.data_ptr(), dgb.data_ptr())
+    assert torch.allclose(dgb[lst.long()], v * hs + 32 * xe, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError, match='multiple of 32'):
+        L.call('pdae_linear_backward_weight_listed', f, 40, C, C, f.data_ptr(), None, f.data_ptr(), None, gram.data_ptr(), None)
+    with pytest.raises(RuntimeError, match='multiple of 32'):
+        L.call('pdae_group_gemm_scatter', f, 40, K, C, f.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), K, lst.data_ptr())
+    with pytest.raises(RuntimeError, match='null pointer'):
+        L.call('pdae_group_gemm_scatter', f, M, K, C, f.data_ptr(), None, w.data_ptr(), None, y.data_ptr(), K, None)
+    with pytest.raises(RuntimeError, match='n_listed <= G'):
+        L.call('pdae_bnrelu_backward_listed', f, 2, C, f.data_ptr(), f.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(),
+               v.data_ptr(), v.data_ptr(), gram.data_ptr(), None, 0, None, 5, lst.data_ptr())
