@@ -359,11 +359,17 @@ int pdae_pool_bn_backward(long long G, int ns, int C, const float* grad, const u
  *       dp[b,c] = sum_g dpre,  dgd_part[blk][g] = sum over block blk's 64 (b,c) pairs --
  *       the caller adds the fold_input_grad_parts(clouds, coarse) partial sets in
  *       order (no atomics) and reduces dp over c for da.  C/4 must divide 256. */
+/*   fold_out_backward: the stage's last layer (C -> 3 outputs zero-padded to 4, weight W[4][C]) backwards in one
+ *       pass over the kept middle activation h2: d2[r] = (h2[r] > 0) ? dy[r] . W : 0 and the per-block partials
+ *       part[blk][4][C] of dW = dy^T h2 (fold_out_backward_parts(rows) sets; the caller adds them in order). */
 int pdae_fold_input(int clouds, int coarse, int cells, int C, const float* a, const float* p,
                     const float* gd, float* h, pdae_stream_t stream);
 int pdae_fold_input_grad_parts(int clouds, int coarse);
 int pdae_fold_input_grad(int clouds, int coarse, int cells, int C, const float* dpre, float* dp,
                          float* dgd_part, pdae_stream_t stream);
+int pdae_fold_out_backward_parts(long long rows);
+int pdae_fold_out_backward(long long rows, int C, const float* dy /*[rows][4]*/, const float* h2, const float* W,
+                           float* d2, float* part, pdae_stream_t stream);
 
 /* Batched Y_b[M,N] = X_b[M,K] . W_b[N,K]^T, b < batch, element strides between the
  * problems (W_b = X_b: the Gram matrices behind DGCNN's feature-space kNN,

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "pdae_pool_bn_backward": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_fold_out_backward": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -83,6 +84,7 @@ _HOST = {
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
     "pdae_fold_input_grad_parts": [_i, _i],
+    "pdae_fold_out_backward_parts": [ctypes.c_longlong],
     "pdae_pool_bn_backward_workspace": [ctypes.c_longlong, _i],
     "pdae_deterministic": [],
 }

@@ -437,8 +437,16 @@ class _FoldMLP(torch.autograd.Function):
         h1, h2, w2, w3 = ctx.saved_tensors
         clouds, coarse, cells, C = ctx.dims
         dy = dy.contiguous()
-        d2 = rows_gemm(dy, w3, True, None, 4, h2)                   # gradient of h2's pre-activation
-        (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
+        if w3.shape[0] == 4 and 256 % (C // 4) == 0:
+            # the 512 -> 3(+1) layer backwards in one pass over h2 (csrc/folding.hip fold_out_backward)
+            parts = _lib.lib().pdae_fold_out_backward_parts(dy.shape[0])
+            d2, part = torch.empty_like(h2), _empty((parts, 4, C), dy)
+            _lib.call('pdae_fold_out_backward', dy, dy.shape[0], C, _lib.ptr(dy), _lib.ptr(h2), _lib.ptr(w3.contiguous()),
+                      _lib.ptr(d2), _lib.ptr(part))
+            dw3, db3 = part.sum(0), dy.sum(0)
+        else:
+            d2 = rows_gemm(dy, w3, True, None, 4, h2)               # gradient of h2's pre-activation
+            (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
         # (the 1.1 TFLOP product of the stage: the [N,K] form of the kernel is 8 % faster than the [K,N] form at
         #  this size, and transposing the 1 MB weight costs nothing)
         d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1)  # gradient of h1's pre-activation

@@ -249,3 +249,26 @@ def test_fold_input_and_grad(clouds, coarse, cells, C):
     d4 = d.double().view(clouds, coarse, cells, C)
     _close(dp, d4.sum(2).reshape(-1, C), 1e-5)
     _close(part.sum(0), d4.sum((0, 1)), 1e-5)
+
+
+@pytest.mark.parametrize('rows,C', [(5000, 512), (1024, 128), (77, 64), (3000, 1024)])
+def test_fold_out_backward(rows, C):
+    """the 512 -> 3(+1) layer backwards in one pass: masked data gradient + ordered weight-gradient partials"""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(rows)
+    dy = torch.randn(rows, 4, device='cuda', generator=g)
+    dy[:, 3] = 0.0
+    h2 = torch.relu(torch.randn(rows, C, device='cuda', generator=g))
+    w = torch.randn(4, C, device='cuda', generator=g) * 0.1
+    parts = L.lib().pdae_fold_out_backward_parts(rows)
+    assert parts == (rows + 1023) // 1024
+    res = []
+    for _ in range(2):
+        d2 = torch.full((rows, C), float('nan'), device='cuda')
+        part = torch.full((parts, 4, C), float('nan'), device='cuda')
+        L.call('pdae_fold_out_backward', dy, rows, C, dy.data_ptr(), h2.data_ptr(), w.data_ptr(), d2.data_ptr(), part.data_ptr())
+        res.append((d2, part))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    _close(res[0][0], (dy.double() @ w.double()) * (h2 > 0), 2e-5)
+    _close(res[0][1].sum(0), dy.double().t() @ h2.double(), 2e-5)
+    assert (res[0][0][h2 == 0] == 0).all()
