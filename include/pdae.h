@@ -459,6 +459,12 @@ int pdae_embed_bnrelu_conv_store_groupmax(int M, int N, int K, const float* X,
 int pdae_embed_conv1_stats(int R, int C, const float* x, const float* W,
                            const float* bias /*nullable*/, float* y,
                            double* stats, pdae_stream_t stream);
+/* embed_conv1_backward_weight: the first conv's weight gradient (K = 3), dW[c][k] = sum_r d[r][c] x[r][k], as
+ * per-block partials part[blk][3][C] in one pass over d (embed_conv1_backward_weight_parts(R) sets; the caller
+ * adds them in block order and transposes to the (C, 3, 1) weight layout). */
+int pdae_embed_conv1_backward_weight_parts(int R);
+int pdae_embed_conv1_backward_weight(int R, int C, const float* d, const float* x, float* part,
+                                     pdae_stream_t stream);
 int pdae_bn_finalize(int C, long long rows, const double* stats64 /*nullable*/,
                      const float* partials /*nullable*/, int P,
                      const float* gamma, const float* beta, float eps,

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "pdae_scale_colsum": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_embed_conv1_stats": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_conv1_backward_weight": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_bn_finalize": [_i, ctypes.c_longlong, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_adamw_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp],
     "pdae_bnrelu_backward_listed": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
@@ -84,6 +85,7 @@ _HOST = {
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
     "pdae_fold_input_grad_parts": [_i, _i],
+    "pdae_embed_conv1_backward_weight_parts": [_i],
     "pdae_fold_out_backward_parts": [ctypes.c_longlong],
     "pdae_pool_bn_backward_workspace": [ctypes.c_longlong, _i],
     "pdae_deterministic": [],

@@ -470,3 +470,57 @@ extern "C" int pdae_masked_group_sums(int n_listed, int C, const float* hs, cons
                      reinterpret_cast<const float4*>(v), groups, reinterpret_cast<float4*>(dgb));
   return check_launch("masked_group_sums");
 }
+
+// Weight gradient of the embedder's first conv (K = 3): dW[c][k] = sum_r d[r][c] * x[r][k], one pass over d.
+// On the grouped MFMA kernel this N = 128, K = 3(+1) product cost 78 + 44 us (a 128x128 tile for 3 useful
+// columns, 512 partial tiles to add); here a thread owns four channels of a row phase and walks its rows, the
+// phases meet in LDS and every block stores one partial [3][C] (the caller adds the partials in block order).
+namespace pdae {
+constexpr int C1B_ROWS = 1024;
+__global__ __launch_bounds__(256) void conv1_backward_weight_kernel(int R, int C4, const float4* __restrict__ d,
+                                                                    const float* __restrict__ x,
+                                                                    float4* __restrict__ part) {
+  extern __shared__ float4 c1b_red[];             // [phases][3][C4]
+  const int PH = 256 / C4;
+  const int q = threadIdx.x % C4, ph = threadIdx.x / C4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  const int r0 = blockIdx.x * C1B_ROWS, r1 = min(R, r0 + C1B_ROWS);
+#pragma unroll 4
+  for (int r = r0 + ph; r < r1; r += PH) {
+    const float4 g = d[(size_t)r * C4 + q];
+    const float x0 = x[(size_t)r * 3], x1 = x[(size_t)r * 3 + 1], x2 = x[(size_t)r * 3 + 2];
+    a0.x += g.x * x0, a0.y += g.y * x0, a0.z += g.z * x0, a0.w += g.w * x0;
+    a1.x += g.x * x1, a1.y += g.y * x1, a1.z += g.z * x1, a1.w += g.w * x1;
+    a2.x += g.x * x2, a2.y += g.y * x2, a2.z += g.z * x2, a2.w += g.w * x2;
+  }
+  c1b_red[(ph * 3 + 0) * C4 + q] = a0;
+  c1b_red[(ph * 3 + 1) * C4 + q] = a1;
+  c1b_red[(ph * 3 + 2) * C4 + q] = a2;
+  __syncthreads();
+  if (ph == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float4 t = c1b_red[k * C4 + q];
+      for (int p = 1; p < PH; ++p) {
+        const float4 u = c1b_red[(p * 3 + k) * C4 + q];
+        t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+      }
+      part[((size_t)blockIdx.x * 3 + k) * C4 + q] = t;
+    }
+  }
+}
+}  // namespace pdae
+
+extern "C" int pdae_embed_conv1_backward_weight_parts(int R) { return (R + pdae::C1B_ROWS - 1) / pdae::C1B_ROWS; }
+
+extern "C" int pdae_embed_conv1_backward_weight(int R, int C, const float* d, const float* x, float* part,
+                                                pdae_stream_t stream) {
+  if (R < 0 || C <= 0 || C % 4 != 0 || C > 1024 || 256 % (C / 4) != 0)
+    return bad_arg("embed_conv1_backward_weight: C/4 must divide 256");
+  if (R == 0) return PDAE_OK;
+  if (!d || !x || !part) return bad_arg("embed_conv1_backward_weight: null pointer");
+  hipLaunchKernelGGL(conv1_backward_weight_kernel, dim3((R + C1B_ROWS - 1) / C1B_ROWS), dim3(256),
+                     sizeof(float4) * 3 * 256, as_stream(stream), R, C / 4, reinterpret_cast<const float4*>(d), x,
+                     reinterpret_cast<float4*>(part));
+  return check_launch("embed_conv1_backward_weight");
+}

@@ -280,9 +280,9 @@ class PatchEmbedFunction(torch.autograd.Function):
         _lib.call('pdae_bnrelu_backward', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
                   _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None, BG, None, None, None)
         dbe1, dg1 = S1[0], S1[1]
-        xp = torch.zeros((R, 4), device=x.device, dtype=x.dtype)      # K = 3 padded to the GEMMs' multiple of 4
-        xp[:, :3] = x
-        dw1 = _wgrad(d1, xp)[:, :3].unsqueeze(-1)
+        part1 = _empty((_lib.lib().pdae_embed_conv1_backward_weight_parts(R), 3, c1), x)
+        _lib.call('pdae_embed_conv1_backward_weight', x, R, c1, _lib.ptr(d1), _lib.ptr(x), _lib.ptr(part1))
+        dw1 = part1.sum(0).t().unsqueeze(-1)                          # (c1, 3, 1): one pass over d1, ordered partials
         db1 = arena.take(c1, x)[0]                                   # exactly zero, as db3 (saves a 134 MB pass)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
                 dw4.unsqueeze(-1), db4, None, None, None, None, None)

@@ -348,3 +348,18 @@ def test_listed_group_entries():
     with pytest.raises(RuntimeError, match='n_listed <= G'):
         L.call('pdae_bnrelu_backward_listed', f, 2, C, f.data_ptr(), f.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(),
                v.data_ptr(), v.data_ptr(), gram.data_ptr(), None, 0, None, 5, lst.data_ptr())
+
+
+@pytest.mark.parametrize('R,C', [(262144, 128), (5000, 128), (77, 64)])
+def test_conv1_backward_weight(R, C):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(R)
+    d = torch.randn(R, C, device='cuda', generator=g)
+    x = torch.randn(R, 3, device='cuda', generator=g)
+    parts = L.lib().pdae_embed_conv1_backward_weight_parts(R)
+    part = torch.full((parts, 3, C), float('nan'), device='cuda')
+    L.call('pdae_embed_conv1_backward_weight', d, R, C, d.data_ptr(), x.data_ptr(), part.data_ptr())
+    _close(part.sum(0), x.double().t() @ d.double(), 2e-5)
+    part2 = torch.empty_like(part)
+    L.call('pdae_embed_conv1_backward_weight', d, R, C, d.data_ptr(), x.data_ptr(), part2.data_ptr())
+    assert torch.equal(part, part2)
