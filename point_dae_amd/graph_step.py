@@ -45,6 +45,7 @@ def _warn_if_null_stream():
                       'replays corrupts hipGraph replays on this platform)', RuntimeWarning, stacklevel=3)
 
 
+SINK = os.environ.get('PDAE_GRAD_SINK', '1') != '0'
 _AVG_OK = {}
 
 
@@ -144,11 +145,17 @@ class GraphedTrainStep:
         slot['done'].record()
         return tvis
 
-    def _gather(self, idx):
+    def _gather(self, idx, written=()):
         """Gradients are produced as fresh tensors (autograd ASSIGNS them: no 203 accumulate-add
         launches, no memset of the flat buffer) and gathered into the flat gradient buffer with one
-        multi-tensor copy."""
+        multi-tensor copy.  written: data pointers of parameters whose gradient a Function already put
+        into its flat view (nn_ops.GRAD_SINK): nothing to copy, nothing to zero."""
         m = self.model
+        if written:
+            idx = [i for i in idx if m.params[i].data_ptr() not in written or m.params[i].grad is not None]
+            for i, p in enumerate(m.params):
+                if p.grad is None and p.data_ptr() in written:
+                    p.grad = m.grad_views[i]
         have = [(m.grad_views[i], m.params[i].grad) for i in idx if m.params[i].grad is not None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
@@ -166,13 +173,19 @@ class GraphedTrainStep:
             p.grad = None
         enc = self.net.MAE_encoder
         enc.grad_cut = cut
+        # the blocks' weight gradients go straight into the flat buffer (nn_ops.GRAD_SINK): every .grad is None
+        # here and nothing else touches the flat gradient views until the gather below
+        from . import nn_ops
+        sink = {'views': {p.data_ptr(): v for p, v in zip(m.params, m.grad_views)}, 'written': set()}
+        nn_ops.GRAD_SINK = sink if SINK else None
         try:
             lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+            loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
+            loss.backward()
         finally:
             enc.grad_cut = None
-        loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
-        loss.backward()
-        self._gather(self.early_idx if cut is not None else range(len(m.params)))
+            nn_ops.GRAD_SINK = None
+        self._gather(self.early_idx if cut is not None else range(len(m.params)), sink['written'])
         return lx.detach(), ln.detach()
 
     def _phase2(self, cut):

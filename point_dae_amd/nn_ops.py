@@ -374,13 +374,29 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
     return y
 
 
-def rows_wgrad(dys, xs, with_bias):
+# Gradient sink (set by graph_step.GraphedTrainStep around its forward + backward, None otherwise): the flat
+# gradient views of the parameters by data pointer.  A Function that finds its weights here writes their
+# gradients straight into the flat buffer, reports them in GRAD_SINK['written'] and returns None for them --
+# the step's gather copy then skips those tensors (97 % of the 116 MB).  Only sound when nothing else
+# accumulates into the views during the backward, i.e. not in the eager FlatDataParallel path.
+GRAD_SINK = None
+
+
+def _sink_views(weights):
+    sink = GRAD_SINK
+    if sink is None:
+        return None
+    views = [sink['views'].get(w.data_ptr()) for w in weights]
+    return views if all(v is not None and v.shape == w.shape for v, w in zip(views, weights)) else None
+
+
+def rows_wgrad(dys, xs, with_bias, outs=None):
     """Weight (and bias) gradients of a group of Linear layers that share their rows, one grouped
-    launch (+ the ordered slab reduction).  -> ([dW], [db or None])"""
+    launch (+ the ordered slab reduction).  -> ([dW], [db or None]); outs: preallocated dW tensors."""
     M = dys[0].shape[0]
     Ns, Ks = [t.shape[1] for t in dys], [t.shape[1] for t in xs]
     ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dys[0])
-    dws = [_empty((n, k), dys[0]) for n, k in zip(Ns, Ks)]
+    dws = outs if outs is not None else [_empty((n, k), dys[0]) for n, k in zip(Ns, Ks)]
     dbs = [_empty((n,), dys[0]) if f else None for n, f in zip(Ns, with_bias)]
     _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws)
     return dws, dbs
@@ -628,12 +644,17 @@ class _TransformerBlock(torch.autograd.Function):
             da0 = dbias_in = None
         # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
         dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
+        sink = _sink_views([wqkv, wproj, w1, w2])     # graphed step: straight into the flat gradient buffer
         if tail:                               # two row counts: two groups
-            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False])
-            (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False])
+            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False], sink[:1] if sink else None)
+            (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False],
+                                                          sink[1:] if sink else None)
         else:
             (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
-                                                                    [False, False, True, False])
+                                                                    [False, False, True, False], sink)
+        if sink:
+            GRAD_SINK['written'].update(w.data_ptr() for w in (wqkv, wproj, w1, w2))
+            dwqkv = dwproj = dw1 = dw2 = None
         return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
                 dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None, None)
 
