@@ -62,6 +62,15 @@ const char* pdae_last_error(void);
 int pdae_set_deterministic(void* workspace, size_t bytes);
 int pdae_deterministic(void);   /* 1 when a workspace is registered */
 
+/* Deferred column reductions.  Between deferred_begin and deferred_flush the LayerNorm backward entries park their
+ * per-block parameter-gradient partials in `workspace` instead of finishing with float atomics; deferred_flush adds
+ * the partials of all parked calls (up to 48) in block order into their outputs with ONE launch.  The outputs
+ * (dgamma, dbeta, dbias) are complete only after the flush: for callers that consume them later, such as the
+ * hipGraph-replayed step, whose gather copy follows the whole backward (graph_step.py).  A call that does not fit
+ * the workspace simply behaves as usual.  Host-side state: one stream / one thread at a time. */
+int pdae_deferred_begin(void* workspace, size_t bytes);
+int pdae_deferred_flush(pdae_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Farthest point sampling.
  * Replaces furthest_point_sampling_kernel_wrapper(b, n, m, dataset, temp, idxs)

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "pdae_fold_input": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_fold_out_backward": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_deferred_flush": [_vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -84,6 +85,7 @@ _HOST = {
     "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
+    "pdae_deferred_begin": [_vp, ctypes.c_size_t],
     "pdae_fold_input_grad_parts": [_i, _i],
     "pdae_embed_conv1_backward_weight_parts": [_i],
     "pdae_fold_out_backward_parts": [ctypes.c_longlong],
@@ -146,6 +148,22 @@ def set_deterministic(on=True, megabytes=64):
 
 def deterministic():
     return bool(lib().pdae_deterministic())
+
+
+_def_ws = None
+
+
+def deferred_begin(megabytes=64):
+    """Park the LayerNorm parameter-gradient partials until deferred_flush (include/pdae.h)."""
+    global _def_ws
+    if _def_ws is None or _def_ws.numel() != megabytes << 20:
+        _def_ws = torch.empty(megabytes << 20, dtype=torch.uint8, device='cuda')
+    handle = lib()
+    _check(handle, 'pdae_deferred_begin', handle.pdae_deferred_begin(_def_ws.data_ptr(), _def_ws.numel()))
+
+
+def deferred_flush(on):
+    call('pdae_deferred_flush', on)
 
 
 _env_checked = False

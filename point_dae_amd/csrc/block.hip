@@ -464,6 +464,10 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
   int rc = PDAE_OK;
   float* part = static_cast<float*>(det_workspace(sizeof(float) * (size_t)blocks * nred * C, &rc));
   if (rc) return rc;
+  // between pdae_deferred_begin and _flush the partial rows are parked and added by the flush's one launch
+  // (the parameter gradients are then complete only after it): no atomics, no reduction launch per LayerNorm
+  bool parked = false;
+  if (!part && (part = deferred_take(blocks, nred * C, dgamma, C, dbeta, C, dbias, dbias ? C : 0))) parked = true;
   if (C <= 512)
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 16>), dim3(blocks), dim3(1024), 16 * nred * C * sizeof(float), s, M,
                        C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, keep, T, da, dbias, dy_slabs,
@@ -472,7 +476,7 @@ static int ln_backward(const char* what, int M, int C, int T, const float* dy, i
     hipLaunchKernelGGL((layernorm_bwd_kernel<LN_MAX4, 4>), dim3(blocks), dim3(256), 4 * nred * C * sizeof(float), s,
                        M, C, rows, dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, keep, T, da, dbias, dy_slabs,
                        dacc, dacc_mode, part);
-  if (part) return det_reduce(s, blocks, nred * C, part, dgamma, C, dbeta, C, dbias, dbias ? C : 0);
+  if (part && !parked) return det_reduce(s, blocks, nred * C, part, dgamma, C, dbeta, C, dbias, dbias ? C : 0);
   return check_launch(what);
 }
 

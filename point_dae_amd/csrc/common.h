@@ -57,6 +57,14 @@ int det_reduce(hipStream_t s, int P, int width, const float* part, float* o0, in
                int n1 = 0, float* o2 = nullptr, int n2 = 0);
 int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* out);
 
+// ---- deferred column reductions (pdae_deferred_begin / pdae_deferred_flush, det.hip) ----------
+// Between begin and flush a reduction site may park its per-block partial rows in the registered buffer
+// instead of finishing with atomics (or with its own ordered pass): deferred_take returns the rows' place
+// (nullptr when the mode is off or the buffer is full) and records the job; ONE launch at flush adds the
+// partials of all parked jobs in block order into their outputs.  Outputs are complete only after the
+// flush -- the caller (the graphed step) guarantees nothing reads them earlier.
+float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2);
+
 __device__ __forceinline__ void col_add(float* out, float* part, int partition, int width, int c, float t) {
   if (part) part[(size_t)partition * width + c] = t;
   else atomicAdd(out, t);

@@ -63,6 +63,64 @@ int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* 
   return check_launch("det_reduce_f64");
 }
 
+// ---- deferred reductions ---------------------------------------------------------------------
+constexpr int DEF_MAX = 48;
+struct DefJob {
+  const float* part;
+  float* out[3];
+  int n[3];
+  int P, width;
+};
+struct DefJobs {
+  DefJob j[DEF_MAX];
+};
+static float* g_def_ws = nullptr;
+static size_t g_def_floats = 0, g_def_used = 0;
+static bool g_def_on = false;
+static DefJobs g_def_jobs;
+static int g_def_n = 0;
+
+float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2) {
+  if (!g_def_on || g_def_n >= DEF_MAX) return nullptr;
+  const size_t need = ((size_t)P * width + 63) & ~(size_t)63;
+  if (g_def_used + need > g_def_floats) return nullptr;
+  float* part = g_def_ws + g_def_used;
+  g_def_used += need;
+  DefJob& d = g_def_jobs.j[g_def_n++];
+  d.part = part, d.P = P, d.width = width;
+  d.out[0] = o0, d.out[1] = o1, d.out[2] = o2;
+  d.n[0] = n0, d.n[1] = n1, d.n[2] = n2;
+  return part;
+}
+
+// grid (column chunks of 32, jobs); block = 32 columns x 8 partial lanes: lane l adds partials l, l + 8, ...
+// (eight loads in flight), the lanes are added in lane order, out[c] += the sum (fixed order => reproducible).
+__global__ __launch_bounds__(256) void deferred_reduce_kernel(const DefJobs jobs) {
+  const DefJob& d = jobs.j[blockIdx.y];
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float t = 0.f;
+  if (c < d.width)
+    for (int p = l; p < d.P; p += 64) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p + 8 * k < d.P ? d.part[(size_t)(p + 8 * k) * d.width + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
+    }
+  red[l][cl] = t;
+  __syncthreads();
+  if (l == 0 && c < d.width) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][cl];
+    float* out = c < d.n[0] ? (d.out[0] ? d.out[0] + c : nullptr)
+                            : (c < d.n[0] + d.n[1] ? (d.out[1] ? d.out[1] + (c - d.n[0]) : nullptr)
+                                                   : (d.out[2] ? d.out[2] + (c - d.n[0] - d.n[1]) : nullptr));
+    if (out) *out += t;
+  }
+}
+
 }  // namespace pdae
 
 extern "C" int pdae_set_deterministic(void* workspace, size_t bytes) {
@@ -73,3 +131,23 @@ extern "C" int pdae_set_deterministic(void* workspace, size_t bytes) {
 }
 
 extern "C" int pdae_deterministic(void) { return pdae::det_on() ? 1 : 0; }
+
+extern "C" int pdae_deferred_begin(void* workspace, size_t bytes) {
+  if (!workspace || bytes < (1u << 20)) return pdae::bad_arg("deferred_begin: workspace of at least 1 MiB");
+  pdae::g_def_ws = static_cast<float*>(workspace);
+  pdae::g_def_floats = bytes / sizeof(float);
+  pdae::g_def_used = 0, pdae::g_def_n = 0, pdae::g_def_on = true;
+  return PDAE_OK;
+}
+
+extern "C" int pdae_deferred_flush(pdae_stream_t stream) {
+  using namespace pdae;
+  g_def_on = false;
+  if (g_def_n == 0) return PDAE_OK;
+  int widest = 0;
+  for (int i = 0; i < g_def_n; ++i) widest = g_def_jobs.j[i].width > widest ? g_def_jobs.j[i].width : widest;
+  hipLaunchKernelGGL(deferred_reduce_kernel, dim3((widest + 31) / 32, g_def_n), dim3(256), 0, as_stream(stream),
+                     g_def_jobs);
+  g_def_n = 0;
+  return check_launch("deferred_flush");
+}

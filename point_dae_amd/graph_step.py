@@ -17,6 +17,7 @@ embedder's backward -- replays; only the embedder's 2 MB are reduced in the open
 import os
 import torch
 
+from . import _lib
 from .corrupt_util_tensor import draw_corruption
 from .data_parallel import FlatDataParallel
 from .point_cae_transformer import draw_mask, mask_row_ids
@@ -181,7 +182,16 @@ class GraphedTrainStep:
         try:
             lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
             loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
-            loss.backward()
+            # the 34 LayerNorm backward launches park their parameter-gradient partials; ONE launch adds them
+            # all after the backward (include/pdae.h: deferred reductions) -- nothing reads those gradients
+            # before the gather below
+            if SINK:
+                _lib.deferred_begin()
+            try:
+                loss.backward()
+            finally:
+                if SINK:
+                    _lib.deferred_flush(lx)
         finally:
             enc.grad_cut = None
             nn_ops.GRAD_SINK = None

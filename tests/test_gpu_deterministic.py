@@ -250,3 +250,41 @@ def test_deterministic_flag_of_the_cli_switches_the_library_mode():
     finally:
         _lib.set_deterministic(False)
         torch.backends.cudnn.deterministic = False
+
+
+def test_deferred_layernorm_reductions():
+    """pdae_deferred_begin / _flush: LayerNorm backward calls park their parameter-gradient partials and ONE
+    launch adds them -- same sums as the atomic path (1e-6), same bits twice, outputs accumulate (+=), and a
+    call that does not fit the workspace falls back to the usual path."""
+    from point_dae_amd import _lib, nn_ops
+    torch.manual_seed(7)
+    lns = [torch.nn.LayerNorm(384).cuda() for _ in range(5)]
+    xs = [torch.randn(m, 384, device='cuda') for m in (3584, 8192, 1664, 100, 16)]
+    gos = [torch.randn_like(x) for x in xs]
+
+    def run(deferred, small=False):
+        for ln in lns:
+            ln.zero_grad()
+        ys = [nn_ops.layer_norm(x.clone().requires_grad_(), ln) for x, ln in zip(xs, lns)]
+        if deferred and small:           # 1 MiB: only some of the calls fit, the others take the usual path
+            _lib._check(_lib.lib(), 'pdae_deferred_begin', _lib.lib().pdae_deferred_begin(_lib._def_ws.data_ptr(), 1 << 20))
+        elif deferred:
+            _lib.deferred_begin()
+        for y, go in zip(ys, gos):
+            y.backward(go)
+        if deferred:
+            _lib.deferred_flush(xs[0])
+        return [(ln.weight.grad.clone(), ln.bias.grad.clone()) for ln in lns]
+
+    ref = run(False)
+    a, b = run(True), run(True)
+    for (rw, rb), (aw, ab), (bw, bb) in zip(ref, a, b):
+        assert torch.equal(aw, bw) and torch.equal(ab, bb)
+        assert (aw - rw).abs().max().item() <= 2e-6 * rw.abs().max().item()
+        assert (ab - rb).abs().max().item() <= 2e-6 * rb.abs().max().item()
+    again = run(False)                                               # the mode is off again after the flush
+    small = run(True, small=True)
+    for (rw, rb), (gw, gb_), (sw, sb) in zip(ref, again, small):
+        assert (gw - rw).abs().max().item() <= 2e-6 * rw.abs().max().item()
+        assert (sw - rw).abs().max().item() <= 2e-6 * rw.abs().max().item()
+        assert (sb - rb).abs().max().item() <= 2e-6 * rb.abs().max().item()
