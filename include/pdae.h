@@ -70,6 +70,10 @@ int pdae_deterministic(void);   /* 1 when a workspace is registered */
  * the workspace simply behaves as usual.  Host-side state: one stream / one thread at a time. */
 int pdae_deferred_begin(void* workspace, size_t bytes);
 int pdae_deferred_flush(pdae_stream_t stream);
+/* rows_wgrad parks its partial-tile reduction in the same window (the dW / db outputs and the workspace of the call
+ * must then stay untouched until the flush, which adds the tiles of up to 8 parked launches per reduction launch).
+ * deferred_hold(1) ... deferred_hold(0) brackets calls whose results the caller reads right away. */
+int pdae_deferred_hold(int hold);
 
 /* ------------------------------------------------------------------------
  * Farthest point sampling.

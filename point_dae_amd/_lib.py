@@ -86,6 +86,7 @@ _HOST = {
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
     "pdae_deferred_begin": [_vp, ctypes.c_size_t],
+    "pdae_deferred_hold": [_i],
     "pdae_fold_input_grad_parts": [_i, _i],
     "pdae_embed_conv1_backward_weight_parts": [_i],
     "pdae_fold_out_backward_parts": [ctypes.c_longlong],
@@ -160,10 +161,17 @@ def deferred_begin(megabytes=64):
         _def_ws = torch.empty(megabytes << 20, dtype=torch.uint8, device='cuda')
     handle = lib()
     _check(handle, 'pdae_deferred_begin', handle.pdae_deferred_begin(_def_ws.data_ptr(), _def_ws.numel()))
+    global _def_keep
+    _def_keep = []
+
+
+_def_keep = None      # while reductions are parked: the workspaces their partials live in
 
 
 def deferred_flush(on):
+    global _def_keep
     call('pdae_deferred_flush', on)
+    _def_keep = None      # (the flush is enqueued: later allocations reuse the memory behind it in stream order)
 
 
 _env_checked = False
@@ -258,10 +266,18 @@ def rows_wgrad_workspace(M, Ns, Ks):
     return hit
 
 
-def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace):
-    """pdae_rows_wgrad over lists of tensors (dbs entries may be None)."""
+def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace, may_defer=False):
+    """pdae_rows_wgrad over lists of tensors (dbs entries may be None).  may_defer: the caller hands the results
+    to autograd without reading them, so inside a deferred window the reduction may be parked until the flush."""
+    parked = _def_keep is not None and may_defer
+    if _def_keep is not None and not may_defer:
+        lib().pdae_deferred_hold(1)
     n = len(dYs)
     parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
     call('pdae_rows_wgrad', on, M, n, parr(*[ptr(t) for t in dYs]), parr(*[ptr(t) for t in Xs]),
          parr(*[ptr(t) for t in dWs]), parr(*[ptr(t) for t in dbs]),
          iarr(*[t.shape[1] for t in dYs]), iarr(*[t.shape[1] for t in Xs]), ptr(workspace))
+    if parked:                           # the reduction is parked until deferred_flush: so is the workspace
+        _def_keep.append(workspace)
+    elif _def_keep is not None:
+        lib().pdae_deferred_hold(0)

@@ -64,6 +64,8 @@ int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* 
 // partials of all parked jobs in block order into their outputs.  Outputs are complete only after the
 // flush -- the caller (the graphed step) guarantees nothing reads them earlier.
 float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2);
+bool deferred_on();
+int rows_wgrad_flush(hipStream_t s);   // rows_gemm.hip: the parked weight-gradient reductions
 
 __device__ __forceinline__ void col_add(float* out, float* part, int partition, int width, int c, float t) {
   if (part) part[(size_t)partition * width + c] = t;

@@ -76,12 +76,14 @@ struct DefJobs {
 };
 static float* g_def_ws = nullptr;
 static size_t g_def_floats = 0, g_def_used = 0;
-static bool g_def_on = false;
+static bool g_def_on = false, g_def_hold = false;
 static DefJobs g_def_jobs;
 static int g_def_n = 0;
 
+bool deferred_on() { return g_def_on && !g_def_hold; }
+
 float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2) {
-  if (!g_def_on || g_def_n >= DEF_MAX) return nullptr;
+  if (!deferred_on() || g_def_n >= DEF_MAX) return nullptr;
   const size_t need = ((size_t)P * width + 63) & ~(size_t)63;
   if (g_def_used + need > g_def_floats) return nullptr;
   float* part = g_def_ws + g_def_used;
@@ -136,13 +138,15 @@ extern "C" int pdae_deferred_begin(void* workspace, size_t bytes) {
   if (!workspace || bytes < (1u << 20)) return pdae::bad_arg("deferred_begin: workspace of at least 1 MiB");
   pdae::g_def_ws = static_cast<float*>(workspace);
   pdae::g_def_floats = bytes / sizeof(float);
-  pdae::g_def_used = 0, pdae::g_def_n = 0, pdae::g_def_on = true;
+  pdae::g_def_used = 0, pdae::g_def_n = 0, pdae::g_def_on = true, pdae::g_def_hold = false;
   return PDAE_OK;
 }
 
 extern "C" int pdae_deferred_flush(pdae_stream_t stream) {
   using namespace pdae;
   g_def_on = false;
+  const int rc = rows_wgrad_flush(as_stream(stream));
+  if (rc) return rc;
   if (g_def_n == 0) return PDAE_OK;
   int widest = 0;
   for (int i = 0; i < g_def_n; ++i) widest = g_def_jobs.j[i].width > widest ? g_def_jobs.j[i].width : widest;
@@ -150,4 +154,9 @@ extern "C" int pdae_deferred_flush(pdae_stream_t stream) {
                      g_def_jobs);
   g_def_n = 0;
   return check_launch("deferred_flush");
+}
+
+extern "C" int pdae_deferred_hold(int hold) {
+  pdae::g_def_hold = hold != 0;
+  return PDAE_OK;
 }

@@ -617,13 +617,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 // 121 us, PL = 8 takes 15).  Elements outside the weight are skipped.  The blocks with part == 0
 // also reduce the bias-gradient column sums.
 template <int PL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+__device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block) {
   constexpr int EPB = 256 / PL;              // float4 per block
   constexpr int PARTS = WTM * WTN / 4 / EPB;  // blocks per tile
   static_assert(EPB >= WTM / 4, "the bias sums of a tile fit one block");
   __shared__ float4 red[PL > 1 ? PL : 1][EPB];
   __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
-  const int tile = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
+  const int tile = block / PARTS, part = block % PARTS;
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < WG_MAX; ++q)
@@ -680,6 +680,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
   }
   if (valid) *reinterpret_cast<float4*>(P.dW + (size_t)row * P.K + col) = s;
   if (bias) *reinterpret_cast<float4*>(P.db + n0 + el * 4) = bs;
+}
+
+template <int PL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
+  wgrad_reduce_body<PL>(g, blockIdx.x);
+}
+
+// the reductions of several deferred grouped launches (pdae_deferred_begin / _flush) in one launch
+constexpr int WG_MULTI = 8;
+struct WgradMulti {
+  int njobs;
+  int first[WG_MULTI + 1];     // first block of job j; first[njobs] = the grid
+  WgradArgs job[WG_MULTI];
+};
+template <int PL>
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradMulti m) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < WG_MULTI; ++q)
+    if (q < m.njobs && (int)blockIdx.x >= m.first[q]) j = q;
+  wgrad_reduce_body<PL>(m.job[j], (int)blockIdx.x - m.first[j]);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -907,6 +928,39 @@ static int wgrad_layout(int M, int nprob, const int* Ns, const int* Ks, WgradArg
   return PDAE_OK;
 }
 
+constexpr int WG_DEFER_MAX = 64;
+static WgradArgs g_wg_jobs[WG_DEFER_MAX];
+static int g_wg_pl[WG_DEFER_MAX];
+static int g_wg_n = 0;
+
+namespace pdae {
+// called by pdae_deferred_flush (det.hip): the parked reductions, grouped by lane count, up to WG_MULTI per launch
+int rows_wgrad_flush(hipStream_t s) {
+  using namespace rows;
+  for (int pl : {1, 4, 8}) {
+    WgradMulti m;
+    m.njobs = 0, m.first[0] = 0;
+    auto launch = [&]() {
+      if (m.njobs == 0) return;
+      const unsigned grid = (unsigned)m.first[m.njobs];
+      if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<1>, dim3(grid), dim3(256), 0, s, m);
+      else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<4>, dim3(grid), dim3(256), 0, s, m);
+      else hipLaunchKernelGGL(wgrad_reduce_multi_kernel<8>, dim3(grid), dim3(256), 0, s, m);
+      m.njobs = 0, m.first[0] = 0;
+    };
+    for (int i = 0; i < g_wg_n; ++i) {
+      if (g_wg_pl[i] != pl) continue;
+      m.job[m.njobs] = g_wg_jobs[i];
+      m.first[m.njobs + 1] = m.first[m.njobs] + g_wg_jobs[i].tiles * 16 * pl;
+      if (++m.njobs == WG_MULTI) launch();
+    }
+    launch();
+  }
+  g_wg_n = 0;
+  return check_launch("rows_wgrad_flush");
+}
+}  // namespace pdae
+
 extern "C" int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks, long long* floats) {
   if (M < 0 || nprob <= 0 || nprob > WG_MAX || !Ns || !Ks || !floats)
     return bad_arg("rows_wgrad_workspace: bad argument");
@@ -942,8 +996,16 @@ extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const f
   hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
   // partial lanes of the reduction by the most partials a tile can have
   const long long most = (g.chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
-  if (most <= 16) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
-  else if (most <= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
+  const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
+  if (deferred_on() && g_wg_n < WG_DEFER_MAX) {
+    // between pdae_deferred_begin and _flush the reduction is postponed: the flush adds the partial tiles of
+    // all parked launches with a few launches that fill the chip (the workspace must live until then)
+    g_wg_pl[g_wg_n] = pl;
+    g_wg_jobs[g_wg_n++] = g;
+    return check_launch("rows_wgrad");
+  }
+  if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
+  else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(g.tiles * 128), dim3(256), 0, s, g);
   return check_launch("rows_wgrad");
 }

@@ -200,7 +200,13 @@ class GraphedTrainStep:
 
     def _phase2(self, cut):
         """the patch embedder's backward from the token gradient phase 1 left in cut['leaf'].grad"""
-        cut['tokens'].backward(cut['leaf'].grad)
+        if SINK:
+            _lib.deferred_begin()
+        try:
+            cut['tokens'].backward(cut['leaf'].grad)
+        finally:
+            if SINK:
+                _lib.deferred_flush(self.pts)
         self._gather(self.late_idx)
         cut.clear()
 

@@ -390,15 +390,20 @@ def _sink_views(weights):
     return views if all(v is not None and v.shape == w.shape for v, w in zip(views, weights)) else None
 
 
-def rows_wgrad(dys, xs, with_bias, outs=None):
+def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     """Weight (and bias) gradients of a group of Linear layers that share their rows, one grouped
-    launch (+ the ordered slab reduction).  -> ([dW], [db or None]); outs: preallocated dW tensors."""
+    launch (+ the ordered slab reduction).  -> ([dW], [db or None]); outs / db_outs: preallocated outputs
+    (db_outs: one per True in with_bias).  When EVERY output is preallocated by the caller -- the flat gradient
+    views of nn_ops.GRAD_SINK, which autograd never sees -- the reduction may be parked until
+    _lib.deferred_flush; a tensor handed to autograd may be cloned by it on the spot and must be complete."""
     M = dys[0].shape[0]
     Ns, Ks = [t.shape[1] for t in dys], [t.shape[1] for t in xs]
     ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dys[0])
     dws = outs if outs is not None else [_empty((n, k), dys[0]) for n, k in zip(Ns, Ks)]
-    dbs = [_empty((n,), dys[0]) if f else None for n, f in zip(Ns, with_bias)]
-    _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws)
+    it = iter(db_outs) if db_outs is not None else None
+    dbs = [(next(it) if it is not None else _empty((n,), dys[0])) if f else None for n, f in zip(Ns, with_bias)]
+    _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws,
+                    may_defer=outs is not None and (db_outs is not None or not any(with_bias)))
     return dws, dbs
 
 
@@ -553,7 +558,7 @@ class _PosEmbed(torch.autograd.Function):
 def pos_embed(xyz_rows, seq):
     """Linear(3,128) -> GELU -> Linear(128,C) (PointCAE_transformer.py:329-333)."""
     if not xyz_rows.is_cuda:
-        return seq[2](F.gelu(seq[0](xyz_rows)))
+        raise RuntimeError('pos_embed: rows must be on the GPU (there is no CPU path)')
     return _PosEmbed.apply(xyz_rows.contiguous(), seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
 
 
@@ -600,7 +605,7 @@ class _TransformerBlock(torch.autograd.Function):
         h = rows_gemm(n2, w1, False, bf1, 2, gp)
         a2 = rows_gemm(h, w2, may_split=True)
         ctx.save_for_backward(x1, n1, mean1, rstd1, qkv, o, lse, x2, n2, mean2, rstd2, gp, h, keep_in, keep1,
-                              g1, wqkv, wproj, g2, w1, w2)
+                              g1, wqkv, wproj, g2, w1, w2, bf1)
         ctx.dims = (B, T, H, D, float(scale))
         ctx.tail = tail
         ctx.has_in, ctx.has_pos, ctx.has_bias_in, ctx.in_slabs = a_in is not None, pos is not None, bias_in is not None, \
@@ -613,7 +618,7 @@ class _TransformerBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, da2, dx2):
         (x1, n1, mean1, rstd1, qkv, o, lse, x2, n2, mean2, rstd2, gp, h, keep_in, keep1,
-         g1, wqkv, wproj, g2, w1, w2) = ctx.saved_tensors
+         g1, wqkv, wproj, g2, w1, w2, bf1) = ctx.saved_tensors
         B, T, H, D, scale = ctx.dims
         da2 = _from_slabs(da2).contiguous()
         dz = rows_gemm(da2, w2, True, None, 3, gp)                        # (M, 4C): GELU' in the epilogue
@@ -644,17 +649,18 @@ class _TransformerBlock(torch.autograd.Function):
             da0 = dbias_in = None
         # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
         dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
-        sink = _sink_views([wqkv, wproj, w1, w2])     # graphed step: straight into the flat gradient buffer
+        sink = _sink_views([wqkv, wproj, w1, w2, bf1])     # graphed step: straight into the flat gradient buffer
+        ws_, bs_ = (sink[:4], sink[4:]) if sink else (None, None)
         if tail:                               # two row counts: two groups
-            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False], sink[:1] if sink else None)
+            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False], ws_[:1] if sink else None)
             (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False],
-                                                          sink[1:] if sink else None)
+                                                          ws_[1:] if sink else None, bs_)
         else:
             (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
-                                                                    [False, False, True, False], sink)
+                                                                    [False, False, True, False], ws_, bs_)
         if sink:
-            GRAD_SINK['written'].update(w.data_ptr() for w in (wqkv, wproj, w1, w2))
-            dwqkv = dwproj = dw1 = dw2 = None
+            GRAD_SINK['written'].update(w.data_ptr() for w in (wqkv, wproj, w1, w2, bf1))
+            dwqkv = dwproj = dw1 = dw2 = dbf1 = None
         return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
                 dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None, None)
 

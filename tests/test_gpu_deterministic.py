@@ -288,3 +288,50 @@ def test_deferred_layernorm_reductions():
         assert (gw - rw).abs().max().item() <= 2e-6 * rw.abs().max().item()
         assert (sw - rw).abs().max().item() <= 2e-6 * rw.abs().max().item()
         assert (sb - rb).abs().max().item() <= 2e-6 * rb.abs().max().item()
+
+
+@pytest.mark.parametrize('mode', ['atomic', 'deterministic'])
+def test_graphed_step_gradients_equal_eager_gradients(mode):
+    """One step's gradients, every parameter: the graphed step's path (gradient sink for the blocks' weights,
+    parked LayerNorm / weight-gradient reductions, one flush) against plain eager autograd into the flat buffer.
+    Catches a gradient that was read (or cloned by autograd) before its deferred reduction ran."""
+    from point_dae_amd import _lib, builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(
+        ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.transformer_config.drop_path_rate = 0.0
+    config.model.transformer_config.depth = 3
+    config.model.transformer_config.decoder_depth = 2
+    if mode == 'deterministic':
+        _lib.set_deterministic(True)
+    try:
+        torch.manual_seed(0)
+        net_a = builder.model_builder(config.model).cuda().train()
+        net_b = copy.deepcopy(net_a)
+        B = 16
+        x = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=4)).cuda()
+        model_a, model_b = FlatDataParallel(net_a), FlatDataParallel(net_b)
+        opt_b, _ = builder.build_opti_sche(model_b, config)
+        step = GraphedTrainStep(model_b, opt_b, config, B, 1024, warmup_eager=1)
+        random.seed(9), np.random.seed(9), torch.manual_seed(9)
+        step.pts.copy_(x)
+        tvis = step._draw()
+        step._phase1(tvis)                                           # eager launches of the graphed step's body
+        nv = B * tvis
+        model_a.zero_grad()
+        la, lna = model_a(step.pts, step.pts, steps=step.steps, rows=(step.vis[:nv], step.msk[:B * (step.G - tvis)]))
+        (la + step.normal_weight * lna.sum()).backward()
+        tol = 1e-6 if mode == 'deterministic' else 2e-3      # (atomic mode: summation-order noise, measured 2.5e-4)
+        for name, (off, n) in zip(model_a.names, model_a.offsets):
+            ga, gb = model_a.flat_grad[off:off + n], model_b.flat_grad[off:off + n]
+            scale = ga.abs().max().item()
+            if scale < 1e-7:
+                assert gb.abs().max().item() < 1e-5, name
+                continue
+            assert (ga - gb).abs().max().item() <= tol * scale, (name, (ga - gb).abs().max().item(), scale)
+    finally:
+        if mode == 'deterministic':
+            _lib.set_deterministic(False)
