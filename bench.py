@@ -54,6 +54,8 @@ def parse():
     p.add_argument('--steps', type=int, default=50)
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg2'])
+    p.add_argument('--model-name', default=None,
+                   help='override model.NAME of the cfg3 YAML (e.g. PointCAE_transformer_fc_global_folding_local, the published runs)')
     p.add_argument('--batch', type=int, default=128, help='clouds per GPU')
     p.add_argument('--npoints', type=int, default=1024)
     p.add_argument('--num_group', type=int, default=64)
@@ -326,6 +328,8 @@ def main():
     from point_dae_amd.synthetic import shapenet_like_clouds
 
     config = cfg_from_yaml_file(os.path.join(ROOT, CFG3 if args.workload == 'cfg3' else CFG2))
+    if args.model_name and args.workload == 'cfg3':
+        config.model.NAME = args.model_name
     config.npoints = args.npoints
     config.model.num_group = args.num_group
     if args.workload == 'cfg2':
@@ -447,7 +451,8 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
+            'config': {'workload': (('model ' + args.model_name + ' on ' if args.model_name else '') +
+                                    'cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
                                     if args.workload == 'cfg3' else
                                     'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2) ') +
                                    'full train step (fwd+loss+bwd+AdamW%s)' % ('+RCCL all-reduce' if world > 1 else ''),
