@@ -516,6 +516,14 @@ class PointNetv2_encoder(nn.Module):
         return l3.view(xyz.shape[0], 1024)
 
 
+def dropout_global_random(pointcloud, drop_rate=0.5):
+    """datasets/corrupt_util.py:572-588: a random half of every cloud (one CPU torch.rand per batch, argsort)."""
+    num_samples, num_points = pointcloud.size(0), pointcloud.size(1)
+    inx = torch.rand(num_samples, num_points, 1).argsort(1).to(pointcloud.device)
+    pointcloud = torch.take_along_dim(pointcloud, inx, dim=1)
+    return pointcloud[:, :int(num_points * (1 - drop_rate)), :].contiguous()
+
+
 class Point_CAE_PointNetv2(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -539,7 +547,9 @@ class Point_CAE_PointNetv2(nn.Module):
         corrupted_pts = corrupted_pts[:, :, :3].contiguous()
         pts = pts[:, :, :3].contiguous()
         for item in self.corrupt_type:                 # only the CUDA-side dropouts act here (:144-149)
-            if item in ('dropout_patch_pointmae', 'dropout_global'):
+            if item == 'dropout_global':
+                corrupted_pts = dropout_global_random(corrupted_pts)
+            elif item == 'dropout_patch_pointmae':
                 raise NotImplementedError(item)
         feature = self.pointnetv2_encoder(corrupted_pts)
         B = pts.shape[0]

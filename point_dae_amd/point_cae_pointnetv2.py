@@ -147,8 +147,15 @@ class Point_CAE_PointNetv2(nn.Module):
         nn_ops.begin_step(pts.device)
         corrupted_pts = corrupted_pts[:, :, :3].contiguous()
         pts = pts[:, :, :3].contiguous()
+        B0 = pts.shape[0]
         for item in self.corrupt_type:
-            if item in ('dropout_patch_pointmae', 'dropout_global'):
+            if item == 'dropout_global':
+                # dropout_global_random (datasets/corrupt_util.py:572-588): a random half of every cloud; the
+                # reference draws torch.rand on the CPU and sorts there -- the same call keeps the same subset
+                n = corrupted_pts.shape[1]
+                inx = torch.rand(B0, n, 1).argsort(1).to(corrupted_pts.device)
+                corrupted_pts = torch.take_along_dim(corrupted_pts, inx, dim=1)[:, :int(n * 0.5), :].contiguous()
+            elif item == 'dropout_patch_pointmae':
                 raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
         B = pts.shape[0]
         feature = self.pointnetv2_encoder(corrupted_pts)                       # (B, 1024)

@@ -101,8 +101,10 @@ def transformer_fixture(name, B, seed, overrides, cls='PointCAE_transformer'):
           'size %.0f KB' % (os.path.getsize(path) / 1024))
 
 
-def pointnetv2_fixture(name, B, seed):
-    """BASELINE config 1: pretrain_PointCAE_clean.yaml, Point_CAE_PointNetv2, B=2, N=1024."""
+def pointnetv2_fixture(name, B, seed, corrupt_type=None):
+    """BASELINE config 1: pretrain_PointCAE_clean.yaml, Point_CAE_PointNetv2, B=2, N=1024.  corrupt_type:
+    an in-forward corruption list (pretrain_PointCAE_dropout_global.yaml: ['dropout_global']); the host RNG
+    is re-seeded with seed + 7 right before each forward so that the drawn subset can be reproduced."""
     from easydict import EasyDict
     import yaml
     import pointnet2_utils as vendored
@@ -111,6 +113,8 @@ def pointnetv2_fixture(name, B, seed):
     from oracle import model as OM
     from point_dae_amd.synthetic import shapenet_like_clouds
     cfg = EasyDict(yaml.safe_load(open(os.path.join(R.REF, 'cfgs/pretrain_PointCAE_clean.yaml')))['model'])
+    if corrupt_type is not None:
+        cfg.corrupt_type = list(corrupt_type)
     R.seed_all(seed)
     ref = M.Point_CAE_PointNetv2(cfg)
     ref.device = torch.device('cpu')
@@ -121,9 +125,11 @@ def pointnetv2_fixture(name, B, seed):
     cap = {}
     ref.pointnetv2_encoder.register_forward_hook(lambda m, i, o: cap.update(feature=o))
     ref.folding1.register_forward_hook(lambda m, i, o: cap.update(coarse=o))
+    torch.manual_seed(seed + 7)
     l_coarse, l_fine = ref(corrupted, clean)
     (l_coarse + 0.5 * l_fine).backward()
     orc = fill_state(OM.Point_CAE_PointNetv2(cfg), seed).train()
+    torch.manual_seed(seed + 7)
     o1, o2 = orc(corrupted, clean)
     assert o1.item() == l_coarse.item() and o2.item() == l_fine.item(), (o1.item(), l_coarse.item())
     out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
@@ -194,6 +200,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'dgcnn':
         dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dropout_global':
+        pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'nomask':
         # the branch without patch masking (corrupt_type without 'Drop-Patch': NormalTransformer)
         transformer_fixture('transformer_nomask_b2.npz', 2, 14, {'transformer_config.drop_path_rate': 0.0,
@@ -201,6 +210,7 @@ if __name__ == '__main__':
                             'transformer_config.decoder_depth': 1})
         sys.exit(0)
     pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
+    pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])
     transformer_fixture('transformer_folding_b2.npz', 2, 13, {'transformer_config.drop_path_rate': 0.0,
                         'transformer_config.depth': 4, 'transformer_config.decoder_depth': 2},
                         cls='PointCAE_transformer_fc_global_folding_local')

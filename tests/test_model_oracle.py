@@ -122,6 +122,24 @@ def test_oracle_pointnetv2_reproduces_reference_fixture():
     check_grads(model, fx, 2e-4, 'pointnetv2')
 
 
+def test_oracle_pointnetv2_dropout_global_fixture():
+    """pretrain_PointCAE_dropout_global.yaml's in-forward corruption (dropout_global_random: a random half of every
+    cloud) -- fixture from the live reference, host RNG re-seeded with seed + 7 right before the forward."""
+    from oracle import model as OM
+    from point_dae_amd.config import cfg_from_yaml_file
+    fx = load_fixture('pointnetv2_dropout_global_b2.npz')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_clean.yaml')).model
+    cfg.corrupt_type = ['dropout_global']
+    model = fill_state(OM.Point_CAE_PointNetv2(cfg), int(fx['seed'])).train()
+    torch.manual_seed(int(fx['seed']) + 7)
+    lc, lf = model(torch.from_numpy(fx['corrupted']), torch.from_numpy(fx['clean']))
+    (lc + 0.5 * lf).backward()
+    assert abs(lc.item() - float(fx['loss_coarse'])) <= 1e-6 * abs(float(fx['loss_coarse']))
+    assert abs(lf.item() - float(fx['loss_fine'])) <= 1e-6 * abs(float(fx['loss_fine']))
+    check_grads(model, fx, 2e-4, 'pointnetv2 dropout_global')
+
+
 def test_oracle_dgcnn_reproduces_reference_fixture():
     """Point_CAE_DGCNN_FCOnly (the published non-Transformer model; fixture from the live reference)."""
     from oracle import model as OM
