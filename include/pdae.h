@@ -371,7 +371,7 @@ int pdae_pool_bn_backward(long long G, int ns, int C, const float* grad, const u
  *       ReLU (rows_gemm epi 4 of the next layer's data gradient):
  *       dp[b,c] = sum_g dpre,  dgd_part[blk][g] = sum over block blk's 64 (b,c) pairs --
  *       the caller adds the fold_input_grad_parts(clouds, coarse) partial sets in
- *       order (no atomics) and reduces dp over c for da.  C/4 must divide 256. */
+ *       order (no atomics) and reduces dp over c for da.  C <= 1024. */
 /*   fold_out_backward: the stage's last layer (C -> 3 outputs zero-padded to 4, weight W[4][C]) backwards in one
  *       pass over the kept middle activation h2: d2[r] = (h2[r] > 0) ? dy[r] . W : 0 and the per-block partials
  *       part[blk][4][C] of dW = dy^T h2 (fold_out_backward_parts(rows) sets; the caller adds them in order). */

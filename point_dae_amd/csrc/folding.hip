@@ -48,28 +48,25 @@ __global__ __launch_bounds__(256) void fold_input_grad_kernel(long long pairs, i
                                                               float4* __restrict__ dp,
                                                               float4* __restrict__ dgd_part) {
   extern __shared__ float4 red[];                 // [phases][C4]
-  const int PH = 256 / C4;                        // row phases
-  const int q = threadIdx.x % C4, ph = threadIdx.x / C4;
+  const int PH = 256 / C4;                        // row phases (C4 need not divide 256: the threads of an
+  const int q = threadIdx.x % C4, ph = threadIdx.x / C4;   // incomplete last phase only keep the barriers)
+  const bool active = ph < PH;
   const long long p0 = (long long)blockIdx.x * FG_PAIRS;
   const long long p1 = p0 + FG_PAIRS < pairs ? p0 + FG_PAIRS : pairs;
   float4 acc[CPT];
 #pragma unroll
   for (int k = 0; k < CPT; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long long pr = p0; pr < p1; ++pr) {
-    float4 v[CPT];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
       const int g = ph + k * PH;
-      v[k] = g < cells ? dpre[(pr * cells + g) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 s = v[0];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-      acc[k].x += v[k].x, acc[k].y += v[k].y, acc[k].z += v[k].z, acc[k].w += v[k].w;
-      if (k) s.x += v[k].x, s.y += v[k].y, s.z += v[k].z, s.w += v[k].w;
+      const float4 v = (active && g < cells) ? dpre[(pr * cells + g) * C4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[k].x += v.x, acc[k].y += v.y, acc[k].z += v.z, acc[k].w += v.w;
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
     // the pair's sum over its cells: the phases meet in LDS, added in phase order
-    red[ph * C4 + q] = s;
+    if (active) red[ph * C4 + q] = s;
     __syncthreads();
     if (ph == 0) {
       float4 t = red[q];
@@ -84,7 +81,7 @@ __global__ __launch_bounds__(256) void fold_input_grad_kernel(long long pairs, i
 #pragma unroll
   for (int k = 0; k < CPT; ++k) {
     const int g = ph + k * PH;
-    if (g < cells) dgd_part[((long long)blockIdx.x * cells + g) * C4 + q] = acc[k];
+    if (active && g < cells) dgd_part[((long long)blockIdx.x * cells + g) * C4 + q] = acc[k];
   }
 }
 
@@ -113,8 +110,8 @@ extern "C" int pdae_fold_input_grad_parts(int clouds, int coarse) {
 
 extern "C" int pdae_fold_input_grad(int clouds, int coarse, int cells, int C, const float* dpre, float* dp,
                                     float* dgd_part, pdae_stream_t stream) {
-  if (clouds < 0 || coarse <= 0 || cells <= 0 || C <= 0 || C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024)
-    return bad_arg("fold_input_grad: C/4 must divide 256");
+  if (clouds < 0 || coarse <= 0 || cells <= 0 || C <= 0 || C % 4 != 0 || C > 1024)
+    return bad_arg("fold_input_grad: C must be a positive multiple of 4, at most 1024");
   if (clouds == 0) return PDAE_OK;
   if (!dpre || !dp || !dgd_part) return bad_arg("fold_input_grad: null pointer");
   const int C4 = C / 4, PH = 256 / C4;
@@ -131,7 +128,8 @@ extern "C" int pdae_fold_input_grad(int clouds, int coarse, int cells, int C, co
   else if (cpt <= 4) hipLaunchKernelGGL(fold_input_grad_kernel<4>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
   else if (cpt <= 8) hipLaunchKernelGGL(fold_input_grad_kernel<8>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
   else if (cpt <= 16) hipLaunchKernelGGL(fold_input_grad_kernel<16>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
-  else return unsupported("fold_input_grad: more than 16 cells per row phase");
+  else if (cpt <= 20) hipLaunchKernelGGL(fold_input_grad_kernel<20>, dim3(grid), dim3(256), lds, s, pairs, cells, C4, a4, b4, c4);
+  else return unsupported("fold_input_grad: more than 20 cells per row phase");
   return check_launch("fold_input_grad");
 }
 
@@ -151,12 +149,13 @@ __global__ __launch_bounds__(256) void fold_out_backward_kernel(long long rows, 
   extern __shared__ float4 fo_red[];              // [phases][4][C4]
   const int PH = 256 / C4;
   const int q = threadIdx.x % C4, ph = threadIdx.x / C4;
+  const bool active = ph < PH;
   const float4 w0 = W[q], w1 = W[C4 + q], w2 = W[2 * C4 + q], w3 = W[3 * C4 + q];
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
   const long long r0 = (long long)blockIdx.x * FO_ROWS;
   const long long r1 = r0 + FO_ROWS < rows ? r0 + FO_ROWS : rows;
 #pragma unroll 4
-  for (long long r = r0 + ph; r < r1; r += PH) {
+  for (long long r = active ? r0 + ph : r1; r < r1; r += PH) {
     const float4 g = dy[r];                       // the row's four output gradients (same address across q: broadcast)
     const float4 h = h2[r * C4 + q];
     float4 o;
@@ -170,10 +169,12 @@ __global__ __launch_bounds__(256) void fold_out_backward_kernel(long long rows, 
     a2.x += g.z * h.x, a2.y += g.z * h.y, a2.z += g.z * h.z, a2.w += g.z * h.w;
     a3.x += g.w * h.x, a3.y += g.w * h.y, a3.z += g.w * h.z, a3.w += g.w * h.w;
   }
-  fo_red[(ph * 4 + 0) * C4 + q] = a0;
-  fo_red[(ph * 4 + 1) * C4 + q] = a1;
-  fo_red[(ph * 4 + 2) * C4 + q] = a2;
-  fo_red[(ph * 4 + 3) * C4 + q] = a3;
+  if (active) {
+    fo_red[(ph * 4 + 0) * C4 + q] = a0;
+    fo_red[(ph * 4 + 1) * C4 + q] = a1;
+    fo_red[(ph * 4 + 2) * C4 + q] = a2;
+    fo_red[(ph * 4 + 3) * C4 + q] = a3;
+  }
   __syncthreads();
   if (ph == 0) {
 #pragma unroll
@@ -194,8 +195,8 @@ extern "C" int pdae_fold_out_backward_parts(long long rows) { return (int)((rows
 
 extern "C" int pdae_fold_out_backward(long long rows, int C, const float* dy, const float* h2, const float* W,
                                       float* d2, float* part, pdae_stream_t stream) {
-  if (rows < 0 || C <= 0 || C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024)
-    return bad_arg("fold_out_backward: C/4 must divide 256");
+  if (rows < 0 || C <= 0 || C % 4 != 0 || C > 1024)
+    return bad_arg("fold_out_backward: C must be a positive multiple of 4, at most 1024");
   if (rows == 0) return PDAE_OK;
   if (!dy || !h2 || !W || !d2 || !part) return bad_arg("fold_out_backward: null pointer");
   const int C4 = C / 4;

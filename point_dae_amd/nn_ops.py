@@ -441,16 +441,21 @@ class _FoldMLP(torch.autograd.Function):
     the first layer's masked gradient yields dp and the partial sums of dgd."""
 
     @staticmethod
-    def forward(ctx, a, p, gd, w2, b2, w3, b3, clouds, coarse, cells):
-        a, p, gd = a.contiguous(), p.contiguous(), gd.contiguous()
-        C = a.shape[1]
+    def forward(ctx, a, p, gd, row, w2, b2, w3, b3, clouds, coarse, cells):
+        p = p.contiguous()
+        C = p.shape[1]
         rows = clouds * coarse * cells
-        h1 = _empty((rows, C), a)
-        _lib.call('pdae_fold_input', a, clouds, coarse, cells, C, _lib.ptr(a), _lib.ptr(p), _lib.ptr(gd), _lib.ptr(h1))
+        if row is None:
+            a, gd = a.contiguous(), gd.contiguous()
+            h1 = _empty((rows, C), p)
+            _lib.call('pdae_fold_input', p, clouds, coarse, cells, C, _lib.ptr(a), _lib.ptr(p), _lib.ptr(gd), _lib.ptr(h1))
+        else:      # a per-point term instead of the per-cloud / per-cell ones (the published variant's second stage)
+            h1 = torch.relu_(row.reshape(clouds * coarse, cells, C) + p.unsqueeze(1)).reshape(rows, C)
         h2 = rows_gemm(h1, w2, False, b2, 1)
         y = rows_gemm(h2, w3, False, b3, 0)
         ctx.save_for_backward(h1, h2, w2, w3)
         ctx.dims = (clouds, coarse, cells, C)
+        ctx.per_row = row is not None
         return y
 
     @staticmethod
@@ -458,8 +463,8 @@ class _FoldMLP(torch.autograd.Function):
         h1, h2, w2, w3 = ctx.saved_tensors
         clouds, coarse, cells, C = ctx.dims
         dy = dy.contiguous()
-        if w3.shape[0] == 4 and 256 % (C // 4) == 0:
-            # the 512 -> 3(+1) layer backwards in one pass over h2 (csrc/folding.hip fold_out_backward)
+        if w3.shape[0] == 4:
+            # the C -> 3(+1) layer backwards in one pass over h2 (csrc/folding.hip fold_out_backward)
             parts = _lib.lib().pdae_fold_out_backward_parts(dy.shape[0])
             d2, part = torch.empty_like(h2), _empty((parts, 4, C), dy)
             _lib.call('pdae_fold_out_backward', dy, dy.shape[0], C, _lib.ptr(dy), _lib.ptr(h2), _lib.ptr(w3.contiguous()),
@@ -468,26 +473,30 @@ class _FoldMLP(torch.autograd.Function):
         else:
             d2 = rows_gemm(dy, w3, True, None, 4, h2)               # gradient of h2's pre-activation
             (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
-        # (the 1.1 TFLOP product of the stage: the [N,K] form of the kernel is 8 % faster than the [K,N] form at
-        #  this size, and transposing the 1 MB weight costs nothing)
+        # (the large product of the stage: the [N,K] form of the kernel is 8 % faster than the [K,N] form at
+        #  this size, and transposing the weight costs nothing)
         d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1)  # gradient of h1's pre-activation
         (dw2,), (db2,) = rows_wgrad([d2], [h1], [True])
         del d2
+        if ctx.per_row:
+            return None, d1.view(clouds * coarse, cells, C).sum(1), None, d1, dw2, db2, dw3, db3, None, None, None
         parts = _lib.lib().pdae_fold_input_grad_parts(clouds, coarse)
         dp = _empty((clouds * coarse, C), dy)
         part = _empty((parts, cells, C), dy)
         _lib.call('pdae_fold_input_grad', dy, clouds, coarse, cells, C, _lib.ptr(d1), _lib.ptr(dp), _lib.ptr(part))
-        return dp.view(clouds, coarse, C).sum(1), dp, part.sum(0), dw2, db2, dw3, db3, None, None, None
+        return (dp.view(clouds, coarse, C).sum(1), dp, part.sum(0), None, dw2, db2, dw3, db3, None, None, None)
 
 
-def fold_mlp(a, p, gd, conv2, conv3, clouds, coarse, cells):
-    """-> (clouds*coarse*cells, 3) offsets; conv2 / conv3 = folding2[2] / folding2[4] (Conv1d, kernel 1)."""
+def fold_mlp(a, p, gd, conv2, conv3, clouds, coarse, cells, row_term=None):
+    """-> (clouds*coarse*cells, 3) offsets; conv2 / conv3 = the stage's second and third Conv1d (kernel 1).
+    First-layer terms: a (clouds, C) per cloud, p (clouds*coarse, C) per coarse point / patch, gd (cells, C) per
+    grid cell -- or, with row_term (rows, C), p plus a per-point term (a and gd unused)."""
     w3, b3 = conv3.weight.squeeze(-1), conv3.bias
     n = w3.shape[0]
     pn = (-n) % 4
     if pn:                                              # 3 output coordinates: a zero fourth row
         w3, b3 = F.pad(w3, (0, 0, 0, pn)), F.pad(b3, (0, pn))
-    y = _FoldMLP.apply(a, p, gd, conv2.weight.squeeze(-1), conv2.bias, w3, b3, clouds, coarse, cells)
+    y = _FoldMLP.apply(a, p, gd, row_term, conv2.weight.squeeze(-1), conv2.bias, w3, b3, clouds, coarse, cells)
     return y[:, :n] if pn else y
 
 

@@ -383,11 +383,12 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
         patch, extra (P, 36, e) or (36, e) per point.  -> (P*36, 3)."""
         C = tok.shape[1]
         w = stage[0].weight.squeeze(-1)
-        a = nn_ops.linear_any(tok, w[:, :C].contiguous(), stage[0].bias).unsqueeze(1)   # (P, 1, C)
+        a = nn_ops.linear_any(tok, w[:, :C].contiguous(), stage[0].bias)                  # (P, C) once per patch
         e = nn_ops.linear_any(extra.reshape(-1, extra.shape[-1]), w[:, C:C + extra_w_cols])
-        h = F.relu(a + e.reshape(extra.shape[:-1] + (C,)))                         # (P, 36, C)
-        h = nn_ops.linear_any(h.reshape(-1, C), stage[2].weight.squeeze(-1), stage[2].bias, relu=True)
-        return nn_ops.linear_any(h, stage[4].weight.squeeze(-1), stage[4].bias)
+        P, cells = tok.shape[0], extra.shape[-2]
+        if extra.dim() == 2:            # one term per grid cell: the fused first layer (csrc/folding.hip)
+            return nn_ops.fold_mlp(a.new_zeros(1, C), a, e, stage[2], stage[4], 1, P, cells)
+        return nn_ops.fold_mlp(None, a, None, stage[2], stage[4], 1, P, cells, row_term=e)   # one term per point
 
     def forward(self, corrupted_pts, pts, vis=False, return_feat=False, mask=None, steps=None, capture=None,
                 rows=None, **kwargs):

@@ -220,7 +220,8 @@ def test_rows_gemm_relu_mask_epilogue(M, N, K):
     assert (y2[h == 0] == 0).all()
 
 
-@pytest.mark.parametrize('clouds,coarse,cells,C', [(3, 40, 16, 512), (2, 7, 16, 128), (1, 5, 9, 64), (5, 129, 4, 256)])
+@pytest.mark.parametrize('clouds,coarse,cells,C', [(3, 40, 16, 512), (2, 7, 16, 128), (1, 5, 9, 64), (5, 129, 4, 256),
+                                                   (1, 300, 36, 384), (2, 33, 36, 96)])
 def test_fold_input_and_grad(clouds, coarse, cells, C):
     """fold_input / fold_input_grad (csrc/folding.hip) against the broadcast formulation in torch:
     forward bit for bit (same association (a + p) + gd), the sums to fp32 accuracy, partial sets
@@ -251,7 +252,7 @@ def test_fold_input_and_grad(clouds, coarse, cells, C):
     _close(part.sum(0), d4.sum((0, 1)), 1e-5)
 
 
-@pytest.mark.parametrize('rows,C', [(5000, 512), (1024, 128), (77, 64), (3000, 1024)])
+@pytest.mark.parametrize('rows,C', [(5000, 512), (1024, 128), (77, 64), (3000, 1024), (4000, 384), (333, 96)])
 def test_fold_out_backward(rows, C):
     """the 512 -> 3(+1) layer backwards in one pass: masked data gradient + ordered weight-gradient partials"""
     L = _lib()

@@ -149,8 +149,8 @@ def test_entries_refuse_bad_arguments():
     with pytest.raises(RuntimeError, match='C/4 must divide 256'):
         _lib.call('pdae_pool_bn_backward', y, 2, 32, 24, out.data_ptr(), arg.data_ptr(), out.data_ptr(), y.data_ptr(),
                   sc.data_ptr(), sc.data_ptr(), sc.data_ptr(), st.data_ptr(), st.data_ptr(), y.data_ptr())
-    with pytest.raises(RuntimeError, match='C/4 must divide 256'):
-        _lib.call('pdae_fold_input_grad', y, 1, 2, 4, 24, y.data_ptr(), y.data_ptr(), y.data_ptr())
+    with pytest.raises(RuntimeError, match='at most 1024'):
+        _lib.call('pdae_fold_input_grad', y, 1, 2, 4, 2048, y.data_ptr(), y.data_ptr(), y.data_ptr())
     with pytest.raises(RuntimeError, match='positive multiple of 4'):
         _lib.call('pdae_fold_input', y, 1, 2, 4, 6, y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr())
     with pytest.raises(RuntimeError, match='needs Z'):                # masking epilogue without the kept output
