@@ -45,7 +45,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma
 HBM_PEAK_GBS = 8000.0
 VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
                                   # kernels are sub / mul / add / min chains
-ROUND = 2                         # profiles/*_rNN.json this bench refers to
+ROUND = 3                         # profiles/*_rNN.json this bench refers to
 
 
 def parse():
@@ -68,6 +68,8 @@ def parse():
                    help='two-phase graphed step with the all-reduce under the embedder backward (auto: when ranks > 1)')
     p.add_argument('--no-also', action='store_true', help='skip the geometry-kernel rooflines and the cfg2 leg')
     p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 and published-variant legs')
+    p.add_argument('--no-tvis-table', action='store_true',
+                   help='skip the per-visible-token-count replay timings and the straggler model built on them')
     return p.parse_args()
 
 
@@ -126,6 +128,96 @@ def geometry_rooflines(args, clouds):
                                           _lib.ptr(i2), _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(ga), _lib.ptr(gb)))
     row('chamfer_bwd_packed (%d patches of %dx%d)' % (P, k, k), us, P * (12 * 2 * k + 4 * 2 * k + 4 * 2 * k + 12 * 2 * k), P * 2 * k)
     return out
+
+
+def tvis_table(step, batch, replays=6):
+    """ms per replay of every captured step graph, keyed by its visible-token count T_vis (HIP events on the launch
+    stream, `replays` replays back to back after one warm replay).  The mask ratio is drawn per batch AND per rank
+    (seed + rank, main.py:81 of the reference), so in a data-parallel job every step waits for the rank that drew the
+    most visible tokens: this table is what bounds that straggler effect."""
+    out = {}
+    step.pts.copy_(batch)
+    for tvis in sorted(step.graphs):
+        g = step.graphs[tvis]
+        gs = g if isinstance(g, tuple) else (g,)
+        for x in gs:
+            x.replay()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(replays):
+            for x in gs:
+                x.replay()
+        e.record()
+        torch.cuda.synchronize()
+        out[tvis] = s.elapsed_time(e) / replays
+    return out
+
+
+def tvis_distribution(G):
+    """P(T_vis) under MaskTransformer._mask_center_rand (:395-422): ratio ~ U(0.5, 0.8), num_mask = int(ratio G)."""
+    lo, hi = 0.5, 0.8
+    p = {}
+    for m in range(int(lo * G), int(hi * G) + 1):
+        a, b = max(lo, m / G), min(hi, (m + 1) / G)
+        if b > a:
+            p[G - m] = (b - a) / (hi - lo)
+    return p
+
+
+def ddp_model(table, G, ms_per_step, ranks=(2, 4, 8), allreduce_mb=116.0):
+    """Straggler bound on data-parallel scaling from the T_vis table: per step every rank replays the graph of ITS
+    draw and the collective waits for the slowest.  E[max of n draws] from the exact distribution of T_vis;
+    `other_ms` = the measured step minus the expected replay time (AdamW, host gaps) is added unchanged.
+    The all-reduce itself is modelled separately: the early slice overlaps the embedder backward, ~2 MB
+    are exposed.  A MODEL, not a measurement: no multi-GPU node was available to this build."""
+    p = tvis_distribution(G)
+    ts = sorted(t for t in p if t in table)
+    if not ts:
+        return None
+    z = sum(p[t] for t in ts)
+    mean = sum(p[t] * table[t] for t in ts) / z
+    other = max(ms_per_step - mean, 0.0)
+    order = sorted(ts, key=lambda t: table[t])             # by replay time
+    out = {'p_tvis': {str(t): round(p[t] / z, 5) for t in ts}, 'expected_replay_ms': mean, 'other_ms': other,
+           'slowest_replay_ms': max(table[t] for t in ts), 'fastest_replay_ms': min(table[t] for t in ts),
+           'note': 'straggler bound only (every rank draws its own mask ratio); all-reduce of %.0f MB fp32 not included: '
+                   'its early slice runs under the embedder backward, see DESIGN.md 6' % allreduce_mb,
+           'predicted': {}}
+    for n in ranks:
+        cdf, emax = 0.0, 0.0
+        for t in order:
+            c2 = cdf + p[t] / z
+            emax += (c2 ** n - cdf ** n) * table[t]
+            cdf = c2
+        out['predicted'][str(n)] = {'expected_max_replay_ms': emax, 'step_ms': emax + other,
+                                    'efficiency': (mean + other) / (emax + other),
+                                    'speedup': n * (mean + other) / (emax + other)}
+    return out
+
+
+def dominant_roofline(probe, steps):
+    """`roofline_dominant`: the row GEMM family (rows_gemm_kernel: every Linear / 1x1 conv forward and data gradient)
+    and the grouped weight gradients (wgrad_kernel + its reductions) -- the kernels that own ~60 % of the step --
+    as ONE time-weighted figure: all their algorithmic FLOPs over all their launch time, HIP events around every
+    launch of the eager probe steps."""
+    fam = probe.family_summary()
+    if not fam:
+        return None
+    rows = {}
+    tot_f = tot_ms = 0.0
+    for name, r in fam.items():
+        tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+        rows[name] = {'launches_per_step': r['launches'] / max(steps, 1), 'ms_per_step': r['ms'] / max(steps, 1),
+                      'gflop_per_step': r['flops'] / max(steps, 1) / 1e9, 'achieved': tf, 'frac': tf / MFMA_F32_PEAK_TFLOPS}
+        tot_f += r['flops']
+        tot_ms += r['ms']
+    ach = tot_f / (tot_ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / MFMA_F32_PEAK_TFLOPS, 'ms_per_step': tot_ms / max(steps, 1),
+            'gflop_per_step': tot_f / max(steps, 1) / 1e9, 'families': rows,
+            'timing': 'HIP events around every launch of the two families over %d eager probe steps '
+                      '(launch-to-launch, so each figure carries the launch ramp a hipGraph replay also pays; '
+                      'profiles/kernel_summary_r%02d.txt has the in-replay durations)' % (steps, ROUND)}
 
 
 def cfg2_leg(args, device, rank):
@@ -409,6 +501,9 @@ def main():
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
                       'timed hipGraph region' % args.probe_steps)
     nn_ops.set_probe(None)
+    table = None
+    if not args.eager and rank == 0 and args.workload == 'cfg3' and not args.no_tvis_table and isinstance(step, GraphedTrainStep):
+        table = tvis_table(step, batches[0])
     in_sync = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -466,6 +561,13 @@ def main():
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
+        dom = dominant_roofline(probe, args.probe_steps if not args.eager else args.steps)
+        if dom:
+            line['roofline_dominant'] = dom
+        if table:
+            line['tvis_table'] = {'unit': 'ms per replay (forward + loss + backward graph(s), no AdamW)',
+                                  'ms': {str(t): round(v, 4) for t, v in table.items()}}
+            line['ddp_model'] = ddp_model(table, args.num_group, elapsed / args.steps * 1e3)
         if world > 1:
             line['replicas_in_sync'] = in_sync          # parameters bit-identical on all ranks after the timed steps
         if args.workload == 'cfg3' and not args.no_also:

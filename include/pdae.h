@@ -180,6 +180,22 @@ int pdae_patch_affine(int b, int g, int k, int nsteps, const float* nbr,
                       float* t_nbr, float* t_center, pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Point-M2AE token pyramid: index bookkeeping of the hierarchical grouping.
+ * Replaces the tensor chains of Group.forward, models/Point_M2AE_modules.py:239-247 (the flat neighbour index
+ *   `idx + arange(B).view(-1,1,1) * num_points` that Group returns next to neighbourhood and centre) and of
+ *   H_Encoder.forward, models/Point_M2AE.py:112-117 (multi-scale masking pushed one level down).  FPS and kNN of a
+ *   level are pdae_furthest_point_sampling / pdae_knn.
+ * flatten_group_index: idx (b, g*k) i64 local indices into clouds of n points -> flat (b*g*k) i64 = idx + cloud*n.
+ * mask_propagate: parent_masked (parents) u8, flat_idx (parents*k) i64 into `children` finer tokens ->
+ *   child_masked (children) u8, fully written: 1, except 0 at every child of a visible parent -- and at flat child 0
+ *   whenever some parent is masked (the reference multiplies the indices of masked parents by 0 and scatters them
+ *   too; kept bug-for-bug).
+ */
+int pdae_flatten_group_index(int b, int n, int gk, const int64_t* idx, int64_t* flat, pdae_stream_t stream);
+int pdae_mask_propagate(int parents, int k, int children, const uint8_t* parent_masked, const int64_t* flat_idx,
+                        uint8_t* child_masked, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Loader-side corruption on the device.  Replaces corrupt_dropout_local
  *   datasets/corrupt_util.py:590-612, which the reference runs per item in its
  *   DataLoader workers (ShapeNet55Dataset.__getitem__ :90-119).

@@ -288,3 +288,44 @@ def earth_mover_distance(xyz1, xyz2):
     match = emd_approxmatch(xyz1, xyz2)
     cost = emd_matchcost(xyz1, xyz2, match)
     return (cost / np.float32(np.asarray(xyz1).shape[1])).mean(dtype=np.float32)
+
+
+# ---- Point-M2AE hierarchical grouping -------------------------------------------------
+def m2ae_group(xyz, num_group, group_size):
+    """Group.forward, models/Point_M2AE_modules.py:227-248: centres by FPS (misc.fps), k nearest by KNN, the flat
+    index `idx + b * num_points`, the gathered neighbourhood minus its centre.
+    -> neighborhood (B,G,M,3) f32, center (B,G,3) f32, idx (B*G*M,) i64."""
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    _, center = furthest_point_sample(xyz, num_group, return_centres=True)
+    _, idx = knn(xyz, center, group_size)                                   # (B,G,M) i64
+    flat = (idx + np.arange(B, dtype=np.int64).reshape(-1, 1, 1) * N).reshape(-1)      # :243-245
+    neighborhood = xyz.reshape(B * N, 3)[flat].reshape(B, num_group, group_size, 3)   # :246-247
+    neighborhood = neighborhood - center[:, :, None, :]                                # :249
+    return np.ascontiguousarray(neighborhood), center, flat
+
+
+def m2ae_hierarchy(pts, num_groups, group_sizes):
+    """Point_M2AE.forward, models/Point_M2AE.py:245-263: level 0 groups the points, level i the centres of i - 1."""
+    neighborhoods, centers, idxs = [], [], []
+    src = _f32(pts)[:, :, :3]
+    for g, k in zip(num_groups, group_sizes):
+        nb, c, idx = m2ae_group(src, g, k)
+        neighborhoods.append(nb), centers.append(c), idxs.append(idx)
+        src = c
+    return neighborhoods, centers, idxs
+
+
+def m2ae_multi_scale_mask(top_masked, idxs, centers):
+    """H_Encoder.forward, models/Point_M2AE.py:107-121: `idx_masked = ~mask[:, None] * idx` (masked parents send
+    index 0), `ones(b * G_child).scatter(0, idx_masked, 0)`; -> masks finest level first (after :121's reverse)."""
+    masks = [np.asarray(top_masked, dtype=bool)]
+    for i in range(len(idxs) - 1, 0, -1):
+        b, g, _ = centers[i].shape
+        idx = idxs[i].reshape(b * g, -1)
+        idx_masked = (~masks[-1].reshape(-1))[:, None] * idx
+        child = np.ones(b * centers[i - 1].shape[1], dtype=bool)
+        child[idx_masked.reshape(-1)] = False
+        masks.append(child.reshape(b, centers[i - 1].shape[1]))
+    masks.reverse()
+    return masks

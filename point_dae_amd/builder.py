@@ -80,13 +80,10 @@ class CosineLRScheduler:
         if t < self.warmup_t:
             return [self.warmup_lr_init + t * s for s in self.warmup_steps]
         i = t // self.t_initial
-        t_curr = t - self.t_initial * i
-        gamma = self.decay_rate ** i
-        lr_min = self.lr_min * gamma
-        if i < 1:
-            return [lr_min + 0.5 * (v * gamma - lr_min) * (1 + math.cos(math.pi * t_curr / self.t_initial))
+        if i < 1:                          # cycle_limit = 1: one cosine cycle (gamma = decay_rate ** 0 = 1)
+            return [self.lr_min + 0.5 * (v - self.lr_min) * (1 + math.cos(math.pi * t / self.t_initial))
                     for v in self.base_values]
-        return [lr_min for _ in self.base_values]
+        return [self.lr_min * self.decay_rate for _ in self.base_values]      # lr_min * decay_rate ** cycle_limit
 
     def step(self, epoch):
         self._set(self._get_lr(epoch))

@@ -22,6 +22,8 @@ xGMI (point-to-point links, per-link-bound rings): few, large collectives.
 
 Works on CPU tensors with gloo, which is how tests cover world_size 2.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -78,6 +80,11 @@ class FlatDataParallel(nn.Module):
             off += n
         self.params = params
         self.grad_views = [p.grad for p in params]
+        # gradient sink (nn_ops._sink_views): armed by a graphed step around its own forward + backward only
+        self.sink_armed, self.sink_written = False, set()
+        me = weakref.ref(self)
+        for i, p in enumerate(params):
+            p._pdae_flat = (me, i)
         if self.world_size > 1 and broadcast:
             dist.broadcast(self.flat_param, src=0, group=process_group)
             for b in module.buffers():

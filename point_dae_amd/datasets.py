@@ -187,7 +187,10 @@ class ShapeNet:
         self.npoints = config.get('npoints', 1024)
         self.dense = config.get('N_POINTS', 8192)
         self.bs = config.get('bs', 128)
-        self.steps = config.get('steps_per_epoch', 50)
+        # batches per epoch: given, else the reference's len(DataLoader) = ceil(len(set) / (bs * world)) once a listed
+        # set is loaded (DistributedSampler shards it, builder.py:19), else 50 synthetic batches
+        self.steps = config.get('steps_per_epoch', None)
+        self.rank, self.world = int(config.get('rank', 0)), max(int(config.get('world', 1)), 1)
         self.seed = config.get('seed', 0)
         self.device = config.get('device', 'cuda')
         self.pool = config.get('pool', 4)
@@ -218,8 +221,13 @@ class ShapeNet:
         self._clouds = torch.from_numpy(np.ascontiguousarray(clouds)).to(self.device)
         self.gen = torch.Generator(device=self._clouds.device)
         self.gen.manual_seed(self.seed)
+        self.listed = bool(listed)
+        if self.steps is None:
+            self.steps = -(-clouds.shape[0] // (self.bs * self.world)) if listed else 50
 
     def __len__(self):
+        if self.steps is None:
+            self._materialise()
         return self.steps
 
     def batch(self, index):
@@ -290,9 +298,18 @@ class ShapeNet:
         if self._clouds is None:
             self._materialise()
         n = self._clouds.shape[0]
-        order = self.rng.permutation(n)
+        if self.listed and self.world > 1:
+            # DistributedSampler semantics: ONE permutation per epoch shared by the ranks (seeded without the
+            # rank), padded by wrapping to a multiple of world, rank r takes every world-th index
+            self._epoch = getattr(self, '_epoch', -1) + 1
+            shared = np.random.default_rng([self.seed - self.rank, self._epoch]).permutation(n)
+            total = -(-n // self.world) * self.world
+            order = np.resize(shared, total)[self.rank::self.world]
+            n = order.shape[0]
+        else:
+            order = self.rng.permutation(n)
         for i in range(self.steps):
-            sel = order[(np.arange(self.bs) + i * self.bs) % n]
+            sel = order[(np.arange(self.bs) + i * self.bs) % order.shape[0]]
             corrupted, clean = self.batch(torch.from_numpy(sel).to(self._clouds.device))
             yield self.ids[int(sel[0])][0], i, corrupted, clean
 
@@ -311,6 +328,11 @@ class ModelNet:
         self.device = config.get('device', 'cuda')
         seed = config.get('seed', 0) + (1000 if self.subset == 'train' else 2000)
         x, y = labelled_clouds(self.count, self.npoints, seed=seed, classes=min(3, config.get('NUM_CATEGORY', 3)))
+        rank, world = int(config.get('rank', 0)), max(int(config.get('world', 1)), 1)
+        if world > 1:      # DistributedSampler(shuffle=False): wrap-padded to a multiple of world, every world-th item
+            sel = np.resize(np.arange(self.count), -(-self.count // world) * world)[rank::world]
+            x, y = x[sel], y[sel]
+            self.count = len(sel)
         self.x, self.y = torch.from_numpy(x).to(self.device), torch.from_numpy(y).to(self.device)
 
     def __len__(self):

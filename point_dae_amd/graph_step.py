@@ -81,11 +81,18 @@ class GraphedTrainStep:
     MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
     RING = int(os.environ.get("PDAE_RING", "4"))   # staging slots = how many steps the host may run ahead
 
-    def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2, split=None):
+    def __init__(self, model, optimizer, config, batch_size, npoints, warmup_eager=2, split=None,
+                 step_per_update=None):
         """split: two-phase step -- graph 1 = forward + loss + the Transformer's backward, graph 2 = the
         patch embedder's backward (2.4 of the 14 ms); the all-reduce of the Transformer's gradients
         (model.early_range, 98 % of the bytes) is started between the two replays and runs on RCCL's
-        stream under graph 2.  Default: on when world_size > 1."""
+        stream under graph 2.  Default: on when world_size > 1.
+
+        Every branch of the reference's step body (runner_pretrain.py:161-197) replays: the loss mix reads its
+        normal-loss weight from a DEVICE scalar (set_gradual_weight, once per epoch: `xyznormal_gradual` /
+        `xyznormal_warm` change it between replays), the un-masked model (NormalTransformer, :473-541) has one
+        static shape and draws no mask, and with step_per_update > 1 the micro-steps' gradients are summed in a
+        second flat buffer; the collective and AdamW run on the step that closes the group."""
         assert isinstance(model, FlatDataParallel)
         self.model, self.optimizer, self.config = model, optimizer, config
         self.net = model.module
@@ -97,10 +104,13 @@ class GraphedTrainStep:
         self.late_idx = [i for i, (off, _) in enumerate(model.offsets) if not e0 <= off < e1]
         dev = model.flat_param.device
         self.B, self.G = batch_size, self.net.num_group
+        self.masked = bool(getattr(self.net, 'masked', True))
         self.pts = torch.zeros(batch_size, npoints, 3, device=dev)
         self.steps = torch.zeros(self.MAX_STEPS, batch_size, 10, device=dev)
         self.vis = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
         self.msk = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
+        if not self.masked:
+            self.vis.copy_(torch.arange(batch_size * self.G))
         # The host runs several steps ahead of the GPU, so the pinned staging buffers of
         # the draws form a ring; a slot is reused only after the event recorded behind its
         # H2D copies has completed.
@@ -114,18 +124,38 @@ class GraphedTrainStep:
         self.pool = None
         self.eager_left = warmup_eager
         self.normal_weight = float(config.normal_weight)
-        if config.loss_type not in ('xyz', 'xyznormal'):
-            raise NotImplementedError('graphed step: loss_type %s' % config.loss_type)
-        if not getattr(self.net, 'masked', True):
-            raise NotImplementedError('graphed step: the un-masked variant has one static shape; use GraphedStaticStep')
+        self.loss_type = config.loss_type
+        if self.loss_type not in ('xyz', 'normal', 'xyznormal', 'xyznormal_gradual', 'xyznormal_warm'):
+            raise NotImplementedError('graphed step: loss_type %s' % self.loss_type)
+        # weight of the normal loss as the captured graphs read it: normal_weight (x the epoch's gradual weight)
+        self.w_dev = torch.full((), self.normal_weight, device=dev)
+        if self.loss_type in ('xyznormal_gradual', 'xyznormal_warm'):
+            self.w_dev.zero_()                                     # epoch 0 of both ramps
+        self.spu = int(config.get('step_per_update', 1) if step_per_update is None else step_per_update)
+        self.micro = 0
+        self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
+
+    def set_gradual_weight(self, gw):
+        """runner_pretrain.py:113-122: the epoch's ramp factor of `xyznormal_gradual` / `xyznormal_warm`."""
+        if self.loss_type in ('xyznormal_gradual', 'xyznormal_warm'):
+            self.w_dev.fill_(self.normal_weight * float(gw))
+
+    def _mix(self, lx, ln):
+        lt = self.loss_type
+        if lt == 'xyz':
+            return lx
+        if lt == 'normal':
+            return self.w_dev * ln.sum()
+        return lx + self.w_dev * ln.sum()
 
     def _draw(self):
         """Host RNG, in the order the eager forward consumes it: corruption
-        (corrupt_util_tensor.py:706-727) first, then the mask (:395-422)."""
+        (corrupt_util_tensor.py:706-727) first, then the mask (:395-422; none for the un-masked model)."""
         enc = self.net.MAE_encoder
         steps = draw_corruption(self.net.corrupt_type, self.B)
-        mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
-        enc.num_mask = int(enc.mask_ratio * self.G)
+        if self.masked:
+            mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
+            enc.num_mask = int(enc.mask_ratio * self.G)
         n = steps.shape[0]
         slot = self.ring[self.slot]
         self.slot = (self.slot + 1) % self.RING
@@ -135,13 +165,15 @@ class GraphedTrainStep:
         slot['steps'][:, :, 1:4] = 1.0                         # identity 'multiply' steps
         if n:
             slot['steps'][:n].copy_(steps)
-        vis_rows, mask_rows = mask_row_ids(mask)
-        tvis = vis_rows.numel() // self.B
-        slot['vis'][:vis_rows.numel()].copy_(vis_rows)
-        slot['msk'][:mask_rows.numel()].copy_(mask_rows)
         self.steps.copy_(slot['steps'], non_blocking=True)
-        self.vis.copy_(slot['vis'], non_blocking=True)
-        self.msk.copy_(slot['msk'], non_blocking=True)
+        tvis = self.G
+        if self.masked:
+            vis_rows, mask_rows = mask_row_ids(mask)
+            tvis = vis_rows.numel() // self.B
+            slot['vis'][:vis_rows.numel()].copy_(vis_rows)
+            slot['msk'][:mask_rows.numel()].copy_(mask_rows)
+            self.vis.copy_(slot['vis'], non_blocking=True)
+            self.msk.copy_(slot['msk'], non_blocking=True)
         slot['done'] = torch.cuda.Event()
         slot['done'].record()
         return tvis
@@ -149,14 +181,14 @@ class GraphedTrainStep:
     def _gather(self, idx, written=()):
         """Gradients are produced as fresh tensors (autograd ASSIGNS them: no 203 accumulate-add
         launches, no memset of the flat buffer) and gathered into the flat gradient buffer with one
-        multi-tensor copy.  written: data pointers of parameters whose gradient a Function already put
-        into its flat view (nn_ops.GRAD_SINK): nothing to copy, nothing to zero."""
+        multi-tensor copy.  written: indices of parameters whose gradient a Function already put
+        into its flat view (the armed sink of nn_ops._sink_views): nothing to copy, nothing to zero."""
         m = self.model
         if written:
-            idx = [i for i in idx if m.params[i].data_ptr() not in written or m.params[i].grad is not None]
-            for i, p in enumerate(m.params):
-                if p.grad is None and p.data_ptr() in written:
-                    p.grad = m.grad_views[i]
+            idx = [i for i in idx if i not in written or m.params[i].grad is not None]
+            for i in written:
+                if m.params[i].grad is None:
+                    m.params[i].grad = m.grad_views[i]
         have = [(m.grad_views[i], m.params[i].grad) for i in idx if m.params[i].grad is not None]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
@@ -174,14 +206,12 @@ class GraphedTrainStep:
             p.grad = None
         enc = self.net.MAE_encoder
         enc.grad_cut = cut
-        # the blocks' weight gradients go straight into the flat buffer (nn_ops.GRAD_SINK): every .grad is None
-        # here and nothing else touches the flat gradient views until the gather below
-        from . import nn_ops
-        sink = {'views': {p.data_ptr(): v for p, v in zip(m.params, m.grad_views)}, 'written': set()}
-        nn_ops.GRAD_SINK = sink if SINK else None
+        # the blocks' weight gradients go straight into THIS model's flat buffer (nn_ops._sink_views): every .grad
+        # is None here and nothing else touches the flat gradient views until the gather below
+        m.sink_armed, m.sink_written = SINK, set()
         try:
             lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
-            loss = lx if self.config.loss_type == 'xyz' else lx + self.normal_weight * ln.sum()
+            loss = self._mix(lx, ln)
             # the 34 LayerNorm backward launches park their parameter-gradient partials; ONE launch adds them
             # all after the backward (include/pdae.h: deferred reductions) -- nothing reads those gradients
             # before the gather below
@@ -194,8 +224,8 @@ class GraphedTrainStep:
                     _lib.deferred_flush(lx)
         finally:
             enc.grad_cut = None
-            nn_ops.GRAD_SINK = None
-        self._gather(self.early_idx if cut is not None else range(len(m.params)), sink['written'])
+            m.sink_armed = False
+        self._gather(self.early_idx if cut is not None else range(len(m.params)), m.sink_written)
         return lx.detach(), ln.detach()
 
     def _phase2(self, cut):
@@ -249,26 +279,36 @@ class GraphedTrainStep:
         self.graphs[tvis], self.outputs[tvis] = g, out
         return g
 
-    def _step_split(self, run1, run2):
-        """phase 1, start the big all-reduce, phase 2 under it, the two small slices, wait."""
+    def _step_split(self, run1, run2, closing=True):
+        """phase 1, start the big all-reduce, phase 2 under it, the two small slices, wait.  closing False: a
+        gradient-accumulation micro-step (nothing is reduced)."""
         m = self.model
         out = run1()
         works = []
-        if m.world_size > 1:
-            works.append(_start_average(m, *m.early_range))
+        reduce = closing and m.world_size > 1
+        if self.accum is not None and closing:
+            a, b = m.early_range
+            m.flat_grad[a:b].add_(self.accum[a:b])
+        if reduce:
+            works.append((m.early_range, _start_average(m, *m.early_range)))
         run2()
-        if m.world_size > 1:
-            works += [_start_average(m, a, b) for a, b in m.late_ranges]
-            for w, _ in works:
+        if self.accum is not None and closing:
+            for a, b in m.late_ranges:
+                m.flat_grad[a:b].add_(self.accum[a:b])
+        if reduce:
+            works += [((a, b), _start_average(m, a, b)) for a, b in m.late_ranges]
+            for (a, b), (w, div) in works:
                 w.wait()
-            if any(div for _, div in works):
-                m.flat_grad.div_(m.world_size)
+                if div:                    # this slice came back as a SUM (no ReduceOp.AVG): divide IT, not the buffer
+                    m.flat_grad[a:b].div_(m.world_size)
         return out
 
     def __call__(self, points, gt=None):
         self.pts.copy_(points[:, :, :3], non_blocking=True)
         tvis = self._draw()
         self.last_tvis = tvis
+        self.micro += 1
+        closing = self.micro >= self.spu
         sync = self.model.require_sync
         self.model.require_sync = False                        # the bucket hooks stay out of this path
         try:
@@ -276,7 +316,7 @@ class GraphedTrainStep:
                 self.eager_left -= 1
                 if self.split:
                     cut = {}
-                    out = self._step_split(lambda: self._phase1(tvis, cut), lambda: self._phase2(cut))
+                    out = self._step_split(lambda: self._phase1(tvis, cut), lambda: self._phase2(cut), closing)
                 else:
                     out = self._phase1(tvis)
             else:
@@ -284,14 +324,23 @@ class GraphedTrainStep:
                 if g is None:
                     g = self._capture(tvis)
                 if self.split:
-                    self._step_split(g[0].replay, g[1].replay)
+                    self._step_split(g[0].replay, g[1].replay, closing)
                 else:
                     g.replay()
                 out = self.outputs[tvis]
         finally:
             self.model.require_sync = sync
-        if self.model.world_size > 1 and not self.split:
-            _average_gradients(self.model)
+        if not closing:
+            self.accum.add_(self.model.flat_grad)              # every replay ASSIGNS the flat gradient: sum it here
+            return out
+        self.micro = 0
+        if not self.split:
+            if self.accum is not None:
+                self.model.flat_grad.add_(self.accum)
+            if self.model.world_size > 1:
+                _average_gradients(self.model)
+        if self.accum is not None:
+            self.accum.zero_()
         self.optimizer.step()
         return out
 
@@ -301,8 +350,11 @@ class GraphedStaticStep:
     draws (Point_CAE_PointNetv2: the corruption is applied by the data loader):
     ONE captured forward+loss+backward graph, replayed every step."""
 
-    def __init__(self, model, optimizer, loss_mix, batch_size, npoints, warmup_eager=2):
+    def __init__(self, model, optimizer, loss_mix, batch_size, npoints, warmup_eager=2, step_per_update=1):
         assert isinstance(model, FlatDataParallel)
+        if getattr(model.module, 'draws_in_forward', False):
+            raise NotImplementedError('GraphedStaticStep: this model draws a corruption on the host inside forward '
+                                      '(dropout_global): a captured graph would replay one frozen draw; step it eagerly')
         self.model, self.optimizer, self.loss_mix = model, optimizer, loss_mix
         dev = model.flat_param.device
         self.corrupted = torch.zeros(batch_size, npoints, 3, device=dev)
@@ -310,6 +362,8 @@ class GraphedStaticStep:
         self.graph, self.out = None, None
         _warn_if_null_stream()
         self.eager_left = warmup_eager
+        self.spu, self.micro = int(step_per_update), 0
+        self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
 
     def _fwd_bwd(self):
         m = self.model
@@ -346,6 +400,14 @@ class GraphedStaticStep:
             self.graph.replay()
             out = self.out
         self.model.require_sync = sync
+        self.micro += 1
+        if self.micro < self.spu:                                  # gradient-accumulation micro-step
+            self.accum.add_(self.model.flat_grad)
+            return out
+        self.micro = 0
+        if self.accum is not None:
+            self.model.flat_grad.add_(self.accum)
+            self.accum.zero_()
         if self.model.world_size > 1:
             _average_gradients(self.model)
         self.optimizer.step()

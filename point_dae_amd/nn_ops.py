@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import _lib
 from .arena import ZeroArena, arena, begin_step  # noqa: F401
 from .patch_embed import patch_embed  # noqa: F401  (fused gfx950 embedder)
-from .probe import Probe, set_probe  # noqa: F401
+from .probe import Probe, probed_family, set_probe  # noqa: F401
 
 
 def _empty(shape, like, dtype=torch.float32):
@@ -369,32 +369,44 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
         return y
     cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
-    _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), epi, _lib.ptr(z),
-              _lib.ptr(y), cfg, splits, sb)
+    probed_family('rows_gemm', 2.0 * M * N * K,
+                  lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
+                                    epi, _lib.ptr(z), _lib.ptr(y), cfg, splits, sb))
     return y
 
 
-# Gradient sink (set by graph_step.GraphedTrainStep around its forward + backward, None otherwise): the flat
-# gradient views of the parameters by data pointer.  A Function that finds its weights here writes their
-# gradients straight into the flat buffer, reports them in GRAD_SINK['written'] and returns None for them --
-# the step's gather copy then skips those tensors (97 % of the 116 MB).  Only sound when nothing else
-# accumulates into the views during the backward, i.e. not in the eager FlatDataParallel path.
-GRAD_SINK = None
+# Gradient sink.  FlatDataParallel tags every parameter it owns with (weakref to itself, index); a graphed step
+# ARMS its own FlatDataParallel instance around its forward + backward (graph_step._phase1).  A Function whose
+# weights all belong to one armed owner -- and still live in that owner's flat parameter buffer -- writes their
+# gradients straight into the owner's flat gradient views, records the indices in owner.sink_written and returns
+# None for them; the step's gather copy then skips those tensors (97 % of the 116 MB).  The state is per
+# FlatDataParallel instance: a second model in the process, or an un-armed (eager) step, never sees it; a parameter
+# moved out of the flat buffer (.to(), a re-allocation) no longer matches its slot and falls back to autograd.
+def _sink_tags(weights):
+    """forward-time: the (owner ref, index) tags of the parameters (saved tensors lose Python attributes)."""
+    return [getattr(w, '_pdae_flat', None) for w in weights]
 
 
-def _sink_views(weights):
-    sink = GRAD_SINK
-    if sink is None:
+def _sink_views(tags, weights):
+    """backward-time: (owner, indices, flat gradient views) when every weight sits in ONE armed owner, else None."""
+    if not tags or any(t is None for t in tags):
         return None
-    views = [sink['views'].get(w.data_ptr()) for w in weights]
-    return views if all(v is not None and v.shape == w.shape for v, w in zip(views, weights)) else None
+    owner = tags[0][0]()
+    if owner is None or not owner.sink_armed or any(t[0]() is not owner for t in tags):
+        return None
+    idx = [t[1] for t in tags]
+    base, esz = owner.flat_param.data_ptr(), owner.flat_param.element_size()
+    for i, w in zip(idx, weights):
+        if w.data_ptr() != base + owner.offsets[i][0] * esz or owner.grad_views[i].shape != w.shape:
+            return None
+    return owner, idx, [owner.grad_views[i] for i in idx]
 
 
 def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     """Weight (and bias) gradients of a group of Linear layers that share their rows, one grouped
     launch (+ the ordered slab reduction).  -> ([dW], [db or None]); outs / db_outs: preallocated outputs
     (db_outs: one per True in with_bias).  When EVERY output is preallocated by the caller -- the flat gradient
-    views of nn_ops.GRAD_SINK, which autograd never sees -- the reduction may be parked until
+    views of an armed FlatDataParallel (_sink_views), which autograd never sees -- the reduction may be parked until
     _lib.deferred_flush; a tensor handed to autograd may be cloned by it on the spot and must be complete."""
     M = dys[0].shape[0]
     Ns, Ks = [t.shape[1] for t in dys], [t.shape[1] for t in xs]
@@ -402,8 +414,9 @@ def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     dws = outs if outs is not None else [_empty((n, k), dys[0]) for n, k in zip(Ns, Ks)]
     it = iter(db_outs) if db_outs is not None else None
     dbs = [(next(it) if it is not None else _empty((n,), dys[0])) if f else None for n, f in zip(Ns, with_bias)]
-    _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws,
-                    may_defer=outs is not None and (db_outs is not None or not any(with_bias)))
+    probed_family('rows_wgrad', 2.0 * M * sum(n * k for n, k in zip(Ns, Ks)),
+                  lambda: _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws,
+                                          may_defer=outs is not None and (db_outs is not None or not any(with_bias))))
     return dws, dbs
 
 
@@ -621,6 +634,7 @@ class _TransformerBlock(torch.autograd.Function):
             (_slabs(a_in) if a_in is not None else 1)
         ctx.a2_slabs = _slabs(a2)
         ctx.pos_grad = pos_grad if pos is not None else None          # (PosGrad, index of this block in its stack)
+        ctx.sink_tags = _sink_tags([wqkv, wproj, w1, w2, bf1])
         ctx.set_materialize_grads(False)
         return a2, x2
 
@@ -658,8 +672,8 @@ class _TransformerBlock(torch.autograd.Function):
             da0 = dbias_in = None
         # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
         dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
-        sink = _sink_views([wqkv, wproj, w1, w2, bf1])     # graphed step: straight into the flat gradient buffer
-        ws_, bs_ = (sink[:4], sink[4:]) if sink else (None, None)
+        sink = _sink_views(ctx.sink_tags, [wqkv, wproj, w1, w2, bf1])   # graphed step: straight into the flat buffer
+        ws_, bs_ = (sink[2][:4], sink[2][4:]) if sink else (None, None)
         if tail:                               # two row counts: two groups
             (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False], ws_[:1] if sink else None)
             (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False],
@@ -668,7 +682,7 @@ class _TransformerBlock(torch.autograd.Function):
             (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
                                                                     [False, False, True, False], ws_, bs_)
         if sink:
-            GRAD_SINK['written'].update(w.data_ptr() for w in (wqkv, wproj, w1, w2, bf1))
+            sink[0].sink_written.update(sink[1])
             dwqkv = dwproj = dw1 = dw2 = dbf1 = None
         return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
                 dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None, None)

@@ -24,7 +24,9 @@ def get_args(argv=None):
     p.add_argument('--total_bs', type=int, default=-1)
     # synthetic-data controls (no dataset ships with this repo)
     p.add_argument('--max_epoch', type=int, default=-1, help='override config.max_epoch')
-    p.add_argument('--steps_per_epoch', type=int, default=50, help='synthetic batches per epoch')
+    p.add_argument('--steps_per_epoch', type=int, default=None,
+                   help='batches per epoch; default: ceil(len(dataset) / total_bs) for a listed .npy set (the '
+                        "reference's DataLoader length), 50 for the synthetic one")
     args = p.parse_args(argv)
     if args.resume and args.start_ckpts is not None:
         raise ValueError('--resume and --start_ckpts cannot be both activate')

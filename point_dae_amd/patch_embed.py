@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .arena import arena
-from .probe import probed
+from .probe import probed, probed_family
 
 
 ALGEBRA = os.environ.get('PDAE_EMBED_ALGEBRA', '1') != '0'
@@ -56,8 +56,9 @@ def _gemm(x, w, w_kn=False, bias=None):
     N = w.shape[1] if w_kn else w.shape[0]
     cfg, _, _ = _lib.rows_gemm_plan(M, N, K, w_kn, False)
     y = _empty((M, N), x)
-    _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias), 0, None,
-              _lib.ptr(y), cfg, 1, 0)
+    probed_family('rows_gemm', 2.0 * M * N * K,
+                  lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
+                                    0, None, _lib.ptr(y), cfg, 1, 0))
     return y
 
 
@@ -67,7 +68,7 @@ def _wgrad(dy, x):
     Ns, Ks = [dy.shape[1]], [x.shape[1]]
     ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dy)
     dw = _empty((Ns[0], Ks[0]), dy)
-    _lib.rows_wgrad(dy, M, [dy], [x], [dw], [None], ws)
+    probed_family('rows_wgrad', 2.0 * M * Ns[0] * Ks[0], lambda: _lib.rows_wgrad(dy, M, [dy], [x], [dw], [None], ws))
     return dw
 
 
@@ -298,11 +299,34 @@ def patch_embed(points, first_conv, second_conv, training, groups=None, masked=N
     if n != 32:
         raise NotImplementedError('the fused embedder is written for group_size 32')
     if isinstance(first_conv[1], torch.nn.SyncBatchNorm) or isinstance(second_conv[1], torch.nn.SyncBatchNorm):
-        # --sync_bn (runner_pretrain.py:81-83, off in every shipped config): the fused embedder computes
-        # per-replica batch statistics; refusing is better than silently ignoring the flag
-        raise NotImplementedError('SyncBatchNorm in the fused patch embedder (batch statistics are per replica)')
+        # --sync_bn (runner_pretrain.py:81-83, off in every shipped config): batch statistics over ALL replicas.
+        # The fused kernels keep BatchNorm's sums on the device of one replica, so this flag takes the layer-by-layer
+        # path: the same row GEMMs, torch's SyncBatchNorm modules (which own the collectives) in between.
+        return patch_embed_layerwise(points, first_conv, second_conv, groups)
     return PatchEmbedFunction.apply(
         points.reshape(BG * n, 3), first_conv[0].weight, first_conv[0].bias, first_conv[1].weight,
         first_conv[1].bias, first_conv[3].weight, first_conv[3].bias, second_conv[0].weight,
         second_conv[0].bias, second_conv[1].weight, second_conv[1].bias, second_conv[3].weight,
         second_conv[3].bias, first_conv, second_conv, training, groups, masked)
+
+
+def patch_embed_layerwise(points, first_conv, second_conv, groups=None):
+    """Encoder.forward (models/PointCAE_transformer.py:37-51) layer by layer on the row GEMMs, calling the
+    BatchNorm MODULES as they are -- which is what lets nn.SyncBatchNorm (collective C4 of SURVEY 2.2) compute its
+    statistics across the replicas.  Slower than the fused path (every intermediate is materialised); used only under
+    --sync_bn.  The last conv + max-pool run on the listed groups only, like the fused path."""
+    from . import nn_ops
+    BG, n, _ = points.shape
+    R = BG * n
+    y = nn_ops.linear_any(points.reshape(R, 3), first_conv[0].weight.squeeze(-1), first_conv[0].bias)
+    y = torch.relu(first_conv[1](y))
+    f = nn_ops.linear_any(y, first_conv[3].weight.squeeze(-1), first_conv[3].bias)
+    C2 = f.shape[1]
+    g = f.view(BG, n, C2).max(dim=1, keepdim=True)[0]
+    cat = torch.cat([g.expand(-1, n, -1), f.view(BG, n, C2)], dim=2).reshape(R, 2 * C2)
+    h = nn_ops.linear_any(cat, second_conv[0].weight.squeeze(-1), second_conv[0].bias)
+    h = torch.relu(second_conv[1](h))
+    if groups is not None:
+        h = h.view(BG, n, -1).index_select(0, groups.long()).reshape(-1, h.shape[1])
+    t = nn_ops.linear_any(h, second_conv[3].weight.squeeze(-1), second_conv[3].bias)
+    return t.view(-1, n, t.shape[1]).max(dim=1)[0]

@@ -50,6 +50,8 @@ class _ConvBN(nn.Sequential):
         if pad_at is not None:
             w = torch.cat([w[:, :pad_at], w.new_zeros(w.shape[0], 1), w[:, pad_at:]], dim=1)
         y = nn_ops.linear_any(x, w)
+        if isinstance(bn, nn.SyncBatchNorm):
+            return F.relu(bn(y))                       # --sync_bn: the module owns the cross-replica statistics
         if self.training:
             bn.num_batches_tracked += 1
         y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training,
@@ -134,6 +136,12 @@ class Point_CAE_PointNetv2(nn.Module):
         self.register_buffer('grid', grid, persistent=False)
         self.loss = config.loss
         self.build_loss_func(self.loss)
+
+    @property
+    def draws_in_forward(self):
+        """True when forward() draws random numbers on the host (the in-forward corruptions): such a step
+        must not be captured into a hipGraph -- the draw and its H2D copy would be replayed frozen."""
+        return any(item in ('dropout_global', 'dropout_patch_pointmae') for item in self.corrupt_type)
 
     def build_loss_func(self, loss_type):
         if loss_type == 'cdl1':

@@ -69,17 +69,21 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     use_created_stream(device)
     ds_cfg = dict(config.dataset.train._base_)          # NAME, N_POINTS, PC_PATH, DATA_PATH (reference schema)
     ds_cfg.update(dict(config.dataset.train.others))
-    ds_cfg.update(seed=args.seed + rank, device=device, steps_per_epoch=getattr(args, 'steps_per_epoch', 50))
+    ds_cfg.update(seed=args.seed + rank, device=device, steps_per_epoch=getattr(args, 'steps_per_epoch', None),
+                  rank=rank, world=world)
     ds_cfg.setdefault('bs', config.total_bs // world)
     train_loader = DATASETS.build(ds_cfg)
 
     base_model = builder.model_builder(config.model).to(device)
-    start_epoch = 0
+    start_epoch, best_metric = 0, 0.
     if args.resume:
-        start_epoch, _ = builder.resume_model(base_model, args)
+        start_epoch, best_metric = builder.resume_model(base_model, args)   # runner_pretrain.py:69-72
     elif args.start_ckpts is not None:
         builder.load_model(base_model, args.start_ckpts)
-    if args.sync_bn and world > 1:
+    sync_bn = bool(args.sync_bn) and world > 1
+    if sync_bn:
+        # runner_pretrain.py:81-83.  The converted modules run the layer-by-layer embedder / set-abstraction paths
+        # (patch_embed.patch_embed_layerwise), whose SyncBatchNorm modules issue their own collectives: eager steps.
         base_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(base_model)
     spu = int(config.get('step_per_update', 1))     # gradient accumulation (runner_pretrain.py:188-197): eager steps
     model = FlatDataParallel(base_model)
@@ -92,20 +96,27 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     from .point_cae_transformer import PointCAE_transformer
     bs = ds_cfg['bs']
     gw_dev = torch.zeros((), device=device)                 # gradual weight, read inside the captured graph
-    if isinstance(base_model, PointCAE_transformer) and config.loss_type in ('xyz', 'xyznormal') \
-            and config.step_per_update == 1 and base_model.masked:
-        graphed = GraphedTrainStep(model, optimizer, config, bs, config.npoints)
+    graphed = None
+    if sync_bn:
+        step_fn = None
+    elif isinstance(base_model, PointCAE_transformer):
+        # every branch of the step body replays (graph_step.GraphedTrainStep): all loss types through a device
+        # scalar, the un-masked model, gradient accumulation
+        graphed = GraphedTrainStep(model, optimizer, config, bs, config.npoints, step_per_update=spu)
         step_fn = lambda corrupted, clean: graphed(clean)   # noqa: E731  (corrupted input unused on this path)
-    elif isinstance(base_model, Point_CAE_PointNetv2) and config.step_per_update == 1:
+    elif isinstance(base_model, Point_CAE_PointNetv2) and not base_model.draws_in_forward:
         w = float(config.normal_weight)
         mixes = {'xyz': lambda a, b: a, 'normal': lambda a, b: w * b, 'xyznormal': lambda a, b: a + w * b,
                  'xyznormal_gradual': lambda a, b: a + w * b * gw_dev, 'xyznormal_warm': lambda a, b: a + w * b * gw_dev}
-        graphed = GraphedStaticStep(model, optimizer, mixes[config.loss_type], bs, config.npoints)
+        graphed = GraphedStaticStep(model, optimizer, mixes[config.loss_type], bs, config.npoints, step_per_update=spu)
         step_fn = graphed
     else:
+        # a model that draws a corruption on the host inside forward (`dropout_global`) cannot be captured -- the
+        # draw would be frozen into the graph -- and models without a graphed step (DGCNN) step eagerly
         step_fn = None
-    if spu != 1:
-        step_fn = None                                          # the captured steps update on every batch
+    if rank == 0:
+        log('step: %s' % ('eager' if step_fn is None else 'hipGraph replay (%s, step_per_update %d, loss_type %s)' % (
+            type(graphed).__name__, spu, config.loss_type)))
 
     # SVM-probe validation (runner_pretrain.py:263-270): labelled loaders, when the experiment has them
     val = None
@@ -116,18 +127,20 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
             def _loader(node):
                 c = dict(node._base_)
                 c.update(dict(node.others))
-                c.update(device=device, seed=args.seed)
+                c.update(device=device, seed=args.seed, rank=rank, world=world)   # sharded: validate() all_gathers
                 c.setdefault('bs', 32)
                 return DATASETS.build(c)
             val = (_loader(dcfg.extra_train), _loader(dcfg.val))
     from .svm_probe import Acc_Metric, validate
-    best_metrics, metrics = Acc_Metric(0.), Acc_Metric(0.)
+    best_metrics, metrics = Acc_Metric(best_metric), Acc_Metric(0.)
     num_iter = 0
 
     for epoch in range(start_epoch, config.max_epoch + 1):
         model.train()
         gw = gradual_weight_of(config, epoch)
         gw_dev.fill_(float(gw))
+        if isinstance(graphed, GraphedTrainStep):
+            graphed.set_gradual_weight(gw)
         acc = torch.zeros(2, device=device)
         t0 = time.time()
         n = 0

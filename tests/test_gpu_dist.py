@@ -133,3 +133,105 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(want), '--steps', '1',
                         '--warmup', '0'], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and '{"metric"' not in r.stdout, (r.returncode, r.stdout[-500:])
+
+
+def _nccl_one_rank(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    from point_dae_amd import graph_step
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import use_created_stream
+    use_created_stream()
+    net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.LayerNorm(64), torch.nn.Linear(64, 8)).cuda()
+    model = FlatDataParallel(net)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    model.flat_grad.copy_(torch.randn(model.flat_grad.shape, device='cuda', generator=g))
+    want = model.flat_grad.clone()
+    n = model.flat_grad.numel()
+    # the slices of the split step: async all-reduce on RCCL's stream behind an event on the compute stream
+    (w1, d1), (w2, d2) = graph_step._start_average(model, 0, n // 2), graph_step._start_average(model, n // 2, n)
+    busy = torch.randn(1 << 20, device='cuda').sum()             # compute-stream work issued while RCCL runs
+    for (a, b), (w, d) in (((0, n // 2), (w1, d1)), ((n // 2, n), (w2, d2))):
+        w.wait()
+        if d:
+            model.flat_grad[a:b].div_(1)
+    torch.cuda.synchronize()
+    graph_step._average_gradients(model)                          # the single-phase path
+    torch.cuda.synchronize()
+    torch.save({'equal': torch.equal(model.flat_grad, want), 'avg_in_collective': not (d1 or d2),
+                'backend': dist.get_backend(), 'busy': float(busy)}, out)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_average_path(tmp_path):
+    """The `nccl` backend of this torch build IS RCCL.  One rank (the box has one GPU) through the exact calls of the
+    multi-GPU step -- graph_step._start_average on slices (async_op, ReduceOp.AVG) and _average_gradients: RCCL links,
+    initialises a communicator, accepts AVG on fp32 views of the flat gradient buffer and returns it unchanged."""
+    out = str(tmp_path / 'rccl.pt')
+    mp.spawn(_nccl_one_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r['backend'] == 'nccl'
+    assert r['equal'], 'an average over one rank changed the gradients'
+    assert r['avg_in_collective'], 'ReduceOp.AVG was rejected by this RCCL build: the step falls back to SUM + divide'
+
+
+def _sync_bn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    from point_dae_amd.graph_step import use_created_stream
+    from point_dae_amd.point_cae_transformer import Encoder
+    use_created_stream()
+    torch.manual_seed(3)
+    enc = Encoder(384).cuda().train()                              # same seed: same weights on both ranks
+    for bn in (enc.first_conv[1], enc.second_conv[1]):
+        torch.nn.init.uniform_(bn.weight, 0.5, 1.5), torch.nn.init.uniform_(bn.bias, -0.2, 0.2)
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.randn(64, 32, 3, generator=g) * 0.2).cuda()        # 64 groups; rank r owns [32 r, 32 r + 32)
+    groups = torch.arange(0, 32, 2, dtype=torch.int32, device='cuda')   # visible groups of a half (local ids)
+    w = torch.randn(16, 384, generator=g).cuda()
+    sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Encoder(384).cuda().train())
+    sync.load_state_dict(enc.state_dict())
+    mine = pts[32 * rank:32 * rank + 32].reshape(1, 32, 32, 3)
+    tok = sync(mine, groups=groups)
+    (tok * w).sum().backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in sync.parameters()])
+    dist.all_reduce(grads)                                          # the sum over the replicas (DDP would average)
+    toks = [torch.empty_like(tok) for _ in range(world)]
+    dist.all_gather(toks, tok.detach())
+    if rank == 0:
+        # one process, the whole batch, the FUSED embedder: per-"replica" statistics over all 64 groups
+        allg = torch.cat([groups, groups + 32])
+        ref = enc(pts.reshape(1, 64, 32, 3), groups=allg)
+        (ref * torch.cat([w, w])).sum().backward()
+        ref_g = torch.cat([p.grad.reshape(-1) for p in enc.parameters()])
+        torch.save({'tok': torch.cat(toks).cpu(), 'ref': ref.detach().cpu(), 'g': grads.cpu(), 'ref_g': ref_g.cpu(),
+                    'rm': sync.second_conv[1].running_mean.cpu(), 'ref_rm': enc.second_conv[1].running_mean.cpu(),
+                    'rv': sync.first_conv[1].running_var.cpu(), 'ref_rv': enc.first_conv[1].running_var.cpu()}, out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sync_bn_statistics_span_the_replicas(tmp_path):
+    """--sync_bn (runner_pretrain.py:81-83, collective C4): the converted embedder takes the layer-by-layer path
+    (patch_embed.patch_embed_layerwise) whose SyncBatchNorm modules reduce the batch statistics over the ranks.
+    Two ranks with half of the groups each reproduce ONE process running the fused embedder on all groups: tokens,
+    running estimates and (summed over the ranks) every parameter gradient."""
+    out = str(tmp_path / 'sbn.pt')
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert (r['tok'] - r['ref']).abs().max().item() <= 2e-4 * r['ref'].abs().max().item()
+    assert torch.allclose(r['rm'], r['ref_rm'], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(r['rv'], r['ref_rv'], rtol=1e-4, atol=1e-6)
+    scale = r['ref_g'].abs().max().item()
+    # (the fused path returns exactly zero for the two conv biases that feed a BatchNorm; the layer-wise path returns
+    # their rounding residue -- both are ~0 on this scale)
+    assert (r['g'] - r['ref_g']).abs().max().item() <= 2e-3 * scale

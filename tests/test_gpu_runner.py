@@ -1,0 +1,163 @@
+"""Runner-level behaviour on the GPU (tools/runner_pretrain.py:50-288): which step implementation a
+configuration gets, the gradient sink's ownership rules, resume of the best metric."""
+import copy
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG3 = os.path.join(ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml')
+CFG2 = os.path.join(ROOT, 'cfgs', 'pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml')
+
+
+def _tiny_transformer_cfg():
+    from point_dae_amd.config import cfg_from_yaml_file
+    config = cfg_from_yaml_file(CFG3)
+    config.model.transformer_config.drop_path_rate = 0.0
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    return config
+
+
+def _seed(s):
+    random.seed(s), np.random.seed(s), torch.manual_seed(s)
+
+
+def test_gradient_sink_belongs_to_one_model():
+    """nn_ops._sink_views: the sink is state of ONE FlatDataParallel instance.  While model A's graphed step has A
+    armed, (1) a second model B in the same process still gets its gradients from autograd, (2) a weight of A that
+    left A's flat buffer (what .to() / a re-allocation does) is not written through its stale slot."""
+    from point_dae_amd import builder
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = _tiny_transformer_cfg()
+    torch.manual_seed(0)
+    net_a = builder.model_builder(config.model).cuda().train()
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    B = 8
+    x = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=5)).cuda()
+    model_a, model_b, model_c = FlatDataParallel(net_a), FlatDataParallel(net_b), FlatDataParallel(net_c)
+    opt_a, _ = builder.build_opti_sche(model_a, config)
+    step = GraphedTrainStep(model_a, opt_a, config, B, 1024, warmup_eager=1)
+    step.pts.copy_(x)
+    _seed(3)
+    tvis = step._draw()
+    nv, nm = B * tvis, B * (step.G - tvis)
+    kw = dict(steps=step.steps, rows=(step.vis[:nv], step.msk[:nm]))
+
+    def eager(model):
+        model.zero_grad()
+        lx, ln = model(step.pts, step.pts, **kw)
+        (lx + step.normal_weight * ln.sum()).backward()
+        return model.flat_grad.clone()
+
+    ref = eager(model_c)                                           # nobody armed: plain autograd
+    # (1) A armed, B steps: B's weights carry B's tag, B is not armed -> autograd, nothing recorded anywhere
+    model_a.sink_armed, model_a.sink_written = True, set()
+    try:
+        got_b = eager(model_b)
+    finally:
+        model_a.sink_armed = False
+    assert not model_a.sink_written and not model_b.sink_written
+    assert torch.allclose(got_b, ref, rtol=0, atol=2e-3 * ref.abs().max().item())
+    # A's own step uses the sink for its block weights
+    step._phase1(tvis)
+    blk = [i for i, n in enumerate(model_a.names) if '.blocks.' in n and n.endswith(('qkv.weight', 'fc1.weight'))]
+    assert blk and set(blk) <= model_a.sink_written
+    assert torch.allclose(model_a.flat_grad, ref, rtol=0, atol=2e-3 * ref.abs().max().item())
+    # (2) one block weight of A leaves the flat buffer: its Function falls back to autograd for the whole block
+    i = blk[0]
+    p = model_a.params[i]
+    flat_view = p.data
+    p.data = p.data.clone()
+    try:
+        step._phase1(tvis)
+        assert i not in model_a.sink_written
+        assert torch.allclose(model_a.flat_grad, ref, rtol=0, atol=2e-3 * ref.abs().max().item())
+    finally:
+        p.data = flat_view
+
+
+def test_static_graph_refuses_in_forward_draws():
+    """`dropout_global` draws torch.rand on the host inside forward; a captured graph would replay one
+    frozen permutation.  GraphedStaticStep refuses such a model, the runner steps it eagerly."""
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedStaticStep
+    config = cfg_from_yaml_file(CFG2)
+    config.model.corrupt_type = ['dropout_global']
+    net = builder.model_builder(config.model).cuda().train()
+    assert net.draws_in_forward
+    model = FlatDataParallel(net)
+    opt, _ = builder.build_opti_sche(model, config)
+    with pytest.raises(NotImplementedError, match='dropout_global'):
+        GraphedStaticStep(model, opt, lambda a, b: a + b, 4, 1024)
+
+
+def _run_main(tmp_path, cfg, extra=(), steps=4):
+    cfgdir = tmp_path / 'cfgs'
+    cfgdir.mkdir(exist_ok=True)
+    path = cfgdir / 'tiny.yaml'
+    yaml.safe_dump(cfg, open(path, 'w'))
+    cmd = [sys.executable, '-m', 'point_dae_amd.main', '--config', str(path), '--total_bs', '4', '--steps_per_epoch',
+           str(steps), '--exp_name', 'ci', '--root_folder', os.path.relpath(str(tmp_path / 'exp'), ROOT)] + list(extra)
+    return subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True,
+                          timeout=900)
+
+
+def test_main_cli_dropout_global_config_trains(tmp_path):
+    """The reference's pretrain_PointCAE_dropout_global.yaml shape (model.corrupt_type = [dropout_global] on the
+    PointNet++ auto-encoder) through main -> run_net: more steps than the eager warm-up, so a captured graph of
+    this forward would have failed (host RNG + pageable H2D copy under capture)."""
+    cfg = yaml.safe_load(open(CFG2))
+    cfg['model']['corrupt_type'] = ['dropout_global']
+    cfg['dataset']['train']['others']['corrupt_type'] = ['dropout_global']
+    cfg['max_epoch'] = 1
+    r = _run_main(tmp_path, cfg, steps=5)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'clouds/s' in r.stdout
+    assert 'step: eager' in r.stdout
+
+
+@pytest.mark.parametrize('variant', ['xyznormal_gradual', 'normal', 'nomask', 'accumulate'])
+def test_main_cli_graphs_every_branch(tmp_path, variant):
+    """runner_pretrain.py:161-197: every loss_type, the un-masked model and step_per_update > 1 replay as hipGraphs
+    (the runner prints which step implementation it chose)."""
+    cfg = yaml.safe_load(open(CFG3))
+    cfg['model']['transformer_config'].update(depth=2, decoder_depth=1)
+    cfg['max_epoch'] = 1
+    if variant in ('xyznormal_gradual', 'normal'):
+        cfg['loss_type'] = variant
+    elif variant == 'nomask':
+        cfg['model']['corrupt_type'] = [c for c in cfg['model']['corrupt_type'] if c != 'Drop-Patch']
+    else:
+        cfg['step_per_update'] = 2
+    r = _run_main(tmp_path, cfg, steps=6)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'step: hipGraph' in r.stdout, r.stdout[-1500:]
+    assert 'clouds/s' in r.stdout
+
+
+def test_resume_keeps_best_metric(tmp_path):
+    """runner_pretrain.py:69-72: best_metrics = Acc_Metric(best_metric) on --resume."""
+    from point_dae_amd import builder
+    from point_dae_amd.svm_probe import Acc_Metric
+
+    class Args:
+        experiment_path = str(tmp_path)
+        local_rank = 0
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.AdamW(net.parameters())
+    builder.save_checkpoint(net, opt, 7, Acc_Metric(0.5), Acc_Metric(0.75), 'ckpt-last', Args)
+    epoch, best = builder.resume_model(torch.nn.Linear(3, 2), Args)
+    assert epoch == 8 and best == pytest.approx(0.75)
+    assert not Acc_Metric(0.6).better_than(Acc_Metric(best))
