@@ -209,6 +209,36 @@ int pdae_dropout_local(int b, int p, const float* xyz, const int32_t* nclusters,
                        const int32_t* seed_rank, const int32_t* sizes,
                        unsigned char* alive, pdae_stream_t stream);
 
+/* The other loader-side stages (ShapeNet55Dataset.__getitem__ :90-119 = augment_data 'norm' -> random_sample ->
+ * corrupt_data -> random_sample); the random draws are inputs (the host side draws them with the reference's
+ * distributions; tests/golden/make_loader_fixtures.py records the live reference's).  Clouds live in (b, stride, 3)
+ * buffers so that added points can be appended behind the p original ones.
+ * pipeline_norm_affine: replaces _pc_normalize (corrupt_util.py:7-17; when `normalise`), the maps of 'affine_r3'
+ *   (:1062-1070 -> corrupt_tranlate :130-140, corrupt_scale_nonorm_2p :82-92, corrupt_rotate_360 :241-263,
+ *   corrupt_reflection :390-409, corrupt_shear_p5 :412-428) as nmaps[i] <= 3 maps of 12 floats (3x3 M row-major, t):
+ *   y = x M + t applied in order, and corrupt_jitter (:179-191): y += sigma[i] * noise[i,k,:] (noise may be NULL).
+ * pipeline_add_global: replaces corrupt_add_global (:830-841) with _sample_points_inside_unit_sphere (:42-56):
+ *   u (b, nmax, 3) = the radius / cos(theta) / phi uniforms; count[i] points are written behind row p0.
+ * pipeline_add_local: replaces corrupt_add_local (:844-870): added point j of cloud i = cloud point seed[i,j] +
+ *   sigma[i,j] * noise[i,j,:], divided by its squared norm when that exceeds 1 (as the reference does).
+ * pipeline_density: replaces density (:875-897): alive[i,k] &= dist01(xyz, view[i]) * gate[i] < r[i,k].
+ * pipeline_subset: replaces ShapeNet.random_sample (:76-88): out (b, n, 3) = the n alive points of smallest key, in
+ *   ascending key order (ties by index) -- with keys = ranks of a permutation this IS pc[permutation[:n]]; with fewer
+ *   than n survivors they repeat cyclically (the reference refills by sampling with replacement, then shuffles).
+ *   alive may be NULL (all alive).  p <= 16384, n <= 16384.
+ */
+int pdae_pipeline_norm_affine(int b, int p, int out_stride, int normalise, const float* xyz, const int32_t* nmaps,
+                              const float* maps, const float* sigma, const float* noise, float* out,
+                              pdae_stream_t stream);
+int pdae_pipeline_add_global(int b, int nmax, int stride, int p0, const int32_t* count, const float* u, float* xyz,
+                             pdae_stream_t stream);
+int pdae_pipeline_add_local(int b, int nmax, int stride, int p0, const int32_t* count, const int32_t* seed,
+                            const float* sigma, const float* noise, float* xyz, pdae_stream_t stream);
+int pdae_pipeline_density(int b, int p, int stride, const float* xyz, const float* view, const float* gate,
+                          const float* r, unsigned char* alive, pdae_stream_t stream);
+int pdae_pipeline_subset(int b, int p, int stride, int n, const float* xyz, const unsigned char* alive,
+                         const float* keys, float* out, pdae_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Chamfer distance.  Replaces chamfer_cuda_forward(xyz1, xyz2)
  *   extensions/chamfer_dist/chamfer.cu:147-171 (kernel :15-145) and

@@ -26,6 +26,11 @@ _SIGNATURES = {
     "pdae_group_points_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_dropout_local": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_flatten_group_index": [_i, _i, _i, _vp, _vp, _vp],
+    "pdae_pipeline_norm_affine": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_pipeline_add_global": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_pipeline_add_local": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_pipeline_density": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_pipeline_subset": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_mask_propagate": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -138,6 +138,217 @@ __global__ __launch_bounds__(DL_THREADS) void dropout_local_kernel(int P, const 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The other loader-side stages (datasets/corrupt_util.py, ShapeNet55Dataset.py:67-119), each a pure function of the
+// cloud and of the draws the host side makes with the reference's distributions (the live reference pins every one
+// of them through tests/golden/make_loader_fixtures.py):
+//   norm_affine   'norm' (_pc_normalize :7-17: centroid, max norm) -> up to three affine maps y = x M + t applied one
+//                 after the other as 'affine_r3' does (:1062-1070: translate :139-140, scale_nonorm :91-92, rotate
+//                 :262-263, reflection :408-409, shear :425-428) -> 'jitter' (:179-191: + sigma * noise)
+//   add_global    :830-841 / :42-56: points uniform in the unit ball from three uniforms each, appended
+//   add_local     :844-870: Gaussian clusters around cloud points, pulled back into the unit sphere, appended
+//   density       :875-897: distance-gated drop from a random viewpoint -> alive mask
+//   subset        ShapeNet.random_sample :76-88: the n smallest random keys among the survivors, in key order
+// One 1024-thread block per cloud for the stages that reduce over the cloud (norm, subset); the cloud stays in
+// registers.  fp32 throughout; the centroid is accumulated in fp64 (the reference's float32 np.mean adds the rows
+// one by one: its own rounding is ~4e-7, which is what the parity tolerance covers).
+
+template <int PPT>
+__global__ __launch_bounds__(DL_THREADS) void norm_affine_kernel(int P, int out_stride, int normalise,
+                                                                 const float* __restrict__ xyz,
+                                                                 const int* __restrict__ nmaps,
+                                                                 const float* __restrict__ maps,
+                                                                 const float* __restrict__ sigma,
+                                                                 const float* __restrict__ noise,
+                                                                 float* __restrict__ out) {
+  __shared__ double red[3][DL_THREADS / 64];
+  __shared__ float redm[DL_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* pts = xyz + (size_t)b * P * 3;
+  float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * DL_THREADS;          // thread-interleaved: consecutive lanes read consecutive points
+    const bool in = k < P;
+    px[i] = in ? pts[(size_t)k * 3 + 0] : 0.f;
+    py[i] = in ? pts[(size_t)k * 3 + 1] : 0.f;
+    pz[i] = in ? pts[(size_t)k * 3 + 2] : 0.f;
+  }
+  if (normalise) {
+    double sx = 0., sy = 0., sz = 0.;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) sx += px[i], sy += py[i], sz += pz[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      sx += __shfl_xor(sx, o, kWave), sy += __shfl_xor(sy, o, kWave), sz += __shfl_xor(sz, o, kWave);
+    }
+    if (lane == 0) red[0][w] = sx, red[1][w] = sy, red[2][w] = sz;
+    __syncthreads();
+    double cx = 0., cy = 0., cz = 0.;
+#pragma unroll
+    for (int q = 0; q < DL_THREADS / 64; ++q) cx += red[0][q], cy += red[1][q], cz += red[2][q];
+    const float mx = (float)(cx / P), my = (float)(cy / P), mz = (float)(cz / P);
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = tid + i * DL_THREADS;
+      px[i] -= mx, py[i] -= my, pz[i] -= mz;
+      if (k < P) m = fmaxf(m, sqrtf(px[i] * px[i] + py[i] * py[i] + pz[i] * pz[i]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if (lane == 0) redm[w] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int q = 0; q < DL_THREADS / 64; ++q) m = fmaxf(m, redm[q]);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) px[i] /= m, py[i] /= m, pz[i] /= m;
+  }
+  const int nm = nmaps ? min(nmaps[b], 3) : 0;
+  for (int q = 0; q < nm; ++q) {
+    const float* M = maps + ((size_t)b * 3 + q) * 12;
+    const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[3], m11 = M[4], m12 = M[5], m20 = M[6], m21 = M[7],
+                m22 = M[8], t0 = M[9], t1 = M[10], t2 = M[11];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float x = px[i], y = py[i], z = pz[i];
+      px[i] = ((x * m00 + y * m10) + z * m20) + t0;      // row vector times matrix, as np.dot(pointcloud, R)
+      py[i] = ((x * m01 + y * m11) + z * m21) + t1;
+      pz[i] = ((x * m02 + y * m12) + z * m22) + t2;
+    }
+  }
+  const float sg = sigma ? sigma[b] : 0.f;
+  float* dst = out + (size_t)b * out_stride * 3;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * DL_THREADS;
+    if (k >= P) continue;
+    float x = px[i], y = py[i], z = pz[i];
+    if (noise && sg != 0.f) {
+      const float* nz = noise + ((size_t)b * P + k) * 3;
+      x += sg * nz[0], y += sg * nz[1], z += sg * nz[2];
+    }
+    dst[(size_t)k * 3 + 0] = x, dst[(size_t)k * 3 + 1] = y, dst[(size_t)k * 3 + 2] = z;
+  }
+}
+
+// appended points: rows [p0, p0 + count[b]) of cloud b
+__global__ __launch_bounds__(256) void add_global_kernel(int nmax, int stride, int p0, const int* __restrict__ count,
+                                                         const float* __restrict__ u, float* __restrict__ xyz) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= min(count[b], nmax)) return;
+  const float* q = u + ((size_t)b * nmax + j) * 3;
+  const float radius = powf(q[0], 1.0f / 3.0f), theta = acosf(q[1]), phi = q[2];
+  float* d = xyz + ((size_t)b * stride + p0 + j) * 3;
+  const float st = sinf(theta);
+  d[0] = radius * st * cosf(phi), d[1] = radius * st * sinf(phi), d[2] = radius * cosf(theta);
+}
+
+__global__ __launch_bounds__(256) void add_local_kernel(int nmax, int stride, int p0, const int* __restrict__ count,
+                                                        const int* __restrict__ seed, const float* __restrict__ sigma,
+                                                        const float* __restrict__ noise, float* __restrict__ xyz) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= min(count[b], nmax)) return;
+  const size_t e = (size_t)b * nmax + j;
+  const float* c = xyz + ((size_t)b * stride + seed[e]) * 3;
+  const float sg = sigma[e];
+  float x = c[0] + sg * noise[e * 3 + 0], y = c[1] + sg * noise[e * 3 + 1], z = c[2] + sg * noise[e * 3 + 2];
+  const float d2 = (x * x + y * y) + z * z;
+  if (d2 > 1.f) x /= d2, y /= d2, z /= d2;                 // (:866-867: divided by the SQUARED norm, as the reference)
+  float* d = xyz + ((size_t)b * stride + p0 + j) * 3;
+  d[0] = x, d[1] = y, d[2] = z;
+}
+
+__global__ __launch_bounds__(256) void density_kernel(int P, int stride, const float* __restrict__ xyz,
+                                                      const float* __restrict__ view, const float* __restrict__ gate,
+                                                      const float* __restrict__ r, unsigned char* __restrict__ alive) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  const float* p = xyz + ((size_t)b * stride + k) * 3;
+  const float vx = view[b * 3], vy = view[b * 3 + 1], vz = view[b * 3 + 2];
+  const float dv = sqrtf((vx * vx + vy * vy) + vz * vz);          // |v| (= 1 up to rounding), :884-886
+  const float dx = p[0] - vx, dy = p[1] - vy, dz = p[2] - vz;
+  float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+  d = (d - (dv - 1.f)) / ((dv + 1.f) - (dv - 1.f));
+  const bool keep = d * gate[b] < r[(size_t)b * P + k];
+  unsigned char* a = alive + (size_t)b * stride + k;
+  *a = (*a && keep) ? 1 : 0;
+}
+
+// the n smallest keys among the alive points of a cloud, written in ascending key order (ties by index).
+// Fewer than n survivors: the rest repeats them cyclically in that order.
+template <int PPT>
+__global__ __launch_bounds__(DL_THREADS) void subset_kernel(int P, int stride, int n, const float* __restrict__ xyz,
+                                                            const unsigned char* __restrict__ alive,
+                                                            const float* __restrict__ keys, float* __restrict__ out) {
+  extern __shared__ unsigned sel[];                // [2][n]: key bits, point index of the selected
+  __shared__ int red[DL_THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  unsigned key[PPT];
+  int mine = 0;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid * PPT + i;                   // index order = thread order, then slot order
+    const bool in = k < P && (!alive || alive[(size_t)b * stride + k]);
+    key[i] = in ? __float_as_uint(fmaxf(keys[(size_t)b * stride + k], 0.f)) : 0xffffffffu;
+    mine += in ? 1 : 0;
+  }
+  const int total = block_sum_1024(mine, red);
+  const int K = min(n, total);
+  if (K == 0) {                                    // nothing survived: zeros
+    for (int j = tid; j < n * 3; j += DL_THREADS) out[(size_t)b * n * 3 + j] = 0.f;
+    return;
+  }
+  unsigned lo = 0, hi = 0x7f800000u;
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) cnt += key[i] <= mid ? 1 : 0;
+    if (block_sum_1024(cnt, red) >= K) hi = mid;
+    else lo = mid + 1;
+  }
+  const unsigned T = lo;
+  int below = 0, equal = 0;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) below += key[i] < T ? 1 : 0, equal += key[i] == T ? 1 : 0;
+  const int nbelow = block_sum_1024(below, red);
+  const int eq_before = block_excl_scan_1024(equal, red);
+  int quota = K - nbelow - eq_before;
+  bool take[PPT];
+  int ntake = 0;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    take[i] = key[i] < T;
+    if (key[i] == T) {
+      take[i] = quota > 0;
+      --quota;
+    }
+    ntake += take[i] ? 1 : 0;
+  }
+  int pos = block_excl_scan_1024(ntake, red);
+#pragma unroll
+  for (int i = 0; i < PPT; ++i)
+    if (take[i]) sel[pos] = key[i], sel[n + pos] = (unsigned)(tid * PPT + i), ++pos;
+  __syncthreads();
+  // rank of every selected element among the K selected (LDS broadcast reads), then the gather
+  for (int j = tid; j < K; j += DL_THREADS) {
+    const unsigned kj = sel[j], ij = sel[n + j];
+    int rank = 0;
+    for (int q = 0; q < K; ++q) {
+      const unsigned kq = sel[q];
+      rank += (kq < kj || (kq == kj && sel[n + q] < ij)) ? 1 : 0;
+    }
+    const float* p = xyz + ((size_t)b * stride + ij) * 3;
+    for (int o = rank; o < n; o += K) {            // o > rank only when there are fewer than n survivors
+      float* d = out + ((size_t)b * n + o) * 3;
+      d[0] = p[0], d[1] = p[1], d[2] = p[2];
+    }
+  }
+}
+
 }  // namespace pdae
 
 using namespace pdae;
@@ -156,4 +367,75 @@ extern "C" int pdae_dropout_local(int b, int p, const float* xyz, const int32_t*
   else if (ppt <= 8) hipLaunchKernelGGL(dropout_local_kernel<8>, dim3(b), dim3(DL_THREADS), 0, s, p, xyz, nclusters, seed_rank, sizes, alive);
   else hipLaunchKernelGGL(dropout_local_kernel<16>, dim3(b), dim3(DL_THREADS), 0, s, p, xyz, nclusters, seed_rank, sizes, alive);
   return check_launch("dropout_local");
+}
+
+
+extern "C" int pdae_pipeline_norm_affine(int b, int p, int out_stride, int normalise, const float* xyz,
+                                         const int32_t* nmaps, const float* maps, const float* sigma,
+                                         const float* noise, float* out, pdae_stream_t stream) {
+  if (b < 0 || p < 0 || out_stride < p) return bad_arg("pipeline_norm_affine: b, p >= 0 and out_stride >= p required");
+  if (b == 0 || p == 0) return PDAE_OK;
+  if (!xyz || !out || (nmaps && !maps) || (noise && !sigma)) return bad_arg("pipeline_norm_affine: null pointer");
+  if (p > DL_THREADS * DL_MAXPPT) return unsupported("pipeline_norm_affine: more than 16384 points per cloud");
+  hipStream_t s = as_stream(stream);
+  const int ppt = (p + DL_THREADS - 1) / DL_THREADS;
+#define PDAE_NA(PPT) hipLaunchKernelGGL(norm_affine_kernel<PPT>, dim3(b), dim3(DL_THREADS), 0, s, p, out_stride, normalise, xyz, nmaps, maps, sigma, noise, out)
+  if (ppt <= 2) PDAE_NA(2);
+  else if (ppt <= 4) PDAE_NA(4);
+  else if (ppt <= 8) PDAE_NA(8);
+  else PDAE_NA(16);
+#undef PDAE_NA
+  return check_launch("pipeline_norm_affine");
+}
+
+extern "C" int pdae_pipeline_add_global(int b, int nmax, int stride, int p0, const int32_t* count, const float* u,
+                                        float* xyz, pdae_stream_t stream) {
+  if (b < 0 || nmax < 0 || p0 < 0 || stride < p0 + nmax) return bad_arg("pipeline_add_global: bad size");
+  if (b == 0 || nmax == 0) return PDAE_OK;
+  if (!count || !u || !xyz) return bad_arg("pipeline_add_global: null pointer");
+  if (b > 65535) return unsupported("pipeline_add_global: b > 65535");
+  hipLaunchKernelGGL(add_global_kernel, dim3((nmax + 255) / 256, b), dim3(256), 0, as_stream(stream), nmax, stride, p0,
+                     count, u, xyz);
+  return check_launch("pipeline_add_global");
+}
+
+extern "C" int pdae_pipeline_add_local(int b, int nmax, int stride, int p0, const int32_t* count, const int32_t* seed,
+                                       const float* sigma, const float* noise, float* xyz, pdae_stream_t stream) {
+  if (b < 0 || nmax < 0 || p0 < 0 || stride < p0 + nmax) return bad_arg("pipeline_add_local: bad size");
+  if (b == 0 || nmax == 0) return PDAE_OK;
+  if (!count || !seed || !sigma || !noise || !xyz) return bad_arg("pipeline_add_local: null pointer");
+  if (b > 65535) return unsupported("pipeline_add_local: b > 65535");
+  hipLaunchKernelGGL(add_local_kernel, dim3((nmax + 255) / 256, b), dim3(256), 0, as_stream(stream), nmax, stride, p0,
+                     count, seed, sigma, noise, xyz);
+  return check_launch("pipeline_add_local");
+}
+
+extern "C" int pdae_pipeline_density(int b, int p, int stride, const float* xyz, const float* view, const float* gate,
+                                     const float* r, unsigned char* alive, pdae_stream_t stream) {
+  if (b < 0 || p < 0 || stride < p) return bad_arg("pipeline_density: bad size");
+  if (b == 0 || p == 0) return PDAE_OK;
+  if (!xyz || !view || !gate || !r || !alive) return bad_arg("pipeline_density: null pointer");
+  if (b > 65535) return unsupported("pipeline_density: b > 65535");
+  hipLaunchKernelGGL(density_kernel, dim3((p + 255) / 256, b), dim3(256), 0, as_stream(stream), p, stride, xyz, view, gate,
+                     r, alive);
+  return check_launch("pipeline_density");
+}
+
+extern "C" int pdae_pipeline_subset(int b, int p, int stride, int n, const float* xyz, const unsigned char* alive,
+                                    const float* keys, float* out, pdae_stream_t stream) {
+  if (b < 0 || p < 0 || n < 0 || stride < p) return bad_arg("pipeline_subset: bad size");
+  if (b == 0 || n == 0) return PDAE_OK;
+  if (!xyz || !keys || !out) return bad_arg("pipeline_subset: null pointer");
+  if (p > DL_THREADS * DL_MAXPPT) return unsupported("pipeline_subset: more than 16384 points per cloud");
+  if (n > 16384) return unsupported("pipeline_subset: more than 16384 points per subset");
+  hipStream_t s = as_stream(stream);
+  const size_t lds = sizeof(unsigned) * 2 * (size_t)n;
+  const int ppt = (p + DL_THREADS - 1) / DL_THREADS;
+#define PDAE_SS(PPT) hipLaunchKernelGGL(subset_kernel<PPT>, dim3(b), dim3(DL_THREADS), lds, s, p, stride, n, xyz, alive, keys, out)
+  if (ppt <= 2) PDAE_SS(2);
+  else if (ppt <= 4) PDAE_SS(4);
+  else if (ppt <= 8) PDAE_SS(8);
+  else PDAE_SS(16);
+#undef PDAE_SS
+  return check_launch("pipeline_subset");
 }

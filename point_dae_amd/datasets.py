@@ -9,12 +9,15 @@ DataLoader worker processes; at the ~9 k clouds/s of the training step on one MI
 argsorts of 8192-point clouds per second on host cores.
 
 Here the stored clouds are resident in HBM (ShapeNet-55's 41 952 training clouds x 8192 x 3 fp32 =
-4.1 GB of the 288 GB), a batch is gathered, normalised, corrupted and sub-sampled by device launches
-(dropout_local: csrc/pipeline.hip; affine maps and subsets: elementwise / sort launches), and the host
-only draws the random parameters (a few hundred numbers per batch) with the reference's
-distributions.  Random streams are this module's own (numpy Generator seeded with seed + rank): the
-reference's per-worker global numpy / python generators are not reproducible across worker counts
-either.
+4.1 GB of the 288 GB) and a batch is gathered, normalised, corrupted and sub-sampled by the kernels of
+csrc/pipeline.hip -- norm + affine maps + jitter in one launch, add_global / add_local / nonuniform_density /
+dropout_local one launch each, the random subset one launch -- each a pure function of the clouds and of
+random draws, pinned on the LIVE reference's `ShapeNet.__getitem__` with its draws recorded
+(tests/golden/make_loader_fixtures.py, tests/test_pipeline.py).  In production the host draws the
+small parameters (maps, levels, cluster sizes: a few hundred numbers per batch) with the reference's
+distributions and the device draws the bulk noise / keys.  Random streams are this module's own (numpy
+Generator seeded with seed + rank, torch device generator): the reference's per-worker global numpy /
+python generators are not reproducible across worker counts either.
 
 Sources: a directory of .npy clouds listed by `<DATA_PATH>/<subset>.txt` (the reference layout), else
 synthetic ShapeNet-shaped clouds (there is no dataset in the image).
@@ -35,12 +38,6 @@ _AUGS = ('clean', 'norm', 'scale', 'translate', 'rotate_z', 'rotate')          #
 _CORRUPTIONS = ('affine_r3', 'dropout_local') + AFFINE + ('rotate_z', 'scale', 'jitter', 'add_global', 'add_local',
                                                           'nonuniform_density')
 
-
-def pc_normalize(x):
-    """(B,P,3) -> centred, max norm 1 per cloud (corrupt_util._pc_normalize)."""
-    x = x - x.mean(dim=1, keepdim=True)
-    m = x.square().sum(-1).sqrt().amax(dim=1)
-    return x / m.view(-1, 1, 1)
 
 
 def _rot(a):
@@ -101,11 +98,6 @@ def draw_affine_r3(rng, B):
     return draw_affine(rng, B, names)
 
 
-def apply_affine(x, A, t):
-    """y = x A + t per cloud without a batched GEMM: three broadcast multiply-adds."""
-    A, t = torch.from_numpy(A).to(x.device), torch.from_numpy(t).to(x.device)
-    return (x[..., 0:1] * A[:, None, 0, :] + x[..., 1:2] * A[:, None, 1, :]) + (x[..., 2:3] * A[:, None, 2, :] + t[:, None, :])
-
 
 def sphere_points(rng, B, n):
     """n points uniform in the unit ball per cloud (corrupt_util._sample_points_inside_unit_sphere :42-56)."""
@@ -147,22 +139,66 @@ def dropout_local(x, ncl, rank, sizes):
     return alive.bool()
 
 
-def random_subset(x, n, alive=None, generator=None):
-    """A uniformly random subset of n points per cloud, in random order (ShapeNet.random_sample :76-88);
-    `alive` restricts it to the surviving points (clouds with fewer than n survivors are refilled by
-    sampling survivors with replacement, as the reference does)."""
+def _dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
+
+
+def pipeline_norm_affine(x, normalise=False, maps=None, sigma=None, noise=None, stride=None):
+    """x (B,P,3) -> y (B,stride,3) with rows [0,P) = jitter(affine maps(norm(x))) (csrc/pipeline.hip norm_affine).
+    maps: list per cloud of up to three (M (3,3), t (3,)) pairs applied in order, y = x M + t; sigma (B,) and
+    noise (B,P,3) on the device: y += sigma * noise."""
     B, P, _ = x.shape
-    keys = torch.rand((B, P), device=x.device, generator=generator)
-    if alive is not None:
-        keys = torch.where(alive, keys, keys + 2.0)          # dead points sort behind every survivor
-    order = keys.argsort(dim=1)[:, :n]
-    if alive is not None:
-        cnt = alive.sum(1, keepdim=True)
-        if bool((cnt < n).any()):
-            refill = (torch.rand((B, n), device=x.device, generator=generator) * cnt).long().clamp_(max=P - 1)
-            pos = torch.arange(n, device=x.device).view(1, n)
-            order = torch.where(pos < cnt, order, keys.argsort(dim=1).gather(1, refill))
-    return x.gather(1, order.unsqueeze(-1).expand(B, n, 3))
+    stride = P if stride is None else stride
+    dev = x.device
+    y = torch.empty((B, stride, 3), device=dev)
+    nm = mp = None
+    if maps is not None:
+        packed = np.zeros((B, 3, 12), np.float32)
+        packed[:, :, 0] = packed[:, :, 4] = packed[:, :, 8] = 1.0
+        counts = np.zeros(B, np.int32)
+        for b, ms in enumerate(maps):
+            counts[b] = len(ms)
+            for q, (M, t) in enumerate(ms):
+                packed[b, q, :9], packed[b, q, 9:] = np.asarray(M, np.float64).reshape(-1), np.asarray(t, np.float64)
+        nm, mp = _dev(counts, dev), _dev(packed, dev)
+    _lib.call('pdae_pipeline_norm_affine', x, B, P, stride, int(bool(normalise)), _lib.ptr(x.contiguous()), _lib.ptr(nm),
+              _lib.ptr(mp), _lib.ptr(sigma), _lib.ptr(noise), _lib.ptr(y))
+    return y
+
+
+def pipeline_add_global(y, p0, count, u):
+    """append count[b] points uniform in the unit ball behind row p0 of every cloud; u (B,nmax,3) uniforms."""
+    B, stride, _ = y.shape
+    _lib.call('pdae_pipeline_add_global', y, B, u.shape[1], stride, p0, _lib.ptr(count), _lib.ptr(u), _lib.ptr(y))
+
+
+def pipeline_add_local(y, p0, count, seed, sigma, noise):
+    """append count[b] cluster points: cloud point seed[b,j] + sigma[b,j] * noise[b,j], pulled inside the unit sphere."""
+    B, stride, _ = y.shape
+    _lib.call('pdae_pipeline_add_local', y, B, seed.shape[1], stride, p0, _lib.ptr(count), _lib.ptr(seed), _lib.ptr(sigma),
+              _lib.ptr(noise), _lib.ptr(y))
+
+
+def pipeline_density(y, p, view, gate, r, alive):
+    """alive[b,k] &= normalised distance to view[b] * gate[b] < r[b,k] for the first p rows."""
+    B, stride, _ = y.shape
+    _lib.call('pdae_pipeline_density', y, B, p, stride, _lib.ptr(y), _lib.ptr(view), _lib.ptr(gate), _lib.ptr(r),
+              _lib.ptr(alive))
+
+
+def pipeline_subset(y, p, n, keys, alive=None):
+    """-> (B,n,3): the n alive points with the smallest keys among the first p rows, in key order."""
+    B, stride, _ = y.shape
+    out = torch.empty((B, n, 3), device=y.device)
+    _lib.call('pdae_pipeline_subset', y, B, p, stride, n, _lib.ptr(y), _lib.ptr(alive), _lib.ptr(keys), _lib.ptr(out))
+    return out
+
+
+def draw_affine_maps(rng, names):
+    """[(M, t)] for the named maps, in order (draw_affine_map's parameter ranges)."""
+    return [draw_affine_map(rng, n) for n in names]
+
 
 
 def load_npy_clouds(pc_path, data_path, subset, whole=False, limit=None):
@@ -231,67 +267,100 @@ class ShapeNet:
         return self.steps
 
     def batch(self, index):
-        """-> (corrupted (B,npoints,3), clean (B,npoints,3)) on the device."""
+        """-> (corrupted (B,npoints,3), clean (B,npoints,3)) on the device, every stage on csrc/pipeline.hip:
+        ShapeNet.__getitem__ (:90-119) = augment_data -> random_sample -> corrupt_data -> random_sample."""
         x = self._clouds.index_select(0, index)
-        B = x.shape[0]
-        for item in self.aug_type:                                  # in the configured order (:1157-1173)
-            if item == 'norm':
-                x = pc_normalize(x)
-            elif item in ('scale', 'translate'):
-                x = apply_affine(x, *draw_affine(self.rng, B, lambda r, n='aug_' + item: [n]))
-            elif item in ('rotate_z', 'rotate'):
-                x = apply_affine(x, *draw_affine(self.rng, B, lambda r, n=item: [n]))
         B, P, _ = x.shape
-        clean = random_subset(x, self.npoints, generator=self.gen)
-        y, alive, touched = x, None, False
-        for item in self.corrupt_type:
-            if item in _PASS or 'dropout_global' in item:
-                continue                                            # applied in the model's forward
-            touched = True
+        dev, rng = x.device, self.rng
+        # ---- augment_data (:1155-1175), in the configured order: 'norm' and the affine augmentations.  'norm' is
+        # folded into the kernel when it comes first (the shipped configurations); otherwise it is its own pass
+        aug = [a for a in self.aug_type if a != 'clean']
+        norm_first = bool(aug) and aug[0] == 'norm'
+        maps = [[] for _ in range(B)]
+        for item in aug[1:] if norm_first else aug:
+            if item == 'norm':
+                x = pipeline_norm_affine(x, True, maps if any(maps) else None)
+                maps = [[] for _ in range(B)]
+                continue
+            name = 'aug_' + item if item in ('scale', 'translate') else item
+            for b in range(B):
+                maps[b].append(draw_affine_map(rng, name))
+        while max(len(m) for m in maps) > 3:                        # more than three augmentation maps: extra passes
+            x = pipeline_norm_affine(x, norm_first, [m[:3] for m in maps])
+            maps, norm_first = [m[3:] for m in maps], False
+        data = pipeline_norm_affine(x, norm_first, maps if any(maps) else None)
+        clean = pipeline_subset(data, P, self.npoints, torch.rand((B, P), device=dev, generator=self.gen))
+        # ---- corrupt_data (:1046-1096) on the whole cloud
+        items = [c for c in self.corrupt_type if not (c in _PASS or 'dropout_global' in c)]   # those run in the model's forward
+        if not items:
+            return clean, clean
+        n_add = int(P * 0.5) if any(c in ('add_global', 'add_local') for c in items) else 0   # level <= 4: at most +50 %
+        stride = P + n_add
+        maps = [[] for _ in range(B)]
+        sigma = noise = None
+        tail = []
+        for item in items:                                          # the affine maps and jitter of the list: one launch
             if item == 'affine_r3':
-                y = apply_affine(y, *draw_affine_r3(self.rng, B))
-            elif item in AFFINE or item == 'rotate_z':
-                y = apply_affine(y, *draw_affine(self.rng, B, lambda r, n=item: [n]))
-            elif item == 'scale':                                   # U(.5,2)^3 then re-normalised (:59-69)
-                y = pc_normalize(apply_affine(y, *draw_affine(self.rng, B, lambda r: ['scale_nonorm'])))
-            elif item == 'jitter':                                  # sigma = 0.01 (level + 1), level U(0,4) (:179-191)
-                sigma = torch.from_numpy((0.01 * (self.rng.uniform(0.0, 4.0, (B, 1, 1)) + 1.0)).astype(np.float32))
-                y = y + sigma.to(y.device) * torch.randn(y.shape, device=y.device, generator=self.gen)
-            elif item == 'add_global':                              # +50 % points uniform in the unit ball (:830-841, level 4)
-                extra = torch.from_numpy(sphere_points(self.rng, B, int(y.shape[1] * 0.5))).to(y.device)
-                y = torch.cat([y, extra], dim=1)
-                if alive is not None:
-                    alive = torch.cat([alive, torch.ones(extra.shape[:2], dtype=torch.bool, device=y.device)], dim=1)
-            elif item == 'add_local':                               # +50 % points in 1-7 Gaussian clusters around random
-                P2 = y.shape[1]                                     # points of the cloud (:844-870, level 4)
-                total = int(P2 * 0.5)
-                seeds = np.zeros((B, total), np.int64)              # per added point: which cloud point it sits on
-                sig = np.zeros((B, total, 1), np.float32)
                 for b in range(B):
-                    n = int(self.rng.integers(1, 8))
-                    counts = np.bincount(self.rng.integers(0, n, total), minlength=n)
-                    pts = self.rng.integers(0, P2, n)               # (the reference shuffles and takes the first n)
-                    seeds[b] = np.repeat(pts, counts)
-                    sig[b, :, 0] = np.repeat(self.rng.uniform(0.075, 0.125, n), counts)
-                centre = y.gather(1, torch.from_numpy(seeds).to(y.device).unsqueeze(-1).expand(B, total, 3))
-                extra = centre + torch.from_numpy(sig).to(y.device) * torch.randn((B, total, 3), device=y.device,
-                                                                                   generator=self.gen)
-                d2 = extra.square().sum(-1, keepdim=True)
-                extra = torch.where(d2 > 1, extra / d2, extra)      # pulled back inside the unit sphere as the reference
-                y = torch.cat([y, extra], dim=1)
-                if alive is not None:
-                    alive = torch.cat([alive, torch.ones((B, total), dtype=torch.bool, device=y.device)], dim=1)
-            elif item == 'nonuniform_density':                      # distance-gated drop from a random viewpoint (:875-897)
-                gate = torch.from_numpy((self.rng.uniform(0.0, 4.0, (B, 1)) / 4.0 + 0.1).astype(np.float32)).to(y.device)
-                v = self.rng.normal(0.0, 1.0, (B, 3))
-                v = torch.from_numpy((v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)).to(y.device)
-                dist = (y - v[:, None, :]).square().sum(-1).sqrt() / 2.0        # (d - (|v| - 1)) / 2 with |v| = 1
-                keep = dist * gate < torch.rand(dist.shape, device=y.device, generator=self.gen)
-                alive = keep if alive is None else (alive & keep)
+                    number = int(rng.integers(1, 4))
+                    for i in rng.choice(len(AFFINE), size=number, replace=False):
+                        maps[b].append(draw_affine_map(rng, AFFINE[int(i)]))
+            elif item in AFFINE or item == 'rotate_z':
+                for b in range(B):
+                    maps[b].append(draw_affine_map(rng, item))
+            elif item == 'jitter' and not tail:                     # sigma = 0.01 (level + 1), level in 0..4 (:1090-1092)
+                sigma = _dev((0.01 * (rng.integers(0, 5, B) + 1.0)).astype(np.float32), dev)
+                noise = torch.randn((B, P, 3), device=dev, generator=self.gen)
+            else:
+                tail.append(item)
+        if max(len(m) for m in maps) > 3:
+            raise NotImplementedError('more than three affine maps in one corrupt_type list')
+        y = pipeline_norm_affine(data[:, :P].contiguous() if stride != P else data, False, maps if any(maps) else None,
+                                 sigma, noise, stride) if (any(maps) or noise is not None or stride != P) else data
+        cur, alive = P, None                                        # rows in use; survivors
+        for item in tail:
+            if item in ('add_global', 'add_local') and (alive is not None or cur != P):
+                raise NotImplementedError('%s after a drop / another add in one corrupt_type list' % item)
+            if item == 'add_global':                                # int(P (level + 1) 0.1) ball points (:830-841)
+                count = (P * (rng.integers(0, 5, B) + 1) * 0.1).astype(np.int32)
+                pipeline_add_global(y, P, _dev(count, dev), torch.rand((B, n_add, 3), device=dev, generator=self.gen)
+                                    * torch.tensor([1.0, 2.0, 2.0 * math.pi], device=dev) - torch.tensor([0.0, 1.0, 0.0], device=dev))
+                cur, added = P + n_add, count
+            elif item == 'add_local':                               # 1-7 Gaussian clusters on random cloud points (:844-870)
+                count = (P * (rng.integers(0, 5, B) + 1) * 0.1).astype(np.int32)
+                seed = np.zeros((B, n_add), np.int32)
+                sig = np.zeros((B, n_add), np.float32)
+                for b in range(B):
+                    ncl = int(rng.integers(1, 8))
+                    sizes = np.bincount(rng.integers(0, ncl, int(count[b])), minlength=ncl)
+                    pts = rng.choice(P, ncl, replace=False)         # the first ncl points of a shuffle
+                    seed[b, :count[b]] = np.repeat(pts, sizes)
+                    sig[b, :count[b]] = np.repeat(rng.uniform(0.075, 0.125, ncl), sizes)
+                pipeline_add_local(y, P, _dev(count, dev), _dev(seed, dev), _dev(sig, dev),
+                                   torch.randn((B, n_add, 3), device=dev, generator=self.gen))
+                cur, added = P + n_add, count
+            elif item == 'nonuniform_density':                      # (:875-897) gate = level / 4 + 0.1, level in 0..4
+                if alive is None:
+                    alive = torch.ones((B, stride), dtype=torch.uint8, device=dev)
+                v = rng.normal(0.0, 1.0, (B, 3))
+                v = v / np.linalg.norm(v, axis=1, keepdims=True)
+                gate = rng.integers(0, 5, B) / 4.0 + 0.1
+                pipeline_density(y, cur, _dev(v.astype(np.float32), dev), _dev(gate.astype(np.float32), dev),
+                                 torch.rand((B, cur), device=dev, generator=self.gen), alive)
             elif item == 'dropout_local':
-                keep = dropout_local(y.contiguous(), *draw_dropout_local(self.rng, B, y.shape[1]))
+                if cur != P or stride != P:
+                    raise NotImplementedError('dropout_local after an add in one corrupt_type list')
+                keep = dropout_local(y, *draw_dropout_local(rng, B, P)).to(torch.uint8)
                 alive = keep if alive is None else (alive & keep)
-        corrupted = random_subset(y, self.npoints, alive, self.gen) if touched else clean
+            elif item == 'scale':                                   # U(.5,2)^3 then re-normalised (:59-69)
+                y = pipeline_norm_affine(pipeline_norm_affine(y, False, [[draw_affine_map(rng, 'scale_nonorm')] for _ in range(B)]), True)
+            else:
+                raise NotImplementedError(item)
+        if cur != P:                                                # rows behind P + added[b] are not part of cloud b
+            if alive is None:
+                alive = torch.ones((B, stride), dtype=torch.uint8, device=dev)
+            alive &= (torch.arange(stride, device=dev).view(1, -1) < (P + _dev(added, dev)).view(-1, 1)).to(torch.uint8)
+        corrupted = pipeline_subset(y, cur, self.npoints, torch.rand((B, stride), device=dev, generator=self.gen), alive)
         return corrupted, clean
 
     def __iter__(self):

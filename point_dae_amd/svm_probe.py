@@ -39,8 +39,9 @@ def extract_features(base_model, loader, npoints):
     feats, labels = [], []
     for _, _, data in loader:
         points, label = data[0].cuda(), data[1].cuda()
-        if points.shape[1] != npoints:
-            _, points = misc.fps(points, npoints)
+        # ALWAYS resampled (runner_pretrain.py:305,318): with npoints == N the FPS still re-ORDERS the cloud (sample
+        # order, starting from point 0), which moves the model's own FPS centres -- skipping it changes the features
+        _, points = misc.fps(points, npoints)
         assert points.shape[1] == npoints
         feats.append(base_model(points, points, vis=False, return_feat=True).detach())
         labels.append(label.view(-1).detach())

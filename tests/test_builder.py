@@ -82,3 +82,102 @@ def test_build_opti_sche_reads_the_reference_yaml(tmp_path):
     # the two AdamW groups of builder.py:41-98: 1-D tensors and biases without weight decay
     wd = {g['weight_decay']: sum(p.numel() for p in g['params']) for g in opt.param_groups}
     assert wd == {0.0: 4 + 4 + 4, config.optimizer.kwargs.weight_decay: 16}
+
+
+# ---- checkpoints against the LIVE reference's own writer (tests/golden/make_ckpt_fixtures.py) -------------------
+import json   # noqa: E402
+import os     # noqa: E402
+import sys    # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+LAYOUT = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ckpt_layout.json')))
+
+
+def _published_model(seed=5):
+    from weights import fill_state
+    from point_dae_amd.config import cfg_from_yaml_file
+    config = cfg_from_yaml_file(os.path.join(
+        ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.NAME = 'PointCAE_transformer_fc_global_folding_local'
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    torch.manual_seed(0)
+    return fill_state(builder.model_builder(config.model), seed), config
+
+
+def _checksum(t):
+    t = t.detach().double().reshape(-1)
+    return [float(t.sum()), float(t.abs().sum())]
+
+
+def test_state_dict_is_the_reference_checkpoint_layout():
+    """Every key the live reference's save_checkpoint wrote for this model (with nn.DataParallel's `module.` prefix,
+    runner_pretrain.py:86-88) exists here with the same shape, dtype and -- filled by tests/golden/weights.py from
+    (seed, key) -- the same checksum; nothing is missing, nothing is extra."""
+    net, _ = _published_model()
+    mine = net.state_dict()
+    ref = {k[len('module.'):]: v for k, v in LAYOUT['base_model'].items()}
+    assert all(k.startswith('module.') for k in LAYOUT['base_model'])
+    assert sorted(mine) == sorted(ref)
+    for k, rec in ref.items():
+        assert list(mine[k].shape) == rec['shape'] and str(mine[k].dtype) == 'torch.' + rec['dtype'], k
+        assert _checksum(mine[k]) == rec['checksum'], k
+
+
+def test_reads_a_reference_written_checkpoint(tmp_path):
+    """load_model / resume_model / load_pretrained_encoder on a file with the live reference's layout: top-level keys,
+    `module.`-prefixed weights, dict-valued metric records, torch.optim.AdamW state (tools/builder.py:155-227)."""
+    net, config = _published_model()
+    opt_state = {'state': {}, 'param_groups': [dict(g, params=list(range(i * 47, i * 47 + g['params'])))
+                                               for i, g in enumerate(LAYOUT['optimizer']['param_groups'])]}
+    ckpt = {'base_model': {'module.' + k: v.clone() for k, v in net.state_dict().items()}, 'optimizer': opt_state,
+            'epoch': LAYOUT['epoch'], 'metrics': LAYOUT['metrics'], 'best_metrics': LAYOUT['best_metrics']}
+    assert sorted(ckpt) == LAYOUT['top_level_keys'] and sorted(ckpt['base_model']) == sorted(LAYOUT['base_model'])
+    torch.save(ckpt, tmp_path / 'ckpt-last.pth')
+
+    class Args:
+        experiment_path, local_rank = str(tmp_path), 0
+    fresh, _ = _published_model(seed=9)
+    epoch, best = builder.resume_model(fresh, Args)
+    assert [epoch, {'acc': best}] == LAYOUT['resume_model_returns']       # what the reference's resume_model returned
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), net.state_dict().values()))
+    fresh2, _ = _published_model(seed=9)
+    assert builder.load_model(fresh2, str(tmp_path / 'ckpt-last.pth')) == LAYOUT['epoch']
+    assert torch.equal(fresh2.mask_token, net.mask_token)
+    # the downstream remap (models/Point_MAE.py:643-656): MAE_encoder.* becomes the backbone
+    from point_dae_amd.point_cae_transformer import MaskTransformer
+    backbone = MaskTransformer(config.model)
+    rec = builder.load_pretrained_encoder(backbone, str(tmp_path / 'ckpt-last.pth'))
+    assert not rec.missing_keys
+    assert torch.equal(backbone.encoder.first_conv[0].weight, net.MAE_encoder.encoder.first_conv[0].weight)
+
+
+def test_writes_the_reference_checkpoint_layout(tmp_path):
+    """save_checkpoint (builder.py:191-200): same top-level keys, metric records as dicts, torch.optim.AdamW layout
+    with the reference's two groups (no-decay first) holding the same parameter NAMES in the same order."""
+    from point_dae_amd.svm_probe import Acc_Metric
+    net, config = _published_model()
+    opt, _ = builder.build_opti_sche(net, config)
+    out = net.coarse_pred[0].weight.sum() + sum(p.sum() for p in net.parameters()) * 0
+    out.backward()
+    opt.step()
+
+    class Args:
+        experiment_path, local_rank = str(tmp_path), 0
+    builder.save_checkpoint(net, opt, 41, Acc_Metric(0.8125), Acc_Metric(0.875), 'ckpt-last', Args)
+    sd = torch.load(tmp_path / 'ckpt-last.pth', map_location='cpu')
+    assert sorted(sd) == LAYOUT['top_level_keys']
+    assert sd['epoch'] == LAYOUT['epoch'] and sd['metrics'] == LAYOUT['metrics'] and sd['best_metrics'] == LAYOUT['best_metrics']
+    assert sorted('module.' + k for k in sd['base_model']) == sorted(LAYOUT['base_model'])
+    ref_groups = LAYOUT['optimizer']['param_groups']
+    assert [len(g['params']) for g in sd['optimizer']['param_groups']] == [g['params'] for g in ref_groups]
+    for g, r in zip(sd['optimizer']['param_groups'], ref_groups):
+        for key in ('lr', 'weight_decay', 'eps', 'amsgrad'):
+            assert g[key] == r[key], key
+        assert list(g['betas']) == r['betas']
+    names = {id(p): n for n, p in net.named_parameters()}
+    mine = [['module.' + names[id(p)] for p in g['params']] for g in opt.param_groups]
+    assert mine == LAYOUT['optimizer']['group_names']
+    assert sorted({k for st in sd['optimizer']['state'].values() for k in st}) == LAYOUT['optimizer']['state_keys']
+    assert len(sd['optimizer']['state']) == LAYOUT['optimizer']['state_entries']

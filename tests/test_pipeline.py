@@ -116,7 +116,8 @@ def test_device_dataset_end_to_end(tmp_path):
 @pytest.mark.parametrize('aug,cor', [(['norm', 'scale', 'translate'], ['clean']), (['norm'], ['affine_r3', 'jitter']),
                                      (['norm', 'rotate'], ['dropout_local']), (['norm'], ['add_global']),
                                      (['norm', 'rotate_z'], ['nonuniform_density']), (['norm'], ['shear']),
-                                     (['norm'], ['scale']), (['norm'], ['add_global', 'dropout_local']), (['norm'], ['add_local'])])
+                                     (['norm'], ['scale']), (['norm', 'translate', 'scale'], ['affine_r3', 'dropout_local']), (['norm'], ['add_local']),
+                                     (['norm'], ['affine_r3', 'add_local']), (['norm'], ['rotate', 'nonuniform_density'])])
 def test_device_dataset_augmentations_and_corruptions(aug, cor):
     """every loader-side augmentation / corruption the device pipeline implements (the reference's pretrain YAMLs
     use these names: aug ['norm','scale','translate'] in 25 of them) -> finite (B, npoints, 3) batches with the
@@ -143,3 +144,174 @@ def test_device_dataset_augmentations_and_corruptions(aug, cor):
             assert (corrupted.norm(dim=-1).amax(dim=1) <= 1 + 1e-5).all()       # re-normalised (corrupt_scale)
         if cor == ['add_global']:
             assert (corrupted.norm(dim=-1) <= 1 + 1e-5).all()
+
+
+@pytest.mark.gpu
+def test_device_dataset_refuses_orders_it_does_not_implement():
+    """a drop in front of an add (or two adds) would need a compaction pass between them: no shipped configuration of
+    the reference lists one; the loader raises instead of silently running something else"""
+    from point_dae_amd.datasets import ShapeNet
+    ds = ShapeNet({'npoints': 256, 'N_POINTS': 1024, 'bs': 2, 'steps_per_epoch': 1, 'device': 'cuda',
+                   'aug_type': ['norm'], 'corrupt_type': ['dropout_local', 'add_global']})
+    with pytest.raises(NotImplementedError):
+        next(iter(ds))
+
+
+# ---- the whole loader item against the LIVE reference's ShapeNet.__getitem__ (tests/golden/make_loader_fixtures.py) ----
+LOADER_CONFIGS = {
+    'affine_r3': ['affine_r3'], 'jitter': ['jitter'], 'affine_r3_jitter': ['affine_r3', 'jitter'],
+    'add_global': ['add_global'], 'add_local': ['add_local'], 'nonuniform_density': ['nonuniform_density'],
+    'affine_r3_dropout_local': ['affine_r3', 'dropout_local'],
+}
+NPTS = 1024
+
+
+def _loader_fixture():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'loader_pipeline_ref.npz'))
+
+
+def _rec(fx, tag, b):
+    pre = '%s/%d/' % (tag, b)
+    return {k[len(pre):]: fx[k] for k in fx.files if k.startswith(pre)}
+
+
+def _maps_of(rec):
+    return [(m[:9].reshape(3, 3), m[9:]) for m in rec['maps']] if 'maps' in rec else []
+
+
+@pytest.mark.parametrize('tag', sorted(LOADER_CONFIGS))
+def test_loader_oracle_reproduces_live_reference_items(tag, oracle_ops):
+    """oracle/pipeline.py fed with the recorded draws == what the reference's data set class returned."""
+    from oracle import pipeline as OP
+    fx = _loader_fixture()
+    for b in range(fx['clouds'].shape[0]):
+        rec = _rec(fx, tag, b)
+        data = OP.pc_normalize(fx['clouds'][b]).astype(np.float32)
+        assert np.array_equal(data[rec['select_clean']], rec['clean'])
+        pc = data
+        for M, t in _maps_of(rec):
+            pc = np.dot(pc, M) + t
+        if 'jitter_noise' in rec:
+            pc = OP.jitter(pc, int(rec['jitter_level']), rec['jitter_noise'])
+        if 'ball_u' in rec:
+            u = rec['ball_u'].astype(np.float64)
+            pc = OP.add_global(pc, int(rec['add_level']), u[:, 0:1], u[:, 1:2], u[:, 2:3])
+        if 'local_order' in rec:
+            full = OP.add_local(pc, int(rec['add_level']), rec['local_order'], rec['local_sizes'], rec['local_sigmas'],
+                                rec['local_noise'])
+            pc = np.concatenate([pc, full[pc.shape[0]:]])                       # device order: original rows, then the added
+        if 'density_v' in rec:
+            keep = OP.density_keep(pc, int(rec['density_level']), rec['density_v'], rec['density_r'])
+            assert (keep != rec['density_keep']).sum() == 0
+        if 'dl_nclusters' in rec:
+            alive = oracle_ops.dropout_local(rec['dl_input'][None], rec['dl_nclusters'], rec['dl_rank'], rec['dl_sizes'])[0]
+            assert np.array_equal(alive.astype(bool), rec['dl_alive'])
+            assert np.abs(pc - rec['dl_input']).max() <= 2e-6
+        got = pc[rec['select']].astype(np.float32)
+        assert np.abs(got - rec['corrupted']).max() <= 2e-6, (tag, b)
+
+
+def _keys_for(select, stride, device):
+    import torch
+    assert len(np.unique(select)) == len(select)
+    keys = np.full(stride, 1e9, np.float32)
+    keys[select] = np.arange(len(select), dtype=np.float32)
+    return torch.from_numpy(keys).to(device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', sorted(LOADER_CONFIGS))
+def test_hip_loader_stages_reproduce_live_reference_items(tag):
+    """csrc/pipeline.hip on the recorded draws == the reference's items: norm + affine maps + jitter, add_global,
+    add_local, nonuniform_density, dropout_local, and the sub-sampling (keys = the recorded permutation)."""
+    import torch
+    from point_dae_amd import datasets as D
+    fx = _loader_fixture()
+    clouds = torch.from_numpy(fx['clouds']).cuda()
+    B, P, _ = clouds.shape
+    recs = [_rec(fx, tag, b) for b in range(B)]
+    dev = clouds.device
+    data = D.pipeline_norm_affine(clouds, True)
+    keys = torch.stack([_keys_for(r['select_clean'], P, dev) for r in recs])
+    clean = D.pipeline_subset(data, P, NPTS, keys)
+    want = np.stack([r['clean'] for r in recs])
+    assert np.abs(clean.cpu().numpy() - want).max() <= 3e-6
+    n_add = max([int(r['corrupted'].shape[0] * 0) + (len(r['ball_u']) if 'ball_u' in r else 0) for r in recs] +
+                [len(r['local_noise']) if 'local_noise' in r else 0 for r in recs])
+    stride = P + n_add
+    sigma = noise = None
+    if 'jitter_noise' in recs[0]:
+        sigma = torch.tensor([0.01 * (int(r['jitter_level']) + 1) for r in recs], dtype=torch.float32, device=dev)
+        noise = torch.from_numpy(np.stack([r['jitter_noise'] for r in recs])).cuda()
+    y = D.pipeline_norm_affine(data, False, [_maps_of(r) for r in recs], sigma, noise, stride)
+    alive, cur = None, P
+    if 'ball_u' in recs[0]:
+        u = np.zeros((B, n_add, 3), np.float32)
+        count = np.zeros(B, np.int32)
+        for b, r in enumerate(recs):
+            count[b] = int(P * (int(r['add_level']) + 1) * 0.1)
+            u[b, :len(r['ball_u'])] = r['ball_u']
+        D.pipeline_add_global(y, P, torch.from_numpy(count).cuda(), torch.from_numpy(u).cuda())
+        cur = stride
+    if 'local_order' in recs[0]:
+        seed, sig = np.zeros((B, n_add), np.int32), np.zeros((B, n_add), np.float32)
+        nz, count = np.zeros((B, n_add, 3), np.float32), np.zeros(B, np.int32)
+        for b, r in enumerate(recs):
+            sizes = r['local_sizes']
+            count[b] = sizes.sum()
+            seed[b, :count[b]] = np.repeat(r['local_order'][:len(sizes)], sizes)      # cluster i sits on shuffled row i
+            sig[b, :count[b]] = np.repeat(r['local_sigmas'], sizes)
+            nz[b, :count[b]] = r['local_noise']
+        D.pipeline_add_local(y, P, torch.from_numpy(count).cuda(), torch.from_numpy(seed).cuda(),
+                             torch.from_numpy(sig).cuda(), torch.from_numpy(nz).cuda())
+        cur = stride
+    if 'density_v' in recs[0]:
+        v = np.stack([r['density_v'] / np.linalg.norm(r['density_v']) for r in recs]).astype(np.float32)
+        gate = np.array([int(r['density_level']) / 4.0 + 0.1 for r in recs], np.float32)
+        alive = torch.ones((B, stride), dtype=torch.uint8, device=dev)
+        D.pipeline_density(y, P, torch.from_numpy(v).cuda(), torch.from_numpy(gate).cuda(),
+                           torch.from_numpy(np.stack([r['density_r'] for r in recs])).cuda(), alive)
+        got = alive.cpu().numpy().astype(bool)
+        assert np.array_equal(got, np.stack([r['density_keep'] for r in recs]))
+    if 'dl_nclusters' in recs[0]:
+        # the affine stage within tolerance of the reference's fp64 chain ...
+        assert np.abs(y.cpu().numpy() - np.stack([r['dl_input'] for r in recs])).max() <= 5e-6
+        # ... and the drop bit-exact on the reference's own fp32 cloud
+        x = torch.from_numpy(np.stack([r['dl_input'] for r in recs])).cuda()
+        keep = D.dropout_local(x, np.concatenate([r['dl_nclusters'] for r in recs]),
+                               np.concatenate([r['dl_rank'] for r in recs]), np.concatenate([r['dl_sizes'] for r in recs]))
+        assert np.array_equal(keep.cpu().numpy(), np.stack([r['dl_alive'] for r in recs]))
+        alive = keep.to(torch.uint8)
+    keys = torch.stack([_keys_for(r['select'], stride, dev) for r in recs])
+    out = D.pipeline_subset(y, cur, NPTS, keys, alive)
+    want = np.stack([r['corrupted'] for r in recs])
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5, np.abs(out.cpu().numpy() - want).max()
+
+
+@pytest.mark.gpu
+def test_hip_subset_edge_cases():
+    """random keys: a uniformly random subset in random order; ties by index; fewer survivors than n: cyclic refill."""
+    import torch
+    from point_dae_amd import datasets as D
+    g = torch.Generator(device='cuda').manual_seed(0)
+    B, P, n = 3, 1500, 256
+    y = torch.randn((B, P, 3), device='cuda', generator=g)
+    keys = torch.rand((B, P), device='cuda', generator=g)
+    alive = (torch.rand((B, P), device='cuda', generator=g) < 0.7).to(torch.uint8)
+    out = D.pipeline_subset(y, P, n, keys, alive)
+    for b in range(B):
+        k = keys[b].clone()
+        k[alive[b] == 0] = 9.0
+        order = torch.argsort(k, stable=True)[:n]
+        assert torch.equal(out[b], y[b, order])
+    keys0 = torch.zeros((B, P), device='cuda')                       # all ties: index order
+    out = D.pipeline_subset(y, P, n, keys0)
+    assert torch.equal(out, y[:, :n])
+    few = torch.zeros((B, P), dtype=torch.uint8, device='cuda')
+    few[:, 10:15] = 1                                                # 5 survivors, n = 12
+    out = D.pipeline_subset(y, P, 12, keys, few)
+    for b in range(B):
+        order = 10 + torch.argsort(keys[b, 10:15])
+        assert torch.equal(out[b], y[b, order[torch.arange(12, device='cuda') % 5]])
+    none = torch.zeros((B, P), dtype=torch.uint8, device='cuda')
+    assert D.pipeline_subset(y, P, 8, keys, none).abs().max().item() == 0.0
