@@ -493,8 +493,14 @@ def main():
         nn_ops.set_probe(probe)
         model.require_sync = False            # rank-0-only steps: no collective (the other ranks are not in them)
         for i in range(args.probe_steps):       # forward + backward only: the replicas' parameters stay in step
-            lx, ln = model(batches[i % pool], batches[i % pool])
-            (lx + float(config.normal_weight) * ln.sum()).backward()
+            if isinstance(step, GraphedTrainStep):
+                # the graphed step's own body (gradient sink armed, the stacks' grouped weight gradients), launched
+                # kernel by kernel: what the replays run
+                step.pts.copy_(batches[i % pool])
+                step._fwd_bwd(step._draw())
+            else:
+                lx, ln = model(batches[i % pool], batches[i % pool])
+                (lx + float(config.normal_weight) * ln.sum()).backward()
             model.zero_grad()
         model.require_sync = True
         torch.cuda.synchronize()

@@ -257,6 +257,16 @@ int pdae_chamfer_backward(int b, int n, const float* xyz1, int m,
                           const int32_t* idx2, const float* grad_dist1,
                           const float* grad_dist2, float* grad_xyz1,
                           float* grad_xyz2, pdae_stream_t stream);
+/* ChamferDistanceL2 (extensions/chamfer_dist/__init__.py:29-44: `torch.mean(dist1) + torch.mean(dist2)`) without the
+ * reduction / expand / divide launches around the two kernels: mean_sum2 writes mean(a) + mean(b) into out[0] (two
+ * small launches, fixed summation order);
+ * chamfer_backward_mean is chamfer.backward for grad_dist1 = grad_loss[0] / (b n), grad_dist2 = grad_loss[0] / (b m)
+ * (what autograd's mean backward would materialise), grad_loss a DEVICE scalar. */
+int pdae_mean_sum2(long long na, const float* a, long long nb, const float* b, float* workspace /* 256 floats */,
+                   float* out, pdae_stream_t stream);
+int pdae_chamfer_backward_mean(int b, int n, const float* xyz1, int m, const float* xyz2, const int32_t* idx1,
+                               const int32_t* idx2, const float* grad_loss, float* grad_xyz1, float* grad_xyz2,
+                               pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Approximate earth mover's distance.  Replaces ApproxMatchForward /
@@ -444,6 +454,14 @@ int pdae_rows_wgrad(int M, int nprob, const float* const* dY,
                     const float* const* X, float* const* dW,
                     float* const* db /*nullable*/, const int* Ns, const int* Ks,
                     float* workspace, pdae_stream_t stream);
+/* The same with a row count PER layer: the weight gradients of layers that do not share their rows -- every Linear of
+ * every Transformer block of a stack -- in ONE launch (nprob <= 48): work = (128 x 128 output tile, 32-row chunk) units
+ * of all layers in one list, dealt in equal contiguous ranges to one residency of the chip, partial tiles added in
+ * block order by the reduction launch that follows.  A step's backward thereby issues its blocks' weight gradients as
+ * two large launches (decoder stack, encoder stack) instead of one small launch per block. */
+int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats);
+int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X, float* const* dW,
+                          float* const* db, const int* Ns, const int* Ks, float* workspace, pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused layers of the patch embedder, Encoder.forward
@@ -638,6 +656,15 @@ int pdae_scale_residual(int M, int C, int T, const float* a,
                         const float* keep /*nullable*/,
                         const float* res /*nullable*/, float* y,
                         pdae_stream_t stream);
+/* Two small fused launches in place of chains of framework elementwise kernels inside the step:
+ * drop_path_keep: timm 0.4.5 DropPath (models/PointCAE_transformer.py:146-158 `self.drop_path`) for all `sites`
+ *   stochastic-depth sites of a stack: r (sites, B) uniforms -> floor(r + keep[s]) / keep[s] (in place allowed).
+ * pos_embed_fc1: the first layer of pos_embed / decoder_pos_embed (:329-333, :636-640: Linear(3,128) -> GELU) on the
+ *   centre rows `rows` (int64 indices into xyz (.,3); NULL = all rows in order): h = GELU(z), gp = GELU'(z) for
+ *   z = xyz . W1^T + b1, and xp (M,4) = the gathered rows zero-padded (the backward's weight-gradient operand). */
+int pdae_drop_path_keep(int sites, int B, const float* r, const float* keep, float* out, pdae_stream_t stream);
+int pdae_pos_embed_fc1(int M, int H, const float* xyz, const int64_t* rows, const float* w1, const float* b1, float* h,
+                       float* gp, float* xp, pdae_stream_t stream);
 int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
                 pdae_stream_t stream);
 /*   scale_colsum        Y = keep[row/T] * X and out[c] (nullable) = column sums

@@ -39,12 +39,15 @@ _SIGNATURES = {
     "pdae_patch_affine": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_chamfer_backward_mean": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_mean_sum2": [ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "pdae_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "pdae_linear_backward_data": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_linear_backward_weight": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_gemm": [_i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "pdae_rows_gemm_batched": [_i, _i, _i, _i, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp],
     "pdae_rows_wgrad": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_rows_wgrad_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -63,6 +66,8 @@ _SIGNATURES = {
     "pdae_gelu_backward": [ctypes.c_longlong, _vp, _vp, _vp, _vp],
     "pdae_scale_residual": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_colsum": [_i, _i, _vp, _vp, _i, _vp],
+    "pdae_drop_path_keep": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdae_pos_embed_fc1": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_residual_layernorm_forward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "pdae_scale_colsum": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
@@ -91,6 +96,7 @@ _SIGNATURES = {
 _HOST = {
     "pdae_rows_gemm_plan": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_rows_wgrad_workspace": [_i, _i, _vp, _vp, _vp],
+    "pdae_rows_wgrad_multi_workspace": [_i, _vp, _vp, _vp, _vp],
     "pdae_set_deterministic": [_vp, ctypes.c_size_t],
     "pdae_deferred_begin": [_vp, ctypes.c_size_t],
     "pdae_deferred_hold": [_i],
@@ -274,17 +280,34 @@ def rows_wgrad_workspace(M, Ns, Ks):
 
 
 def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace, may_defer=False):
-    """pdae_rows_wgrad over lists of tensors (dbs entries may be None).  may_defer: the caller hands the results
-    to autograd without reading them, so inside a deferred window the reduction may be parked until the flush."""
-    parked = _def_keep is not None and may_defer
-    if _def_keep is not None and not may_defer:
-        lib().pdae_deferred_hold(1)
+    """pdae_rows_wgrad over lists of tensors (dbs entries may be None)."""
     n = len(dYs)
     parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
     call('pdae_rows_wgrad', on, M, n, parr(*[ptr(t) for t in dYs]), parr(*[ptr(t) for t in Xs]),
          parr(*[ptr(t) for t in dWs]), parr(*[ptr(t) for t in dbs]),
          iarr(*[t.shape[1] for t in dYs]), iarr(*[t.shape[1] for t in Xs]), ptr(workspace))
-    if parked:                           # the reduction is parked until deferred_flush: so is the workspace
-        _def_keep.append(workspace)
-    elif _def_keep is not None:
-        lib().pdae_deferred_hold(0)
+
+
+WGRAD_MULTI_MAX = 48
+
+
+def rows_wgrad_multi(jobs):
+    """pdae_rows_wgrad_multi: jobs = [(dY (M,N), X (M,K), dW (N,K), db (N,) or None)], every layer with its own row
+    count, at most WGRAD_MULTI_MAX per launch (longer lists are cut).  The workspace is allocated here."""
+    for i in range(0, len(jobs), WGRAD_MULTI_MAX):
+        part = jobs[i:i + WGRAD_MULTI_MAX]
+        n = len(part)
+        parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
+        Ms, Ns, Ks = (iarr(*v) for v in ([j[0].shape[0] for j in part], [j[0].shape[1] for j in part],
+                                        [j[1].shape[1] for j in part]))
+        key = ('multi', tuple(Ms), tuple(Ns), tuple(Ks))
+        floats = _wg_cache.get(key)
+        if floats is None:
+            f = ctypes.c_longlong(0)
+            handle = lib()
+            _check(handle, 'pdae_rows_wgrad_multi_workspace', handle.pdae_rows_wgrad_multi_workspace(n, Ms, Ns, Ks, ctypes.byref(f)))
+            floats = _wg_cache[key] = f.value
+        on = part[0][0]
+        ws = torch.empty(max(floats, 1), device=on.device, dtype=torch.float32)
+        call('pdae_rows_wgrad_multi', on, n, Ms, parr(*[ptr(j[0]) for j in part]), parr(*[ptr(j[1]) for j in part]),
+             parr(*[ptr(j[2]) for j in part]), parr(*[ptr(j[3]) for j in part]), Ns, Ks, ptr(ws))

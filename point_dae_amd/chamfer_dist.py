@@ -52,11 +52,18 @@ class ChamferFunction(torch.autograd.Function):
         dist1, dist2, idx1, idx2 = forward(xyz1, xyz2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
+        ctx.set_materialize_grads(False)      # no zero-filled gradients for the two index outputs (2 fills per step)
         return dist1, dist2, idx1, idx2
 
     @staticmethod
     def backward(ctx, grad_dist1, grad_dist2, grad_idx1=None, grad_idx2=None):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        if grad_dist1 is None and grad_dist2 is None:
+            return None, None
+        if grad_dist1 is None:
+            grad_dist1 = torch.zeros(idx1.shape, dtype=xyz1.dtype, device=xyz1.device)
+        if grad_dist2 is None:
+            grad_dist2 = torch.zeros(idx2.shape, dtype=xyz2.dtype, device=xyz2.device)
         g1, g2 = backward(xyz1, xyz2, idx1, idx2, grad_dist1.contiguous(),
                           grad_dist2.contiguous())
         return g1, g2
@@ -69,6 +76,31 @@ def _drop_zero_points(xyz1, xyz2):
     return xyz1[nz1].unsqueeze(dim=0), xyz2[nz2].unsqueeze(dim=0)
 
 
+class _ChamferL2Loss(torch.autograd.Function):
+    """mean(dist1) + mean(dist2) as ONE node: the two Chamfer launches + one reduction launch forward, the two
+    gradient launches backward (the gradient of a mean is a constant: no expand / divide / fill launches)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+        dist1, dist2, idx1, idx2 = forward(xyz1, xyz2)
+        ws = torch.empty(257, dtype=torch.float32, device=xyz1.device)        # 256 partials + the result
+        out = ws[256].reshape(())
+        _lib.call("pdae_mean_sum2", xyz1, dist1.numel(), _lib.ptr(dist1), dist2.numel(), _lib.ptr(dist2), _lib.ptr(ws),
+                  _lib.ptr(out))
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        g1, g2 = torch.empty_like(xyz1), torch.empty_like(xyz2)
+        _lib.call("pdae_chamfer_backward_mean", xyz1, B, n, _lib.ptr(xyz1), xyz2.shape[1], _lib.ptr(xyz2), _lib.ptr(idx1),
+                  _lib.ptr(idx2), _lib.ptr(g.contiguous()), _lib.ptr(g1), _lib.ptr(g2))
+        return g1, g2
+
+
 class ChamferDistanceL2(torch.nn.Module):
     """mean(dist1) + mean(dist2)"""
 
@@ -79,8 +111,13 @@ class ChamferDistanceL2(torch.nn.Module):
     def forward(self, xyz1, xyz2):
         if xyz1.size(0) == 1 and self.ignore_zeros:
             xyz1, xyz2 = _drop_zero_points(xyz1, xyz2)
-        dist1, dist2, _, _ = ChamferFunction.apply(xyz1, xyz2)
-        return torch.mean(dist1) + torch.mean(dist2)
+        _lib.require(xyz1, "xyz1", torch.float32) if xyz1.is_contiguous() else None
+        if not xyz1.is_cuda:
+            raise RuntimeError("xyz1 must be a tensor on the GPU (CPU not supported)")
+        if xyz1.numel() == 0 or xyz2.numel() == 0:
+            dist1, dist2, _, _ = ChamferFunction.apply(xyz1, xyz2)
+            return torch.mean(dist1) + torch.mean(dist2)
+        return _ChamferL2Loss.apply(xyz1, xyz2)
 
 
 class ChamferDistanceL2_split(torch.nn.Module):

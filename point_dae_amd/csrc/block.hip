@@ -603,3 +603,70 @@ extern "C" int pdae_scale_colsum(int M, int N, int T, const float* X, const floa
   if (det) return det_reduce(s, P, N, det, out, N);
   return check_launch("scale_colsum");
 }
+
+
+// ---- small fused launches that replace chains of framework elementwise kernels inside the step -----------------
+namespace pdae {
+
+// timm 0.4.5 DropPath for all stochastic-depth sites of a stack at once: r (S, B) uniforms in, per-sample factors
+// floor(r + keep_s) / keep_s out (in place allowed) -- the reference's `x.div(keep) * (keep + rand).floor_()`.
+__global__ __launch_bounds__(256) void drop_path_keep_kernel(int n, int B, const float* __restrict__ r,
+                                                             const float* __restrict__ keep, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float k = keep[i / B];
+  out[i] = floorf(r[i] + k) / k;
+}
+
+// First layer of pos_embed (models/PointCAE_transformer.py:329-333: Linear(3,128) -> GELU) on gathered centre rows:
+// z = xyz[rows[m]] . W1^T + b1 with K = 3 as an fma chain in k order (what the row GEMM computes on the zero-padded
+// operands), h = GELU(z), gp = GELU'(z); also leaves the gathered rows zero-padded to 4 columns for the weight-gradient
+// GEMM of the backward.  One thread per (row, 4 channels).
+__global__ __launch_bounds__(256) void pos_embed_fc1_kernel(int M, int H, const float* __restrict__ xyz,
+                                                            const long long* __restrict__ rows,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            float* __restrict__ h, float* __restrict__ gp,
+                                                            float* __restrict__ xp) {
+  const int q = H / 4;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)M * q) return;
+  const int m = (int)(i / q), c = (int)(i % q) * 4;
+  const long long src = rows ? rows[m] : m;
+  const float x0 = xyz[src * 3 + 0], x1 = xyz[src * 3 + 1], x2 = xyz[src * 3 + 2];
+  if (c == 0) *reinterpret_cast<float4*>(xp + (size_t)m * 4) = make_float4(x0, x1, x2, 0.f);
+  float hv[4], gv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float* w = w1 + (size_t)(c + e) * 3;
+    const float z = fmaf(x2, w[2], fmaf(x1, w[1], x0 * w[0])) + b1[c + e];
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+    hv[e] = z * cdf, gv[e] = cdf + z * pdf;
+  }
+  *reinterpret_cast<float4*>(h + (size_t)m * H + c) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+  *reinterpret_cast<float4*>(gp + (size_t)m * H + c) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+}
+
+}  // namespace pdae
+
+extern "C" int pdae_drop_path_keep(int sites, int B, const float* r, const float* keep, float* out, pdae_stream_t stream) {
+  using namespace pdae;
+  if (sites < 0 || B < 0) return bad_arg("drop_path_keep: negative size");
+  if (sites == 0 || B == 0) return PDAE_OK;
+  if (!r || !keep || !out) return bad_arg("drop_path_keep: null pointer");
+  const int n = sites * B;
+  hipLaunchKernelGGL(drop_path_keep_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), n, B, r, keep, out);
+  return check_launch("drop_path_keep");
+}
+
+extern "C" int pdae_pos_embed_fc1(int M, int H, const float* xyz, const int64_t* rows, const float* w1, const float* b1,
+                                  float* h, float* gp, float* xp, pdae_stream_t stream) {
+  using namespace pdae;
+  if (M < 0 || H <= 0 || H % 4 != 0) return bad_arg("pos_embed_fc1: M >= 0, H a positive multiple of 4 required");
+  if (M == 0) return PDAE_OK;
+  if (!xyz || !w1 || !b1 || !h || !gp || !xp) return bad_arg("pos_embed_fc1: null pointer");
+  const long long n = (long long)M * (H / 4);
+  hipLaunchKernelGGL(pos_embed_fc1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), M, H, xyz,
+                     reinterpret_cast<const long long*>(rows), w1, b1, h, gp, xp);
+  return check_launch("pos_embed_fc1");
+}

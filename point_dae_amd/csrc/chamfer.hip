@@ -143,7 +143,9 @@ __global__ __launch_bounds__(kPackT) void chamfer_bwd_packed(
     int b, int n, int m, const float* __restrict__ xa, const float* __restrict__ xb,
     const int32_t* __restrict__ idx_a, const int32_t* __restrict__ idx_b,
     const float* __restrict__ g_a, const float* __restrict__ g_b, float* __restrict__ grad_a,
-    int own_first) {
+    int own_first, int gs, float gdiv_a, float gdiv_b) {
+  // gs / gdiv: the distance gradients are g_a[r * gs] / gdiv_a -- gs 1, gdiv 1: the arrays as given; gs 0: ONE device
+  // scalar divided by the element count, i.e. the backward of a mean without materialising its expand / div
   extern __shared__ float4 other[];  // per candidate: (x, y, z, 2*g) of cloud b
   const long long total = (long long)b * n;
   const long long r0 = (long long)blockIdx.x * kPackT;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kPackT) void chamfer_bwd_packed(
   const size_t base = (size_t)c0 * m;
   for (int i = threadIdx.x; i < ncand; i += kPackT) {
     other[i] = make_float4(xb[(base + i) * 3 + 0], xb[(base + i) * 3 + 1],
-                           xb[(base + i) * 3 + 2], g_b[base + i] * 2);
+                           xb[(base + i) * 3 + 2], (g_b[(base + i) * gs] / gdiv_b) * 2);
     other_idx[i] = idx_b[base + i];
   }
   __syncthreads();
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kPackT) void chamfer_bwd_packed(
   const int* oi = other_idx + (c - c0) * m;
   // own term: g (a_j - b_{idx_a[j]}), chamfer.cu:192-195
   const int j2 = idx_a[r];
-  const float g = g_a[r] * 2;
+  const float g = (g_a[r * gs] / gdiv_a) * 2;
   const float ox = g * (x1 - ob[j2].x), oy = g * (y1 - ob[j2].y), oz = g * (z1 - ob[j2].z);
   float gx = 0.f, gy = 0.f, gz = 0.f;
   if (own_first) {
@@ -197,12 +199,13 @@ __global__ __launch_bounds__(kPackT) void chamfer_bwd_packed(
 // pass 1 (plain stores): grad_a[j] = own(j).  pass 2: atomics for the scatter.
 __global__ void chamfer_bwd_own(long long total, int n, int m, const float* __restrict__ xa,
                                 const float* __restrict__ xb, const int32_t* __restrict__ idx_a,
-                                const float* __restrict__ g_a, float* __restrict__ grad_a) {
+                                const float* __restrict__ g_a, float* __restrict__ grad_a, int gs,
+                                float gdiv_a) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= total) return;
   const long long c = r / n;
   const size_t o = ((size_t)c * m + idx_a[r]) * 3;
-  const float g = g_a[r] * 2;
+  const float g = (g_a[r * gs] / gdiv_a) * 2;
   grad_a[r * 3 + 0] = g * (xa[r * 3 + 0] - xb[o + 0]);
   grad_a[r * 3 + 1] = g * (xa[r * 3 + 1] - xb[o + 1]);
   grad_a[r * 3 + 2] = g * (xa[r * 3 + 2] - xb[o + 2]);
@@ -211,12 +214,13 @@ __global__ void chamfer_bwd_own(long long total, int n, int m, const float* __re
 __global__ void chamfer_bwd_scatter(long long total, int n, int m, const float* __restrict__ xa,
                                     const float* __restrict__ xb,
                                     const int32_t* __restrict__ idx_a,
-                                    const float* __restrict__ g_a, float* __restrict__ grad_b) {
+                                    const float* __restrict__ g_a, float* __restrict__ grad_b, int gs,
+                                    float gdiv_a) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= total) return;
   const long long c = r / n;
   const size_t o = ((size_t)c * m + idx_a[r]) * 3;
-  const float g = g_a[r] * 2;
+  const float g = (g_a[r * gs] / gdiv_a) * 2;
   atomicAdd(grad_b + o + 0, -(g * (xa[r * 3 + 0] - xb[o + 0])));
   atomicAdd(grad_b + o + 1, -(g * (xa[r * 3 + 1] - xb[o + 1])));
   atomicAdd(grad_b + o + 2, -(g * (xa[r * 3 + 2] - xb[o + 2])));
@@ -246,10 +250,10 @@ extern "C" int pdae_chamfer_forward(int b, int n, const float* xyz1, int m, cons
   return check_launch("chamfer_forward");
 }
 
-extern "C" int pdae_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz2,
-                                     const int32_t* idx1, const int32_t* idx2,
-                                     const float* grad_dist1, const float* grad_dist2,
-                                     float* grad_xyz1, float* grad_xyz2, pdae_stream_t stream) {
+static int chamfer_backward_impl(int b, int n, const float* xyz1, int m, const float* xyz2, const int32_t* idx1,
+                                 const int32_t* idx2, const float* grad_dist1, const float* grad_dist2, int gs,
+                                 float div1, float div2, float* grad_xyz1, float* grad_xyz2, pdae_stream_t stream,
+                                 const char* what) {
   using namespace pdae;
   if (b < 0 || n < 0 || m < 0) return bad_arg("chamfer_backward: negative size");
   if (b == 0 || (n == 0 && m == 0)) return PDAE_OK;
@@ -263,20 +267,77 @@ extern "C" int pdae_chamfer_backward(int b, int n, const float* xyz1, int m, con
     const size_t lds2 = (size_t)((kPackT + m - 1) / m + 1) * n * 20;
     hipLaunchKernelGGL(chamfer_bwd_packed, dim3((unsigned)((t1 + kPackT - 1) / kPackT)),
                        dim3(kPackT), lds1, s, b, n, m, xyz1, xyz2, idx1, idx2, grad_dist1,
-                       grad_dist2, grad_xyz1, 1);
+                       grad_dist2, grad_xyz1, 1, gs, div1, div2);
     hipLaunchKernelGGL(chamfer_bwd_packed, dim3((unsigned)((t2 + kPackT - 1) / kPackT)),
                        dim3(kPackT), lds2, s, b, m, n, xyz2, xyz1, idx2, idx1, grad_dist2,
-                       grad_dist1, grad_xyz2, 0);
+                       grad_dist1, grad_xyz2, 0, gs, div2, div1);
   } else {
     const int T = 256;
     hipLaunchKernelGGL(chamfer_bwd_own, dim3((unsigned)((t1 + T - 1) / T)), dim3(T), 0, s, t1, n, m,
-                       xyz1, xyz2, idx1, grad_dist1, grad_xyz1);
+                       xyz1, xyz2, idx1, grad_dist1, grad_xyz1, gs, div1);
     hipLaunchKernelGGL(chamfer_bwd_own, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2, m, n,
-                       xyz2, xyz1, idx2, grad_dist2, grad_xyz2);
+                       xyz2, xyz1, idx2, grad_dist2, grad_xyz2, gs, div2);
     hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t1 + T - 1) / T)), dim3(T), 0, s, t1,
-                       n, m, xyz1, xyz2, idx1, grad_dist1, grad_xyz2);
+                       n, m, xyz1, xyz2, idx1, grad_dist1, grad_xyz2, gs, div1);
     hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2,
-                       m, n, xyz2, xyz1, idx2, grad_dist2, grad_xyz1);
+                       m, n, xyz2, xyz1, idx2, grad_dist2, grad_xyz1, gs, div2);
   }
-  return check_launch("chamfer_backward");
+  return check_launch(what);
+}
+
+extern "C" int pdae_chamfer_backward(int b, int n, const float* xyz1, int m, const float* xyz2,
+                                     const int32_t* idx1, const int32_t* idx2,
+                                     const float* grad_dist1, const float* grad_dist2,
+                                     float* grad_xyz1, float* grad_xyz2, pdae_stream_t stream) {
+  return chamfer_backward_impl(b, n, xyz1, m, xyz2, idx1, idx2, grad_dist1, grad_dist2, 1, 1.0f, 1.0f, grad_xyz1,
+                               grad_xyz2, stream, "chamfer_backward");
+}
+
+extern "C" int pdae_chamfer_backward_mean(int b, int n, const float* xyz1, int m, const float* xyz2,
+                                          const int32_t* idx1, const int32_t* idx2, const float* grad_loss,
+                                          float* grad_xyz1, float* grad_xyz2, pdae_stream_t stream) {
+  // the gradient of mean(dist1) + mean(dist2): grad_dist1 = grad_loss / (b n), grad_dist2 = grad_loss / (b m)
+  return chamfer_backward_impl(b, n, xyz1, m, xyz2, idx1, idx2, grad_loss, grad_loss, 0, (float)((long long)b * n),
+                               (float)((long long)b * m), grad_xyz1, grad_xyz2, stream, "chamfer_backward_mean");
+}
+
+namespace pdae {
+// out[0] = mean(a) + mean(b) in two small launches with a fixed summation order: MS_BLOCKS blocks leave one partial
+// sum per input (thread-strided float4 reads, wave shuffles, LDS slots in order), one wave adds the partials in order.
+constexpr int MS_BLOCKS = 128;
+__global__ __launch_bounds__(256) void mean_sum2_partial_kernel(long long na, const float* __restrict__ a, long long nb,
+                                                                const float* __restrict__ b, float* __restrict__ part) {
+  __shared__ float red[2][4];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)MS_BLOCKS * 256;
+  float sa = 0.f, sb = 0.f;
+  for (long long i = t; i < na; i += stride) sa += a[i];
+  for (long long i = t; i < nb; i += stride) sb += b[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sa += __shfl_xor(sa, o, kWave), sb += __shfl_xor(sb, o, kWave);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = sa, red[1][threadIdx.x >> 6] = sb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    part[MS_BLOCKS + blockIdx.x] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  }
+}
+__global__ __launch_bounds__(64) void mean_sum2_final_kernel(long long na, long long nb, const float* __restrict__ part,
+                                                             float* __restrict__ out) {
+  const int l = threadIdx.x;
+  float sa = part[l] + part[l + 64], sb = part[MS_BLOCKS + l] + part[MS_BLOCKS + l + 64];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sa += __shfl_xor(sa, o, kWave), sb += __shfl_xor(sb, o, kWave);
+  if (l == 0) out[0] = sa / (float)na + sb / (float)nb;
+}
+}  // namespace pdae
+
+extern "C" int pdae_mean_sum2(long long na, const float* a, long long nb, const float* b, float* workspace, float* out,
+                              pdae_stream_t stream) {
+  using namespace pdae;
+  static_assert(MS_BLOCKS == 128, "the final kernel adds two partials per lane");
+  if (na <= 0 || nb <= 0 || !a || !b || !out || !workspace) return bad_arg("mean_sum2: empty input or null pointer");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(mean_sum2_partial_kernel, dim3(MS_BLOCKS), dim3(256), 0, s, na, a, nb, b, workspace);
+  hipLaunchKernelGGL(mean_sum2_final_kernel, dim3(1), dim3(64), 0, s, na, nb, workspace, out);
+  return check_launch("mean_sum2");
 }

@@ -447,7 +447,7 @@ void rows_gemm_kernel(const Args p) {
 // uniform-split version ran 2 or 4 blocks on a CU: 117 us where the MFMAs need 66).  A block writes
 // the partial tile of every output tile its range touches into its own slots; wgrad_reduce adds a
 // tile's partials in block order: no atomics, bit-identical run to run.
-constexpr int WG_MAX = 8;
+constexpr int WG_MAX = 48;               // layers per launch: 12 Transformer blocks x 4 (the by-value struct is 3.1 KB)
 constexpr int TBK = 16;                 // rows per LDS slab
 constexpr int WCH = 32;                 // rows per work unit
 constexpr int WTM = 128, WTN = 128;     // output tile (n of dY x k of X)
@@ -460,9 +460,11 @@ struct WgradProb {
   int N, K;
   int tk;             // tiles along K
   int tile0;          // first tile of this problem in the group
+  int M, chunks;      // rows of this problem, 32-row chunks per tile
+  long long unit0;    // first unit of this problem
 };
 struct WgradArgs {
-  int M, nprob, tiles, chunks, blocks, slots;   // chunks per tile; grid; slots per block
+  int nprob, tiles, blocks, slots;              // grid; slots per block
   long long units;
   float* partials;                              // [blocks][slots][WSLOT]
   WgradProb p[WG_MAX];
@@ -470,6 +472,24 @@ struct WgradArgs {
 
 __device__ __forceinline__ long long wg_start(const WgradArgs& g, int b) {
   return ((long long)b * g.units) / g.blocks;
+}
+
+// the problem a unit / a tile belongs to (scalar work: u and tile are block-uniform)
+__device__ __forceinline__ int wg_prob_of_unit(const WgradArgs& g, long long u) {
+  int pi = 0;
+  for (int q = 1; q < g.nprob; ++q)
+    if (u >= g.p[q].unit0) pi = q;
+  return pi;
+}
+__device__ __forceinline__ int wg_prob_of_tile(const WgradArgs& g, int tile) {
+  int pi = 0;
+  for (int q = 1; q < g.nprob; ++q)
+    if (tile >= g.p[q].tile0) pi = q;
+  return pi;
+}
+__device__ __forceinline__ int wg_tile_of_unit(const WgradArgs& g, long long u) {
+  const WgradProb& P = g.p[wg_prob_of_unit(g, u)];
+  return P.tile0 + (int)((u - P.unit0) / P.chunks);
 }
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
@@ -493,19 +513,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   const long long uend = wg_start(g, sb + 1);
   float* slot = g.partials + (size_t)sb * g.slots * WSLOT;
   for (; u < uend; slot += WSLOT) {
-    const int tile = (int)(u / g.chunks), c0 = (int)(u % g.chunks);
-    const int c1 = (int)min((long long)g.chunks, c0 + (uend - u));
+    const WgradProb& P = g.p[wg_prob_of_unit(g, u)];
+    const long long rel = u - P.unit0;
+    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
     u += c1 - c0;
-    int pi = 0;
-#pragma unroll
-    for (int q = 1; q < WG_MAX; ++q)
-      if (q < g.nprob && tile >= g.p[q].tile0) pi = q;
-    const WgradProb& P = g.p[pi];
-    const int lt = tile - P.tile0;
     const int bx = lt % P.tk, by = lt / P.tk;
     const int n0 = by * TM, k0 = bx * TN;
     const int N = P.N, K = P.K;
-    const int mbeg = c0 * WCH, mend = min(g.M, c1 * WCH);
+    const int mbeg = c0 * WCH, mend = min(P.M, c1 * WCH);
     const int gcol = isb ? k0 + scol - TM : n0 + scol;
     const bool ok = isb ? gcol < K : gcol < N;
     const float* src = isb ? P.X + gcol : P.dY + gcol;
@@ -624,16 +640,12 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   __shared__ float4 red[PL > 1 ? PL : 1][EPB];
   __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
   const int tile = block / PARTS, part = block % PARTS;
-  int pi = 0;
-#pragma unroll
-  for (int q = 1; q < WG_MAX; ++q)
-    if (q < g.nprob && tile >= g.p[q].tile0) pi = q;
-  const WgradProb& P = g.p[pi];
+  const WgradProb& P = g.p[wg_prob_of_tile(g, tile)];
   const int lt = tile - P.tile0;
   const int bx = lt % P.tk, by = lt / P.tk;
   const int n0 = by * WTM, k0 = bx * WTN;
-  // blocks whose ranges meet this tile's units [tile * chunks, (tile + 1) * chunks)
-  const long long u0 = (long long)tile * g.chunks, u1 = u0 + g.chunks - 1;
+  // blocks whose ranges meet this tile's units
+  const long long u0 = P.unit0 + (long long)lt * P.chunks, u1 = u0 + P.chunks - 1;
   const int b0 = (int)(((u0 + 1) * g.blocks - 1) / g.units), b1 = (int)(((u1 + 1) * g.blocks - 1) / g.units);
   const int tid = threadIdx.x, pl = tid / EPB, el = tid % EPB;
   const int e = (part * EPB + el) * 4;                               // element of the 128 x 128 tile
@@ -642,7 +654,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   const bool bias = part == 0 && bx == 0 && P.db && el < WTM / 4 && n0 + el * 4 < P.N;
   // block b's slot that holds this tile: the (tile - first tile of b's range)-th
   auto src_of = [&](int b) {
-    return g.partials + ((size_t)b * g.slots + (tile - (int)(wg_start(g, b) / g.chunks))) * WSLOT;
+    return g.partials + ((size_t)b * g.slots + (tile - wg_tile_of_unit(g, wg_start(g, b)))) * WSLOT;
   };
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), bs = s;
   if (valid || bias)
@@ -685,22 +697,6 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
 template <int PL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
   wgrad_reduce_body<PL>(g, blockIdx.x);
-}
-
-// the reductions of several deferred grouped launches (pdae_deferred_begin / _flush) in one launch
-constexpr int WG_MULTI = 8;
-struct WgradMulti {
-  int njobs;
-  int first[WG_MULTI + 1];     // first block of job j; first[njobs] = the grid
-  WgradArgs job[WG_MULTI];
-};
-template <int PL>
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradMulti m) {
-  int j = 0;
-#pragma unroll
-  for (int q = 1; q < WG_MULTI; ++q)
-    if (q < m.njobs && (int)blockIdx.x >= m.first[q]) j = q;
-  wgrad_reduce_body<PL>(m.job[j], (int)blockIdx.x - m.first[j]);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -903,72 +899,101 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   return check_launch("rows_gemm");
 }
 
-static int wgrad_layout(int M, int nprob, const int* Ns, const int* Ks, WgradArgs* g) {
+static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g) {
   int tiles = 0;
+  long long units = 0;
   for (int q = 0; q < nprob; ++q) {
     if (Ns[q] <= 0 || Ks[q] <= 0 || Ns[q] % 4 != 0 || Ks[q] % 4 != 0)
       return unsupported("rows_wgrad: N, K positive multiples of 4");
-    g->p[q].N = Ns[q], g->p[q].K = Ks[q];
-    g->p[q].tk = (Ks[q] + WTN - 1) / WTN;
-    g->p[q].tile0 = tiles;
-    tiles += ((Ns[q] + WTM - 1) / WTM) * g->p[q].tk;
+    if (Ms[q] <= 0) return bad_arg("rows_wgrad: every layer of a group needs rows");
+    WgradProb& P = g->p[q];
+    P.N = Ns[q], P.K = Ks[q], P.M = Ms[q];
+    P.tk = (Ks[q] + WTN - 1) / WTN;
+    P.tile0 = tiles;
+    P.chunks = (Ms[q] + WCH - 1) / WCH;
+    P.unit0 = units;
+    const int t = ((Ns[q] + WTM - 1) / WTM) * P.tk;
+    tiles += t;
+    units += (long long)t * P.chunks;
   }
-  g->M = M, g->nprob = nprob, g->tiles = tiles;
-  g->chunks = M > 0 ? (M + WCH - 1) / WCH : 1;
-  g->units = (long long)tiles * g->chunks;
-  // one residency of the chip: 256 CUs x 2 blocks (32 KB of LDS, 122 registers each)
+  g->nprob = nprob, g->tiles = tiles, g->units = units;
+  // one residency of the chip: 256 CUs x 2 blocks (32 KB of LDS, 212 registers each)
 #ifdef PDAE_LAB_PLAN
   static const int wg_blocks = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 512;
 #else
   constexpr int wg_blocks = 512;
 #endif
-  g->blocks = (int)(g->units < wg_blocks ? g->units : wg_blocks);
-  const long long len = (g->units + g->blocks - 1) / g->blocks;       // longest range
-  g->slots = (int)((len + g->chunks - 2) / g->chunks) + 1;            // tiles a range of `len` units can touch
+  g->blocks = (int)(units < wg_blocks ? units : wg_blocks);
+  // slots per block: the most tiles one block's unit range touches (ranges are [b units / B, (b + 1) units / B))
+  auto tile_of = [&](long long u) {
+    int pi = 0;
+    for (int q = 1; q < nprob; ++q)
+      if (u >= g->p[q].unit0) pi = q;
+    return g->p[pi].tile0 + (int)((u - g->p[pi].unit0) / g->p[pi].chunks);
+  };
+  int slots = 1;
+  for (int b = 0; b < g->blocks; ++b) {
+    const long long u0 = (long long)b * units / g->blocks, u1 = (long long)(b + 1) * units / g->blocks;
+    if (u1 > u0) {
+      const int n = tile_of(u1 - 1) - tile_of(u0) + 1;
+      if (n > slots) slots = n;
+    }
+  }
+  g->slots = slots;
   return PDAE_OK;
 }
 
-constexpr int WG_DEFER_MAX = 64;
-static WgradArgs g_wg_jobs[WG_DEFER_MAX];
-static int g_wg_pl[WG_DEFER_MAX];
-static int g_wg_n = 0;
-
 namespace pdae {
-// called by pdae_deferred_flush (det.hip): the parked reductions, grouped by lane count, up to WG_MULTI per launch
-int rows_wgrad_flush(hipStream_t s) {
-  using namespace rows;
-  for (int pl : {1, 4, 8}) {
-    WgradMulti m;
-    m.njobs = 0, m.first[0] = 0;
-    auto launch = [&]() {
-      if (m.njobs == 0) return;
-      const unsigned grid = (unsigned)m.first[m.njobs];
-      if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<1>, dim3(grid), dim3(256), 0, s, m);
-      else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<4>, dim3(grid), dim3(256), 0, s, m);
-      else hipLaunchKernelGGL(wgrad_reduce_multi_kernel<8>, dim3(grid), dim3(256), 0, s, m);
-      m.njobs = 0, m.first[0] = 0;
-    };
-    for (int i = 0; i < g_wg_n; ++i) {
-      if (g_wg_pl[i] != pl) continue;
-      m.job[m.njobs] = g_wg_jobs[i];
-      m.first[m.njobs + 1] = m.first[m.njobs] + g_wg_jobs[i].tiles * 16 * pl;
-      if (++m.njobs == WG_MULTI) launch();
-    }
-    launch();
-  }
-  g_wg_n = 0;
-  return check_launch("rows_wgrad_flush");
-}
+// (the weight-gradient reductions are no longer parked: a step's grouped launches are few and large)
+int rows_wgrad_flush(hipStream_t) { return PDAE_OK; }
 }  // namespace pdae
+
+extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats) {
+  if (nprob <= 0 || nprob > WG_MAX || !Ms || !Ns || !Ks || !floats) return bad_arg("rows_wgrad_multi_workspace: bad argument");
+  static WgradArgs g;                      // (3 KB: off the stack; host-side query, one thread at a time like the plan cache)
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g);
+  if (rc) return rc;
+  *floats = (long long)g.blocks * g.slots * WSLOT;
+  return PDAE_OK;
+}
+
+extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X,
+                                     float* const* dW, float* const* db, const int* Ns, const int* Ks,
+                                     float* workspace, pdae_stream_t stream) {
+  if (nprob <= 0 || nprob > WG_MAX || !Ms || !dY || !X || !dW || !Ns || !Ks) return bad_arg("rows_wgrad_multi: bad argument");
+  WgradArgs g = {};
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g);
+  if (rc) return rc;
+  for (int q = 0; q < nprob; ++q) {
+    if (!dW[q] || !dY[q] || !X[q]) return bad_arg("rows_wgrad_multi: null pointer");
+    g.p[q].dY = dY[q], g.p[q].X = X[q], g.p[q].dW = dW[q], g.p[q].db = db ? db[q] : nullptr;
+  }
+  if (!workspace) return bad_arg("rows_wgrad_multi: null workspace");
+  hipStream_t s = as_stream(stream);
+  g.partials = workspace;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
+  // partial lanes of the reduction by the most partials a tile can have: the shortest reduction spans the fewest
+  // units, the block ranges are units / blocks long
+  int min_chunks = g.p[0].chunks, max_chunks = g.p[0].chunks;
+  for (int q = 1; q < nprob; ++q) {
+    min_chunks = g.p[q].chunks < min_chunks ? g.p[q].chunks : min_chunks;
+    max_chunks = g.p[q].chunks > max_chunks ? g.p[q].chunks : max_chunks;
+  }
+  const long long most = (max_chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
+  const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
+  (void)min_chunks;
+  if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
+  else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(g.tiles * 128), dim3(256), 0, s, g);
+  return check_launch("rows_wgrad_multi");
+}
 
 extern "C" int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks, long long* floats) {
   if (M < 0 || nprob <= 0 || nprob > WG_MAX || !Ns || !Ks || !floats)
     return bad_arg("rows_wgrad_workspace: bad argument");
-  WgradArgs g = {};
-  int rc = wgrad_layout(M, nprob, Ns, Ks, &g);
-  if (rc) return rc;
-  *floats = (long long)g.blocks * g.slots * WSLOT;
-  return PDAE_OK;
+  int Ms[WG_MAX];
+  for (int q = 0; q < nprob; ++q) Ms[q] = M > 0 ? M : 1;
+  return pdae_rows_wgrad_multi_workspace(nprob, Ms, Ns, Ks, floats);
 }
 
 extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const float* const* X,
@@ -976,38 +1001,18 @@ extern "C" int pdae_rows_wgrad(int M, int nprob, const float* const* dY, const f
                                float* workspace, pdae_stream_t stream) {
   if (M < 0 || nprob <= 0 || nprob > WG_MAX || !dY || !X || !dW || !Ns || !Ks)
     return bad_arg("rows_wgrad: bad argument");
-  WgradArgs g = {};
-  int rc = wgrad_layout(M, nprob, Ns, Ks, &g);
-  if (rc) return rc;
-  for (int q = 0; q < nprob; ++q) {
-    if (!dW[q] || (M > 0 && (!dY[q] || !X[q]))) return bad_arg("rows_wgrad: null pointer");
-    g.p[q].dY = dY[q], g.p[q].X = X[q], g.p[q].dW = dW[q], g.p[q].db = db ? db[q] : nullptr;
-  }
-  hipStream_t s = as_stream(stream);
   if (M == 0) {
+    hipStream_t s = as_stream(stream);
     for (int q = 0; q < nprob; ++q) {
-      (void)hipMemsetAsync(g.p[q].dW, 0, sizeof(float) * (size_t)g.p[q].N * g.p[q].K, s);
-      if (g.p[q].db) (void)hipMemsetAsync(g.p[q].db, 0, sizeof(float) * (size_t)g.p[q].N, s);
+      if (!dW[q]) return bad_arg("rows_wgrad: null pointer");
+      (void)hipMemsetAsync(dW[q], 0, sizeof(float) * (size_t)Ns[q] * Ks[q], s);
+      if (db && db[q]) (void)hipMemsetAsync(db[q], 0, sizeof(float) * (size_t)Ns[q], s);
     }
     return check_launch("rows_wgrad");
   }
-  if (!workspace) return bad_arg("rows_wgrad: null workspace");
-  g.partials = workspace;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
-  // partial lanes of the reduction by the most partials a tile can have
-  const long long most = (g.chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
-  const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
-  if (deferred_on() && g_wg_n < WG_DEFER_MAX) {
-    // between pdae_deferred_begin and _flush the reduction is postponed: the flush adds the partial tiles of
-    // all parked launches with a few launches that fill the chip (the workspace must live until then)
-    g_wg_pl[g_wg_n] = pl;
-    g_wg_jobs[g_wg_n++] = g;
-    return check_launch("rows_wgrad");
-  }
-  if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
-  else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(g.tiles * 128), dim3(256), 0, s, g);
-  return check_launch("rows_wgrad");
+  int Ms[WG_MAX];
+  for (int q = 0; q < nprob; ++q) Ms[q] = M;
+  return pdae_rows_wgrad_multi(nprob, Ms, dY, X, dW, db, Ns, Ks, workspace, stream);
 }
 
 // Batched product Y_b[M,N] = X_b[M,K] . W_b[N,K]^T for b < batch (blockIdx.z), element strides between the

@@ -82,6 +82,7 @@ class FlatDataParallel(nn.Module):
         self.grad_views = [p.grad for p in params]
         # gradient sink (nn_ops._sink_views): armed by a graphed step around its own forward + backward only
         self.sink_armed, self.sink_written = False, set()
+        self.wgrad_queue = []           # the armed step's queued weight gradients (nn_ops.flush_wgrad_queue)
         me = weakref.ref(self)
         for i, p in enumerate(params):
             p._pdae_flat = (me, i)

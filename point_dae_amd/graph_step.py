@@ -106,18 +106,39 @@ class GraphedTrainStep:
         self.B, self.G = batch_size, self.net.num_group
         self.masked = bool(getattr(self.net, 'masked', True))
         self.pts = torch.zeros(batch_size, npoints, 3, device=dev)
-        self.steps = torch.zeros(self.MAX_STEPS, batch_size, 10, device=dev)
-        self.vis = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
-        self.msk = torch.zeros(batch_size * self.G, dtype=torch.int64, device=dev)
-        if not self.masked:
-            self.vis.copy_(torch.arange(batch_size * self.G))
+        # Everything the host draws per step travels in ONE packed buffer (one H2D copy): the affine steps, the
+        # visible / masked row lists as int64 (index_select) and as int32 (the embedder's group lists), and the
+        # decoder's token order [visible..., masked...] per sample (otherwise a cat launch inside the graph).
+        BG = batch_size * self.G
+        sizes = [self.MAX_STEPS * batch_size * 10 * 4, BG * 8, BG * 8, BG * 8, BG * 4, BG * 4]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 15) // 16 * 16)
+        self._offs = offs
+
+        def views(buf):
+            cut = [buf[offs[i]:offs[i] + sizes[i]] for i in range(6)]
+            return dict(steps=cut[0].view(torch.float32).view(self.MAX_STEPS, batch_size, 10),
+                        vis=cut[1].view(torch.int64), msk=cut[2].view(torch.int64), order=cut[3].view(torch.int64),
+                        vis32=cut[4].view(torch.int32), msk32=cut[5].view(torch.int32))
+        self.stage = torch.zeros(offs[-1], dtype=torch.uint8, device=dev)
+        dv = views(self.stage)
+        self.steps, self.vis, self.msk, self.order = dv['steps'], dv['vis'], dv['msk'], dv['order']
+        self.vis32, self.msk32 = dv['vis32'], dv['msk32']
         # The host runs several steps ahead of the GPU, so the pinned staging buffers of
         # the draws form a ring; a slot is reused only after the event recorded behind its
-        # H2D copies has completed.
-        self.ring = [dict(steps=torch.zeros(self.MAX_STEPS, batch_size, 10).pin_memory(),
-                          vis=torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory(),
-                          msk=torch.zeros(batch_size * self.G, dtype=torch.int64).pin_memory(),
-                          done=None) for _ in range(self.RING)]
+        # H2D copy has completed.
+        self.ring = []
+        for _ in range(self.RING):
+            raw = torch.zeros(offs[-1], dtype=torch.uint8).pin_memory()
+            slot = views(raw)
+            slot.update(raw=raw, done=None)
+            self.ring.append(slot)
+        if not self.masked:                                        # every token visible, one static shape
+            ar = torch.arange(BG)
+            for slot in self.ring:
+                slot['vis'].copy_(ar), slot['order'].copy_(ar), slot['vis32'].copy_(ar.to(torch.int32))
+            self.stage.copy_(self.ring[0]['raw'])
         self.slot = 0
         self.graphs, self.outputs = {}, {}
         _warn_if_null_stream()
@@ -142,7 +163,9 @@ class GraphedTrainStep:
 
     def _mix(self, lx, ln):
         lt = self.loss_type
-        if lt == 'xyz':
+        if lt == 'xyz' or (lt != 'normal' and not ln.requires_grad):
+            # (the plain model's second loss is the constant zeros(1): lx + w * 0 is lx, bit for bit, without the
+            # fill / sum / mul / add launches and their backward twins)
             return lx
         if lt == 'normal':
             return self.w_dev * ln.sum()
@@ -165,15 +188,18 @@ class GraphedTrainStep:
         slot['steps'][:, :, 1:4] = 1.0                         # identity 'multiply' steps
         if n:
             slot['steps'][:n].copy_(steps)
-        self.steps.copy_(slot['steps'], non_blocking=True)
         tvis = self.G
         if self.masked:
             vis_rows, mask_rows = mask_row_ids(mask)
-            tvis = vis_rows.numel() // self.B
-            slot['vis'][:vis_rows.numel()].copy_(vis_rows)
-            slot['msk'][:mask_rows.numel()].copy_(mask_rows)
-            self.vis.copy_(slot['vis'], non_blocking=True)
-            self.msk.copy_(slot['msk'], non_blocking=True)
+            nv, nm = vis_rows.numel(), mask_rows.numel()
+            tvis = nv // self.B
+            slot['vis'][:nv].copy_(vis_rows)
+            slot['msk'][:nm].copy_(mask_rows)
+            slot['vis32'][:nv].copy_(vis_rows)
+            slot['msk32'][:nm].copy_(mask_rows)
+            torch.cat([vis_rows.view(self.B, tvis), mask_rows.view(self.B, self.G - tvis)], dim=1,
+                      out=slot['order'].view(self.B, self.G))
+        self.stage.copy_(slot['raw'], non_blocking=True)       # ONE copy
         slot['done'] = torch.cuda.Event()
         slot['done'].record()
         return tvis
@@ -208,9 +234,11 @@ class GraphedTrainStep:
         enc.grad_cut = cut
         # the blocks' weight gradients go straight into THIS model's flat buffer (nn_ops._sink_views): every .grad
         # is None here and nothing else touches the flat gradient views until the gather below
+        from . import nn_ops
         m.sink_armed, m.sink_written = SINK, set()
         try:
-            lx, ln = m(self.pts, self.pts, steps=self.steps, rows=(self.vis[:nv], self.msk[:nm]))
+            lx, ln = m(self.pts, self.pts, steps=self.steps,
+                       rows=(self.vis[:nv], self.msk[:nm], self.vis32[:nv], self.msk32[:nm], self.order))
             loss = self._mix(lx, ln)
             # the 34 LayerNorm backward launches park their parameter-gradient partials; ONE launch adds them
             # all after the backward (include/pdae.h: deferred reductions) -- nothing reads those gradients
@@ -219,7 +247,9 @@ class GraphedTrainStep:
                 _lib.deferred_begin()
             try:
                 loss.backward()
+                nn_ops.flush_wgrad_queue(m)        # (stacks flush themselves; this catches a queue left by a cut)
             finally:
+                m.wgrad_queue = []
                 if SINK:
                     _lib.deferred_flush(lx)
         finally:

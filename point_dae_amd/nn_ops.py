@@ -346,7 +346,11 @@ def draw_drop_path(B, drop_probs, training, keep):
     None where p == 0.  `keep` is drop_path_keep_buffer(drop_probs) on the device."""
     if not training or all(p == 0. for p in drop_probs):
         return [(None, None)] * len(drop_probs)
-    r = (torch.rand((2 * len(drop_probs), B), dtype=keep.dtype, device=keep.device) + keep).floor_() / keep
+    r = torch.rand((2 * len(drop_probs), B), dtype=keep.dtype, device=keep.device)
+    if r.is_cuda:                 # floor(r + keep) / keep for every site in one launch (csrc/block.hip)
+        _lib.call('pdae_drop_path_keep', r, r.shape[0], B, _lib.ptr(r), _lib.ptr(keep), _lib.ptr(r))
+    else:
+        r = (r + keep).floor_() / keep
     return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(drop_probs)]
 
 
@@ -400,6 +404,15 @@ def _sink_views(tags, weights):
         if w.data_ptr() != base + owner.offsets[i][0] * esz or owner.grad_views[i].shape != w.shape:
             return None
     return owner, idx, [owner.grad_views[i] for i in idx]
+
+
+def flush_wgrad_queue(owner):
+    """Issue the queued weight gradients of an armed FlatDataParallel (see _TransformerBlock.backward)."""
+    q = owner.wgrad_queue
+    if q:
+        flops = 2.0 * sum(dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in q)
+        probed_family('rows_wgrad', flops, lambda: _lib.rows_wgrad_multi(q))
+        owner.wgrad_queue = []
 
 
 def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
@@ -552,18 +565,17 @@ def conv1x1(x_rows, conv):
 
 class _PosEmbed(torch.autograd.Function):
     """Linear(3,128) -> GELU -> Linear(128,C) on centre rows (PointCAE_transformer.py:329-333).
-    The 3 input columns are padded to 4 (the GEMMs reduce in multiples of 4); GELU and the factor
-    its backward needs come out of the first GEMM's epilogue.  Centres carry no gradient."""
+    The first layer (K = 3) with its row gather, GELU and the factor GELU's backward needs is one small kernel
+    (pdae_pos_embed_fc1: it also leaves the gathered rows zero-padded to 4 columns, the weight-gradient GEMM's
+    operand); the second layer is a row GEMM.  Centres carry no gradient."""
 
     @staticmethod
-    def forward(ctx, xyz, w1, b1, w2, b2):
-        M = xyz.shape[0]
-        xp = torch.zeros((M, 4), device=xyz.device, dtype=xyz.dtype)
-        xp[:, :3] = xyz
-        w1p = torch.zeros((w1.shape[0], 4), device=xyz.device, dtype=xyz.dtype)
-        w1p[:, :3] = w1
-        gp = _empty((M, w1.shape[0]), xyz)
-        h = rows_gemm(xp, w1p, False, b1, 2, gp)
+    def forward(ctx, xyz, rows, w1, b1, w2, b2):
+        M = rows.numel() if rows is not None else xyz.shape[0]
+        H = w1.shape[0]
+        h, gp, xp = _empty((M, H), xyz), _empty((M, H), xyz), _empty((M, 4), xyz)
+        _lib.call('pdae_pos_embed_fc1', xyz, M, H, _lib.ptr(xyz), _lib.ptr(rows), _lib.ptr(w1.contiguous()), _lib.ptr(b1),
+                  _lib.ptr(h), _lib.ptr(gp), _lib.ptr(xp))
         y = rows_gemm(h, w2, False, b2, 0)
         ctx.save_for_backward(xp, gp, h, w2)
         return y
@@ -574,14 +586,17 @@ class _PosEmbed(torch.autograd.Function):
         dy = dy.contiguous()
         dz = rows_gemm(dy, w2, True, None, 3, gp)
         (dw2, dw1p), (db2, db1) = rows_wgrad([dy, dz], [h, xp], [True, True])
-        return None, dw1p[:, :3], db1, dw2, db2
+        return None, None, dw1p[:, :3], db1, dw2, db2
 
 
-def pos_embed(xyz_rows, seq):
-    """Linear(3,128) -> GELU -> Linear(128,C) (PointCAE_transformer.py:329-333)."""
-    if not xyz_rows.is_cuda:
+def pos_embed(xyz, seq, rows=None):
+    """Linear(3,128) -> GELU -> Linear(128,C) (PointCAE_transformer.py:329-333) of xyz (R,3) -- of its rows
+    `rows` (int64 device indices) when given: the gather is part of the first layer's kernel."""
+    if not xyz.is_cuda:
         raise RuntimeError('pos_embed: rows must be on the GPU (there is no CPU path)')
-    return _PosEmbed.apply(xyz_rows.contiguous(), seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
+    if seq[0].weight.shape[0] % 4 != 0:
+        raise NotImplementedError('pos_embed: hidden width must be a multiple of 4')
+    return _PosEmbed.apply(xyz.contiguous(), rows, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
 
 
 class _TransformerBlock(torch.autograd.Function):
@@ -673,17 +688,26 @@ class _TransformerBlock(torch.autograd.Function):
         # d pos: this block's dx0, or -- summed inside the kernels -- the stack's buffer from its first block
         dpos = None if not ctx.has_pos else (dx0 if dmode == 0 else (dacc if ret_acc else None))
         sink = _sink_views(ctx.sink_tags, [wqkv, wproj, w1, w2, bf1])   # graphed step: straight into the flat buffer
-        ws_, bs_ = (sink[2][:4], sink[2][4:]) if sink else (None, None)
-        if tail:                               # two row counts: two groups
-            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False], ws_[:1] if sink else None)
-            (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False],
-                                                          ws_[1:] if sink else None, bs_)
+        if sink:
+            # The weight gradients are not needed before the optimiser: the block only QUEUES them (operands kept
+            # alive by the queue); the first block of the stack -- the last one backward reaches -- issues the whole
+            # stack's weight gradients as ONE grouped launch (pdae_rows_wgrad_multi: every layer with its own row
+            # count, (tile, 32-row chunk) units of all layers dealt in equal ranges to one residency of the chip).
+            # 16 launches of 90-250 us with their ramps, tails and partial-tile traffic become two of ~1 ms.
+            owner, _, views = sink
+            owner.wgrad_queue += [(dqkv, n1, views[0], None), (da1, o_t, views[1], None), (dz, n2, views[2], views[4]),
+                                  (da2, h, views[3], None)]
+            owner.sink_written.update(sink[1])
+            first_of_stack = ctx.pos_grad is None or ctx.pos_grad[1] == 0
+            if first_of_stack:
+                flush_wgrad_queue(owner)
+            dwqkv = dwproj = dw1 = dw2 = dbf1 = None
+        elif tail:                             # two row counts: two groups
+            (dwqkv,), _ = rows_wgrad([dqkv], [n1], [False])
+            (dwproj, dw1, dw2), (_, dbf1, _) = rows_wgrad([da1, dz, da2], [o_t, n2, h], [False, True, False])
         else:
             (dwqkv, dwproj, dw1, dw2), (_, _, dbf1, _) = rows_wgrad([dqkv, da1, dz, da2], [n1, o, n2, h],
-                                                                    [False, False, True, False], ws_, bs_)
-        if sink:
-            sink[0].sink_written.update(sink[1])
-            dwqkv = dwproj = dw1 = dw2 = dbf1 = None
+                                                                    [False, False, True, False])
         return (da0, dbias_in if ctx.has_bias_in else None, None, dx0, dpos, None, None,
                 dg1, db1, dwqkv, dwproj, dbproj, dg2, db2, dw1, dbf1, dw2, None, None, None, None, None, None, None, None)
 

@@ -227,17 +227,22 @@ class MaskTransformer(nn.Module):
         `rows` = (vis_rows, mask_rows) already on the device skips the host-side
         mask draw (hipGraph replay: nothing on this path may touch the host)."""
         B, G = center.shape[:2]
+        vis32 = msk32 = None
         if rows is not None:
-            vis_rows, mask_rows = rows
+            vis_rows, mask_rows = rows[:2]
+            if len(rows) > 2:                     # the graphed step uploads the int32 lists too (no cast launches)
+                vis32, msk32 = rows[2], rows[3]
         else:
             if mask is None:
                 mask = self._mask_center_rand(center, noaug=noaug)
             vis_rows, mask_rows = (r.to(center.device) for r in mask_row_ids(mask.cpu()))
+        if vis32 is None:
+            vis32, msk32 = vis_rows.to(torch.int32), mask_rows.to(torch.int32)
         Tvis = vis_rows.numel() // B
         # every group goes through the embedder up to its last BatchNorm (:437); the
         # final conv + max-pool, whose output the reference computes for all groups and
         # then drops for the masked ones (:449), runs for the visible groups only
-        x_vis = self.encoder(neighborhood, groups=vis_rows.to(torch.int32), masked=mask_rows.to(torch.int32))
+        x_vis = self.encoder(neighborhood, groups=vis32, masked=msk32)
         cut = getattr(self, 'grad_cut', None)
         if cut is not None and x_vis.requires_grad:
             # two-phase backward (graph_step.py): the Transformer's backward stops at a leaf copy of the
@@ -245,7 +250,7 @@ class MaskTransformer(nn.Module):
             cut['tokens'] = x_vis
             x_vis = x_vis.detach().requires_grad_()
             cut['leaf'] = x_vis
-        pos = nn_ops.pos_embed(center.reshape(B * G, 3).index_select(0, vis_rows), self.pos_embed)
+        pos = nn_ops.pos_embed(center.reshape(B * G, 3), self.pos_embed, rows=vis_rows)
         x_vis = self.blocks(x_vis, pos, B, Tvis)
         return nn_ops.layer_norm(x_vis, self.norm), mask, (vis_rows, mask_rows)
 
@@ -316,8 +321,11 @@ class PointCAE_transformer(nn.Module):
             return out
         # decoder positions come from the UN-transformed centres (:695-696)
         ctr = center.reshape(B * G, 3)
-        order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
-        pos_full = nn_ops.pos_embed(ctr.index_select(0, order), self.decoder_pos_embed)
+        if rows is not None and len(rows) > 4:       # uploaded with the row lists by the graphed step
+            order = rows[4]
+        else:
+            order = torch.cat([vis_rows.reshape(B, Tvis), mask_rows.reshape(B, M)], dim=1).reshape(-1)
+        pos_full = nn_ops.pos_embed(ctr, self.decoder_pos_embed, rows=order)
         if M:
             x_full = torch.cat([x_vis.reshape(B, Tvis, C), nn_ops.expand_token(self.mask_token, B, M)], dim=1)
         else:

@@ -181,7 +181,7 @@ def test_graphed_step_equals_eager_step_exactly(det):
     config.model.transformer_config.decoder_depth = 2
     torch.manual_seed(0)
     net_a = builder.model_builder(config.model).cuda().train()
-    net_b = copy.deepcopy(net_a)
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
     B = 16
     x = torch.from_numpy(shapenet_like_clouds(B * 2, 1024, seed=4)).cuda().split(B)
 
@@ -191,8 +191,12 @@ def test_graphed_step_equals_eager_step_exactly(det):
     model_a = FlatDataParallel(net_a)
     opt_a, _ = builder.build_opti_sche(model_a, config)
     model_a.zero_grad()
+    # the SAME step body launched kernel by kernel (never captured) ...
+    eager_step = GraphedTrainStep(model_a, opt_a, config, B, 1024, warmup_eager=1000)
     seed(123)
-    eager = [train_step(model_a, opt_a, config, x[i % 2], x[i % 2])[0].item() for i in range(6)]
+    eager = [eager_step(x[i % 2])[0].item() for i in range(6)]
+    assert not eager_step.graphs
+    # ... against its hipGraph replays
     model_b = FlatDataParallel(net_b)
     opt_b, _ = builder.build_opti_sche(model_b, config)
     step = GraphedTrainStep(model_b, opt_b, config, B, 1024, warmup_eager=1)
@@ -201,6 +205,15 @@ def test_graphed_step_equals_eager_step_exactly(det):
     assert len(step.graphs) >= 1
     for a, b in zip(eager, graphed):
         assert abs(a - b) <= 1e-6 * abs(a), (eager, graphed)
+    # and the plain autograd path of runner_pretrain.train_step (its weight gradients are reduced per block, the
+    # graphed step's per stack: another fixed summation order, so equal to rounding -- amplified by six AdamW updates)
+    model_c = FlatDataParallel(net_c)
+    opt_c, _ = builder.build_opti_sche(model_c, config)
+    model_c.zero_grad()
+    seed(123)
+    plain = [train_step(model_c, opt_c, config, x[i % 2], x[i % 2])[0].item() for i in range(6)]
+    for a, b in zip(plain, graphed):
+        assert abs(a - b) <= 2e-5 * abs(a), (plain, graphed)
     diff = (model_a.flat_param - model_b.flat_param).abs().max().item()
     assert diff <= 1e-6 * model_a.flat_param.abs().max().item(), diff
 

@@ -241,8 +241,13 @@ def test_two_ranks_sync_bn_statistics_span_the_replicas(tmp_path):
     mp.spawn(_sync_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = torch.load(out)
 
+    gmax = max(g.abs().max().item() for g in r['lay_g'])
+
     def worst(a, b):
-        return max(((x - y).abs().max().item() / max(y.abs().max().item(), 1e-6), n) for x, y, n in zip(a, b, r['names']))
+        # error of a parameter's gradient against ITS max, floored at 1e-3 of the largest gradient (the two conv
+        # biases in front of a BatchNorm have an exactly-zero true gradient: only rounding residue to compare)
+        return max(((x - y).abs().max().item() / max(y.abs().max().item(), 1e-3 * gmax), n)
+                   for x, y, n in zip(a, b, r['names']))
     # SyncBN across two ranks == plain BatchNorm over the whole batch, same layer-by-layer code (tight)
     assert (r['tok'] - r['lay']).abs().max().item() <= 1e-5 * r['lay'].abs().max().item()
     assert torch.allclose(r['rm'], r['lay_rm'], rtol=1e-5, atol=1e-7) and torch.allclose(r['rv'], r['lay_rv'], rtol=1e-5, atol=1e-7)

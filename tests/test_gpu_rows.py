@@ -199,6 +199,42 @@ def test_rows_wgrad_long_reduction_narrow_weight(M, dims):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('blocks,enc_m,dec_m,tail_m', [(2, 1664, 2048, 640), (5, 2944, 0, 0), (13, 96, 128, 64)])
+def test_rows_wgrad_multi_layers_with_their_own_rows(blocks, enc_m, dec_m, tail_m):
+    """pdae_rows_wgrad_multi: the weight gradients of MANY layers in one launch, every layer with its own row count --
+    what a stack's backward issues (encoder blocks at B*T_vis rows, decoder blocks at B*G, the trimmed last block's
+    three layers at B*tail).  Against fp64 products; the same bits twice (ordered partial-tile reduction); more
+    layers than one launch holds are cut into several."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(blocks)
+    dims = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
+
+    def make():
+        jobs = []
+        for b in range(blocks):
+            for i, (n, k) in enumerate(dims):
+                m = enc_m if (b % 2 == 0 or not dec_m) else (tail_m if (b == blocks - 1 and i > 0 and tail_m) else dec_m)
+                dy = torch.randn(m, n, device='cuda', generator=g)
+                x = torch.randn(m, k, device='cuda', generator=g)
+                dw = torch.full((n, k), float('nan'), device='cuda')
+                db = torch.full((n,), float('nan'), device='cuda') if i == 2 else None
+                jobs.append((dy, x, dw, db))
+        return jobs
+    st = g.get_state()
+    jobs = make()
+    assert (len(jobs) > L.WGRAD_MULTI_MAX) == (blocks == 13)
+    L.rows_wgrad_multi(jobs)
+    for dy, x, dw, db in jobs:
+        _close(dw, dy.double().t() @ x.double(), 5e-5)
+        if db is not None:
+            _close(db, dy.double().sum(0), 5e-5)
+    g.set_state(st)
+    again = make()
+    L.rows_wgrad_multi(again)
+    for a, b in zip(jobs, again):
+        assert torch.equal(a[2], b[2])
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 512, 512), (1000, 512, 4), (333, 64, 128)])
 def test_rows_gemm_relu_mask_epilogue(M, N, K):
     """epi 4: dX = (dY . W) masked by the sign of the ReLU output the gradient flows into."""

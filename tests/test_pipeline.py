@@ -213,7 +213,6 @@ def test_loader_oracle_reproduces_live_reference_items(tag, oracle_ops):
 
 def _keys_for(select, stride, device):
     import torch
-    assert len(np.unique(select)) == len(select)
     keys = np.full(stride, 1e9, np.float32)
     keys[select] = np.arange(len(select), dtype=np.float32)
     return torch.from_numpy(keys).to(device)
@@ -283,9 +282,17 @@ def test_hip_loader_stages_reproduce_live_reference_items(tag):
         assert np.array_equal(keep.cpu().numpy(), np.stack([r['dl_alive'] for r in recs]))
         alive = keep.to(torch.uint8)
     keys = torch.stack([_keys_for(r['select'], stride, dev) for r in recs])
-    out = D.pipeline_subset(y, cur, NPTS, keys, alive)
-    want = np.stack([r['corrupted'] for r in recs])
-    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5, np.abs(out.cpu().numpy() - want).max()
+    out = D.pipeline_subset(y, cur, NPTS, keys, alive).cpu().numpy()
+    # a cloud that kept fewer than n points went through the reference's refill branch (np.random.choice with
+    # replacement, then a shuffle): its item repeats points, which no key order expresses -- for it the stages above
+    # are what is pinned (mask / added points), the sub-sampled item is compared as a SET of distinct points
+    for b, r in enumerate(recs):
+        if len(np.unique(r['select'])) == len(r['select']):
+            assert np.abs(out[b] - r['corrupted']).max() <= 1e-5, (b, np.abs(out[b] - r['corrupted']).max())
+        else:
+            assert int(r['n_before_sample']) < NPTS
+            d = np.abs(out[b][:, None, :] - r['corrupted'][None, :, :]).max(-1)       # (n, n) max-norm distances
+            assert d.min(1).max() <= 1e-5 and d.min(0).max() <= 1e-5, b          # the same set of distinct points
 
 
 @pytest.mark.gpu
