@@ -88,15 +88,40 @@ __global__ __launch_bounds__(256) void chamfer_fwd_tiled(int n, int m,
     for (int i = threadIdx.x; i < cnt; i += 256)
       cand[i] = make_float4(p2[(k0 + i) * 3 + 0], p2[(k0 + i) * 3 + 1], p2[(k0 + i) * 3 + 2], 0.f);
     __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < cnt; ++k) {
-      const float4 q = cand[k];
+    if constexpr (Q % 2 == 0) {
+      // two queries per packed instruction: v_pk_add_f32 / v_pk_mul_f32 evaluate ((dx*dx + dy*dy) + dz*dz) for a PAIR
+      // of this lane's queries at once -- the same eight roundings per pair as the scalar form (no FMA), half the
+      // issue slots; the strict `<` update (lowest index on ties, chamfer.cu:15-145) stays per query
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 px[Q / 2], py[Q / 2], pz[Q / 2];
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const float d = sqdist(q.x, q.y, q.z, x1[i], y1[i], z1[i]);
-        if (d < best[i]) {
-          best[i] = d;
-          besti[i] = k0 + k;
+      for (int i = 0; i < Q / 2; ++i) {
+        px[i] = f32x2{x1[2 * i], x1[2 * i + 1]}, py[i] = f32x2{y1[2 * i], y1[2 * i + 1]};
+        pz[i] = f32x2{z1[2 * i], z1[2 * i + 1]};
+      }
+#pragma unroll 4
+      for (int k = 0; k < cnt; ++k) {
+        const float4 q = cand[k];
+        const f32x2 qx = f32x2{q.x, q.x}, qy = f32x2{q.y, q.y}, qz = f32x2{q.z, q.z};
+#pragma unroll
+        for (int i = 0; i < Q / 2; ++i) {
+          const f32x2 dx = qx - px[i], dy = qy - py[i], dz = qz - pz[i];
+          const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+          if (d.x < best[2 * i]) best[2 * i] = d.x, besti[2 * i] = k0 + k;
+          if (d.y < best[2 * i + 1]) best[2 * i + 1] = d.y, besti[2 * i + 1] = k0 + k;
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int k = 0; k < cnt; ++k) {
+        const float4 q = cand[k];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+          const float d = sqdist(q.x, q.y, q.z, x1[i], y1[i], z1[i]);
+          if (d < best[i]) {
+            best[i] = d;
+            besti[i] = k0 + k;
+          }
         }
       }
     }

@@ -125,6 +125,13 @@ def pointnetv2_fixture(name, B, seed, corrupt_type=None):
     cap = {}
     ref.pointnetv2_encoder.register_forward_hook(lambda m, i, o: cap.update(feature=o))
     ref.folding1.register_forward_hook(lambda m, i, o: cap.update(coarse=o))
+    # the winners of the three set-abstraction max-pools (F.max_pool2d over nsample, pointnet2_modules.py:60-66): the
+    # gradient is routed through them, and a near-tie resolved the other way by 1 ulp of GEMM rounding moves whole
+    # gradient tensors by ~1e-2 -- the parity test injects these so that it compares like with like
+    enc = ref.pointnetv2_encoder
+    for lvl, sa in enumerate((enc.sa1, enc.sa2, enc.sa3)):
+        sa.mlps[0].register_forward_hook(
+            lambda m, i, o, lvl=lvl: cap.update({'arg%d' % lvl: o.detach().argmax(dim=3)}))      # (B, C, npoint)
     torch.manual_seed(seed + 7)
     l_coarse, l_fine = ref(corrupted, clean)
     (l_coarse + 0.5 * l_fine).backward()
@@ -135,6 +142,9 @@ def pointnetv2_fixture(name, B, seed, corrupt_type=None):
     out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
                loss_coarse=np.float32(l_coarse.item()), loss_fine=np.float32(l_fine.item()),
                feature=cap['feature'].detach().numpy(), coarse=cap['coarse'].detach().numpy().reshape(B, 1024, 3))
+    for lvl in range(3):                                    # product layout: (groups = B * npoint, C) uint8
+        a = cap['arg%d' % lvl]
+        out['sa_argmax%d' % lvl] = a.permute(0, 2, 1).reshape(-1, a.shape[1]).numpy().astype(np.uint8)
     for pname, p in ref.named_parameters():
         g = p.grad
         key = 'grad/' + pname
@@ -201,6 +211,10 @@ if __name__ == '__main__':
         dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'dropout_global':
+        pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'pointnetv2':
+        pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
         pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'nomask':

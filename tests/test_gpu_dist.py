@@ -243,11 +243,15 @@ def test_two_ranks_sync_bn_statistics_span_the_replicas(tmp_path):
 
     gmax = max(g.abs().max().item() for g in r['lay_g'])
 
+    dead = ('first_conv.0.bias', 'second_conv.0.bias')      # in front of a BatchNorm: the true gradient is exactly zero
+
     def worst(a, b):
-        # error of a parameter's gradient against ITS max, floored at 1e-3 of the largest gradient (the two conv
-        # biases in front of a BatchNorm have an exactly-zero true gradient: only rounding residue to compare)
+        # error of a parameter's gradient against ITS max (floored at 1e-3 of the largest gradient)
         return max(((x - y).abs().max().item() / max(y.abs().max().item(), 1e-3 * gmax), n)
-                   for x, y, n in zip(a, b, r['names']))
+                   for x, y, n in zip(a, b, r['names']) if n not in dead)
+    for x, y, n in zip(r['g'], r['lay_g'], r['names']):
+        if n in dead:                                       # only rounding residue on either side
+            assert x.abs().max().item() <= 1e-4 * gmax and y.abs().max().item() <= 1e-4 * gmax, n
     # SyncBN across two ranks == plain BatchNorm over the whole batch, same layer-by-layer code (tight)
     assert (r['tok'] - r['lay']).abs().max().item() <= 1e-5 * r['lay'].abs().max().item()
     assert torch.allclose(r['rm'], r['lay_rm'], rtol=1e-5, atol=1e-7) and torch.allclose(r['rv'], r['lay_rv'], rtol=1e-5, atol=1e-7)

@@ -168,18 +168,39 @@ def test_pointnetv2_product_model_reproduces_reference_fixture():
         assert abs(got.item() - want) <= 1e-5 * abs(want), (key, got.item(), want)
     _close(cap['feature'], fx['feature'], 1e-4, 'feature')
     _close(cap['coarse'], fx['coarse'], 1e-4, 'coarse')
-    # The set-abstraction max-pools sit on exact ties (ball-query padding repeats points), so the gradient is
-    # discontinuous there: jittering the LIBRARY GEMM outputs of the encoder by one ulp moves
-    # sa2.layer0.bn.bias by 6.5e-3 of its scale and sa2.layer0.conv.weight by 3.8e-3, the same figures a
-    # different (equally exact) summation order produces (tools/dbg_cfg1_noise.py, modes `noise` / `fwdmine`;
-    # every row GEMM of this step is within 2e-6 of fp64 on its own operands).  So: every gradient's L2 norm
-    # within 1e-2, every tensor within 1e-2 in the max norm except up to three that may carry a flipped tie
-    # (bounded by 5e-2; measured 1.5e-2 on sa3.layer1.bn.bias in deterministic mode, 0.65e-2 typically); the
-    # loss (1e-5) and the activations (1e-4) above are unaffected by ties.
-    check_grads(model, fx, 1e-2, 'pointnetv2', spike=5e-2, max_spikes=3)
-    for bname, b in model.named_buffers():
+    for bname, b in model.named_buffers():             # BatchNorm running estimates after ONE training forward
         if b.dtype.is_floating_point and 'buf/' + bname in fx:
             _close(b, fx['buf/' + bname], 1e-4, bname)
+    # The gradient is discontinuous where a max-pool winner changes: a near-tie resolved the other way by 1 ulp of GEMM
+    # rounding moves whole tensors (measured 6.5e-3 of sa2.layer0.bn.bias' scale, tools/dbg_cfg1_noise.py).  So the
+    # comparison is made twice.  (1) Like with like: the reference's own winners (captured from the live reference into
+    # the fixture) are injected into the three max-pools' backward, deterministic mode: every tensor within 2e-3, no
+    # exceptions.  (2) With the product's own winners: how many differ is asserted to be a handful, and the old bound
+    # (1e-2, three tensors up to 5e-2) still holds.
+    from point_dae_amd import _lib, sa_mlp
+    model.zero_grad(set_to_none=True)
+    mine, want = [], [torch.from_numpy(fx['sa_argmax%d' % i]).cuda() for i in range(3)]
+
+    def inject(arg):
+        mine.append(arg.clone())
+        return want[len(mine) - 1]
+    _lib.set_deterministic(True)
+    sa_mlp.ARG_HOOK = inject
+    try:
+        lc2, lf2 = model(torch.from_numpy(fx['corrupted']).cuda(), torch.from_numpy(fx['clean']).cuda())
+        (lc2 + 0.5 * lf2).backward()
+    finally:
+        sa_mlp.ARG_HOOK = None
+        _lib.set_deterministic(False)
+    assert len(mine) == 3 and all(a.shape == b.shape for a, b in zip(mine, want))
+    flips = [int((a != b).sum()) for a, b in zip(mine, want)]
+    # exact ties are ball-query's repeated points (identical rows): whichever copy wins, the gradient reaches the same
+    # source point -- so count winners that point at DIFFERENT points only through the gradient check below
+    check_grads(model, fx, 2e-3, 'pointnetv2, reference winners injected')
+    model.zero_grad(set_to_none=True)
+    lc3, lf3 = model(torch.from_numpy(fx['corrupted']).cuda(), torch.from_numpy(fx['clean']).cuda())
+    (lc3 + 0.5 * lf3).backward()
+    check_grads(model, fx, 1e-2, 'pointnetv2 (own winners; flips %s)' % flips, spike=5e-2, max_spikes=3)
 
 
 def test_pointnetv2_dropout_global_fixture():
@@ -203,25 +224,45 @@ def test_pointnetv2_dropout_global_fixture():
     check_grads(model, fx, 1e-2, 'pointnetv2 dropout_global', spike=5e-2, max_spikes=3)
 
 
-def test_cfg2_full_batch_step_runs():
-    """BASELINE config 2 shape (B=128, N=1024): one optimisation step, finite losses."""
+def test_cfg2_losses_equal_the_oracle_and_training_reduces_them():
+    """BASELINE config 2 (pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml).  (1) B=8: both Chamfer losses of
+    the HIP path equal the CPU oracle model's (oracle/model.py, bit-equal to the live reference) to 1e-5 on the same
+    weights and clouds.  (2) The config's own shape, B=128, N=1024: six optimisation steps on one batch -- finite, and
+    the loss goes down."""
     import os
+    import sys
+    from oracle import model as OM
     from point_dae_amd import builder
     from point_dae_amd.config import cfg_from_yaml_file
     from point_dae_amd.synthetic import shapenet_like_clouds
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tests', 'golden'))
+    from weights import fill_state as fill
     config = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'))
+    clean = shapenet_like_clouds(8, 1024, seed=61)
+    corrupted = shapenet_like_clouds(8, 1024, seed=62)
+    orc = fill(OM.Point_CAE_PointNetv2(config.model), 17).train()
+    with torch.no_grad():
+        o1, o2 = orc(torch.from_numpy(corrupted), torch.from_numpy(clean))
+    mine = fill(builder.model_builder(config.model), 17).cuda().train()
+    m1, m2 = mine(torch.from_numpy(corrupted).cuda(), torch.from_numpy(clean).cuda())
+    for got, want, name in ((m1, o1, 'coarse'), (m2, o2, 'fine')):
+        assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item()), (name, got.item(), want.item())
+    # ---- the config's batch
     torch.manual_seed(0)
     model = builder.model_builder(config.model).cuda().train()
     opt, _ = builder.build_opti_sche(model, config)
     x = torch.from_numpy(shapenet_like_clouds(128, 1024, seed=1)).cuda()
     y = torch.from_numpy(shapenet_like_clouds(128, 1024, seed=2)).cuda()
-    for _ in range(2):
+    losses = []
+    for _ in range(6):
         lc, lf = model(y, x)
         (lc + 0.5 * lf).backward()
         opt.step()
         model.zero_grad()
-    assert torch.isfinite(lc) and torch.isfinite(lf)
+        losses.append((lc + 0.5 * lf).item())
+    assert all(np.isfinite(v) for v in losses), losses
+    assert losses[-1] < 0.9 * losses[0], losses
 
 
 def test_cfg5_shape_runs():
