@@ -136,6 +136,65 @@ __global__ __launch_bounds__(256) void chamfer_fwd_tiled(int n, int m,
   }
 }
 
+// ---- forward, FEW queries against MANY candidates (the 1024-point ground truth against the 16384-point fine cloud of
+// Point_CAE_PointNetv2): one query per lane cannot hide the compare / select chain of a 16384-step scan (876 us at
+// B = 128), so every lane runs FOUR running minima over the candidates k = 0, 1, 2, 3 (mod 4) -- two packed pairs -- and
+// merges them at the end: the smallest distance, the LOWEST index among equal ones = what the strict `<` scan in index
+// order returns (chamfer.cu:15-145).  Candidates are staged as x / y / z rows so that two consecutive ones load as one
+// 8-byte LDS read into a register pair for v_pk_add_f32 / v_pk_mul_f32.
+__global__ __launch_bounds__(256) void chamfer_fwd_many(int n, int m, const float* __restrict__ xyz1,
+                                                        const float* __restrict__ xyz2, float* __restrict__ dist,
+                                                        int32_t* __restrict__ idx) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int TILE = 2048;
+  __shared__ float sx[TILE], sy[TILE], sz[TILE];
+  const int bi = blockIdx.y;
+  const float* p1 = xyz1 + (size_t)bi * n * 3;
+  const float* p2 = xyz2 + (size_t)bi * m * 3;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool in = j < n;
+  const float x1 = in ? p1[j * 3 + 0] : 0.f, y1 = in ? p1[j * 3 + 1] : 0.f, z1 = in ? p1[j * 3 + 2] : 0.f;
+  const f32x2 qx = f32x2{x1, x1}, qy = f32x2{y1, y1}, qz = f32x2{z1, z1};
+  float best[4];
+  int besti[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) best[a] = __builtin_huge_valf(), besti[a] = 0;
+  for (int k0 = 0; k0 < m; k0 += TILE) {
+    const int cnt = min(TILE, m - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE; i += 256) {
+      const bool ok = i < cnt;                       // the tail of the last tile: +inf never wins a strict `<`
+      sx[i] = ok ? p2[(size_t)(k0 + i) * 3 + 0] : __builtin_huge_valf();
+      sy[i] = ok ? p2[(size_t)(k0 + i) * 3 + 1] : 0.f;
+      sz[i] = ok ? p2[(size_t)(k0 + i) * 3 + 2] : 0.f;
+    }
+    __syncthreads();
+    const int lim = (cnt + 3) & ~3;
+#pragma unroll 2
+    for (int k = 0; k < lim; k += 4) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 cx = *reinterpret_cast<const f32x2*>(sx + k + 2 * h);
+        const f32x2 cy = *reinterpret_cast<const f32x2*>(sy + k + 2 * h);
+        const f32x2 cz = *reinterpret_cast<const f32x2*>(sz + k + 2 * h);
+        const f32x2 dx = cx - qx, dy = cy - qy, dz = cz - qz;
+        const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+        if (d.x < best[2 * h]) best[2 * h] = d.x, besti[2 * h] = k0 + k + 2 * h;
+        if (d.y < best[2 * h + 1]) best[2 * h + 1] = d.y, besti[2 * h + 1] = k0 + k + 2 * h + 1;
+      }
+    }
+  }
+  float b = best[0];
+  int bidx = besti[0];
+#pragma unroll
+  for (int a = 1; a < 4; ++a)
+    if (best[a] < b || (best[a] == b && besti[a] < bidx)) b = best[a], bidx = besti[a];
+  if (in) {
+    dist[(size_t)bi * n + j] = b;
+    idx[(size_t)bi * n + j] = bidx;
+  }
+}
+
 static bool use_packed(int n, int m) {
   // LDS for the clouds a 256-query workgroup can touch
   const long long clouds = (kPackT + n - 1) / n + 1;
@@ -154,6 +213,9 @@ static void chamfer_fwd_dir(int b, int n, int m, const float* xyz1, const float*
   } else if ((long long)b * ((n + 1023) / 1024) >= 1024 || n >= 4096) {
     dim3 grid((n + 1023) / 1024, b);
     hipLaunchKernelGGL((chamfer_fwd_tiled<4>), grid, dim3(256), 0, s, n, m, xyz1, xyz2, dist, idx);
+  } else if (m >= 2048) {
+    dim3 grid((n + 255) / 256, b);
+    hipLaunchKernelGGL(chamfer_fwd_many, grid, dim3(256), 0, s, n, m, xyz1, xyz2, dist, idx);
   } else {
     dim3 grid((n + 255) / 256, b);
     hipLaunchKernelGGL((chamfer_fwd_tiled<1>), grid, dim3(256), 0, s, n, m, xyz1, xyz2, dist, idx);

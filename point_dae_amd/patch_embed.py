@@ -297,7 +297,9 @@ def patch_embed(points, first_conv, second_conv, training, groups=None, masked=N
     done by algebra (PatchEmbedFunction._masked_by_algebra)."""
     BG, n, _ = points.shape
     if n != 32:
-        raise NotImplementedError('the fused embedder is written for group_size 32')
+        # the fused kernels tile a patch as one 32-row MFMA tile; other group sizes of the reference's YAML grid
+        # (16, 64) take the layer-by-layer path on the same row GEMMs
+        return patch_embed_layerwise(points, first_conv, second_conv, groups)
     if isinstance(first_conv[1], torch.nn.SyncBatchNorm) or isinstance(second_conv[1], torch.nn.SyncBatchNorm):
         # --sync_bn (runner_pretrain.py:81-83, off in every shipped config): batch statistics over ALL replicas.
         # The fused kernels keep BatchNorm's sums on the device of one replica, so this flag takes the layer-by-layer
