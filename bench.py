@@ -212,12 +212,22 @@ def dominant_roofline(probe, steps):
         tot_f += r['flops']
         tot_ms += r['ms']
     ach = tot_f / (tot_ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / MFMA_F32_PEAK_TFLOPS, 'ms_per_step': tot_ms / max(steps, 1),
-            'gflop_per_step': tot_f / max(steps, 1) / 1e9, 'families': rows,
-            'timing': 'HIP events around every launch of the two families over %d eager probe steps '
-                      '(launch-to-launch, so each figure carries the launch ramp a hipGraph replay also pays; '
-                      'profiles/kernel_summary_r%02d.txt has the in-replay durations)' % (steps, ROUND)}
+    out = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': ach / MFMA_F32_PEAK_TFLOPS, 'ms_per_step': tot_ms / max(steps, 1),
+           'gflop_per_step': tot_f / max(steps, 1) / 1e9, 'families': rows,
+           'timing': 'HIP events around every launch of the two families over %d eager probe steps '
+                     '(launch-to-launch from Python, so each figure carries host launch gaps a hipGraph replay does '
+                     'not pay; `replayed` = the same launches of ONE step captured into a hipGraph per family and '
+                     'replayed back to back; profiles/kernel_summary_r%02d.txt has the in-step durations)' % (steps, ROUND)}
+    rep = getattr(probe, 'replay_ms', None)
+    if rep and 'error' not in rep:
+        f1 = sum(r['flops'] for r in fam.values()) / max(steps, 1)
+        ms = sum(rep.get(k, 0.0) for k in fam)
+        out['replayed'] = {'ms_per_step': ms, 'achieved': f1 / (ms * 1e-3) / 1e12, 'frac': f1 / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                           'families_ms': {k: rep.get(k) for k in fam}}
+    elif rep:
+        out['replayed'] = rep
+    return out
 
 
 def cfg2_leg(args, device, rank):
@@ -493,6 +503,7 @@ def main():
         nn_ops.set_probe(probe)
         model.require_sync = False            # rank-0-only steps: no collective (the other ranks are not in them)
         for i in range(args.probe_steps):       # forward + backward only: the replicas' parameters stay in step
+            probe.keep_calls = i == args.probe_steps - 1          # the last probe step's launches are kept for a replay
             if isinstance(step, GraphedTrainStep):
                 # the graphed step's own body (gradient sink armed, the stacks' grouped weight gradients), launched
                 # kernel by kernel: what the replays run
@@ -504,6 +515,13 @@ def main():
             model.zero_grad()
         model.require_sync = True
         torch.cuda.synchronize()
+        probe.keep_calls = False
+        nn_ops.set_probe(None)
+        try:
+            probe.replay_ms = probe.family_replay_ms()
+        except Exception as err:                                   # a measurement aid: never fails the bench line
+            probe.replay_ms = {'error': repr(err)[:200]}
+        probe.calls = {}
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
                       'timed hipGraph region' % args.probe_steps)
     nn_ops.set_probe(None)

@@ -12,6 +12,7 @@ class Probe:
     def __init__(self):
         self.name, self.flops, self.events = None, 0.0, []
         self.families = {}                      # family -> [(start, end, flops)]
+        self.keep_calls, self.calls = False, {}  # keep the launch closures of the families (family_replay_ms)
 
     def _time(self, fn):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +30,30 @@ class Probe:
     def record_family(self, family, flops, fn):
         out, s, e = self._time(fn)
         self.families.setdefault(family, []).append((s, e, flops))
+        if self.keep_calls:
+            self.calls.setdefault(family, []).append(fn)      # (the closure keeps its operand tensors alive)
+        return out
+
+    def family_replay_ms(self, replays=10):
+        """The kept launches of each family captured into ONE hipGraph per family and replayed back to back:
+        ms per replay = the family's device time without host launch gaps (operands as the step left them)."""
+        out = {}
+        for fam, fns in self.calls.items():
+            g = torch.cuda.CUDAGraph()
+            for fn in fns:                                         # warm (allocations inside the closures: none)
+                fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                for fn in fns:
+                    fn()
+            g.replay()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(replays):
+                g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            out[fam] = s.elapsed_time(e) / replays
         return out
 
     def summary(self):
