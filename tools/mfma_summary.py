@@ -31,6 +31,16 @@ for path in glob.glob(os.path.join(sys.argv[1], '**', '*counter_collection.csv')
                 d['GRBM_GUI_ACTIVE'] = max(d.get('GRBM_GUI_ACTIVE', 0.0), v)
             else:                                           # reduce(sum)
                 d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + v
+# Second denominator: the dispatch's own duration from the kernel trace of the same pass, at the 2.4 GHz peak clock.
+# GRBM_GUI_ACTIVE / 8 reads HIGH on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back): a 40 us row
+# GEMM reports ~113 k "cycles" = 2.9 GHz, which understates its utilisation by a third; the duration-based figure is
+# busy cycles / (1024 SIMDs x duration x 2.4e9) = the fraction of the MFMA PEAK the dispatch reached.
+PEAK_HZ = 2.4e9
+dur = {}
+for path in glob.glob(os.path.join(sys.argv[1], '**', '*kernel_trace.csv'), recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            dur[r['Dispatch_Id']] = (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-9
 out = {}
 for key, disp in acc.items():
     busy = sum(d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for d in disp.values())
@@ -39,4 +49,8 @@ for key, disp in acc.items():
         continue
     out[key] = {'dispatches': len(disp), 'SQ_VALU_MFMA_BUSY_CYCLES_avg': busy / len(disp),
                 'GRBM_GUI_ACTIVE_avg': act / len(disp), 'mfma_util': busy / (act / XCDS * SIMDS)}
+    secs = sum(dur.get(i, 0.0) for i in disp)
+    if secs > 0 and all(i in dur for i in disp):
+        out[key]['avg_us_in_this_pass'] = secs / len(disp) * 1e6
+        out[key]['mfma_util_vs_peak_clock'] = busy / (SIMDS * secs * PEAK_HZ)
 print(json.dumps(dict(sorted(out.items(), key=lambda kv: -kv[1]['mfma_util'])), indent=1))
