@@ -83,6 +83,7 @@ class FlatDataParallel(nn.Module):
         # gradient sink (nn_ops._sink_views): armed by a graphed step around its own forward + backward only
         self.sink_armed, self.sink_written = False, set()
         self.wgrad_queue = []           # the armed step's queued weight gradients (nn_ops.flush_wgrad_queue)
+        self.wgrad_stream, self.wgrad_inflight = None, []     # optional side stream for them (graph_step)
         me = weakref.ref(self)
         for i, p in enumerate(params):
             p._pdae_flat = (me, i)

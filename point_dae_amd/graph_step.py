@@ -47,6 +47,7 @@ def _warn_if_null_stream():
 
 
 SINK = os.environ.get('PDAE_GRAD_SINK', '1') != '0'
+WGRAD_SIDE = os.environ.get('PDAE_WGRAD_SIDE', '0') != '0'     # the stacks' weight gradients on a side stream (lab)
 _AVG_OK = {}
 
 
@@ -236,6 +237,8 @@ class GraphedTrainStep:
         # is None here and nothing else touches the flat gradient views until the gather below
         from . import nn_ops
         m.sink_armed, m.sink_written = SINK, set()
+        if WGRAD_SIDE and m.wgrad_stream is None:
+            m.wgrad_stream = torch.cuda.Stream()
         try:
             lx, ln = m(self.pts, self.pts, steps=self.steps,
                        rows=(self.vis[:nv], self.msk[:nm], self.vis32[:nv], self.msk32[:nm], self.order))
@@ -248,6 +251,7 @@ class GraphedTrainStep:
             try:
                 loss.backward()
                 nn_ops.flush_wgrad_queue(m)        # (stacks flush themselves; this catches a queue left by a cut)
+                nn_ops.join_wgrad_stream(m)
             finally:
                 m.wgrad_queue = []
                 if SINK:

@@ -407,12 +407,30 @@ def _sink_views(tags, weights):
 
 
 def flush_wgrad_queue(owner):
-    """Issue the queued weight gradients of an armed FlatDataParallel (see _TransformerBlock.backward)."""
+    """Issue the queued weight gradients of an armed FlatDataParallel (see _TransformerBlock.backward).
+    With `owner.wgrad_stream` set (graph_step: PDAE_WGRAD_SIDE=1) the launch goes to that side stream behind an event
+    on the current one -- a parallel branch of the captured graph: nothing downstream of the backward reads a weight
+    gradient, so the stack's ~1 ms of dW tiles may run beside the rest of the backward (the other stack's / the
+    embedder's chain of small launches); join_wgrad_stream() closes the branch before the gradients are gathered."""
     q = owner.wgrad_queue
     if q:
         flops = 2.0 * sum(dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in q)
-        probed_family('rows_wgrad', flops, lambda: _lib.rows_wgrad_multi(q))
+        side = getattr(owner, 'wgrad_stream', None)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.rows_wgrad_multi(q)
+            owner.wgrad_inflight.append(q)           # operands stay alive until the join
+        else:
+            probed_family('rows_wgrad', flops, lambda: _lib.rows_wgrad_multi(q))
         owner.wgrad_queue = []
+
+
+def join_wgrad_stream(owner):
+    side = getattr(owner, 'wgrad_stream', None)
+    if side is not None and owner.wgrad_inflight:
+        torch.cuda.current_stream().wait_stream(side)
+        owner.wgrad_inflight = []
 
 
 def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
