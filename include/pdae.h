@@ -458,7 +458,8 @@ int pdae_rows_wgrad(int M, int nprob, const float* const* dY,
  * every Transformer block of a stack -- in ONE launch (nprob <= 48): work = (128 x 128 output tile, 32-row chunk) units
  * of all layers in one list, dealt in equal contiguous ranges to one residency of the chip, partial tiles added in
  * block order by the reduction launch that follows.  A step's backward thereby issues its blocks' weight gradients as
- * two large launches (decoder stack, encoder stack) instead of one small launch per block. */
+ * two large launches (decoder stack, encoder stack) instead of one small launch per block.  Output tiles are 128 x 384
+ * when every K of the group is a multiple of 384 (8 waves per block), 128 x 128 otherwise. */
 int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats);
 int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X, float* const* dW,
                           float* const* db, const int* Ns, const int* Ks, float* workspace, pdae_stream_t stream);

@@ -450,8 +450,11 @@ void rows_gemm_kernel(const Args p) {
 constexpr int WG_MAX = 48;               // layers per launch: 12 Transformer blocks x 4 (the by-value struct is 3.1 KB)
 constexpr int TBK = 16;                 // rows per LDS slab
 constexpr int WCH = 32;                 // rows per work unit
-constexpr int WTM = 128, WTN = 128;     // output tile (n of dY x k of X)
-constexpr int WSLOT = WTM * WTN + WTM;  // floats per partial: the tile + the column sums of its dY band
+constexpr int WTM = 128;                // output tile rows (n of dY)
+// output tile columns (k of X): 128 (4 waves, any shape) or 384 (8 waves: the Transformer blocks' K = 384 / 1536 --
+// a unit then moves 64 KB for 3.1 MFLOP instead of 32 KB for 1.05, and the stack-level launches stream their operands
+// from HBM: 48 instead of 32 FLOP per byte)
+constexpr int wslot(int TN) { return WTM * TN + WTM; }   // floats per partial: the tile + the column sums of its dY band
 struct WgradProb {
   const float* dY;    // [M, N]
   const float* X;     // [M, K]
@@ -466,7 +469,7 @@ struct WgradProb {
 struct WgradArgs {
   int nprob, tiles, blocks, slots;              // grid; slots per block
   long long units;
-  float* partials;                              // [blocks][slots][WSLOT]
+  float* partials;                              // [blocks][slots][wslot(TN)]
   WgradProb p[WG_MAX];
 };
 
@@ -492,15 +495,22 @@ __device__ __forceinline__ int wg_tile_of_unit(const WgradArgs& g, long long u) 
   return P.tile0 + (int)((u - P.unit0) / P.chunks);
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
-  constexpr int TM = WTM, TN = WTN, WN = TN / 64, NT = 256;
+template <int TN, int NT>
+__global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
+  constexpr int TM = WTM;
+  constexpr int WNV = NT / 128;                       // waves along k (two along n)
+  constexpr int WK = TN / WNV;                        // columns of a wave: 64 (TN 128) or 96 (TN 384)
+  constexpr int TJ = WK / 32;                         // MFMA tiles of a wave along k
+  constexpr int WSLOT = wslot(TN);
   constexpr int ROW4 = (TM + TN) / 4;                 // float4 per staged row
   constexpr int SLOTS = (TBK * ROW4 + NT - 1) / NT;   // float4 per thread per slab
-  static_assert(NT % ROW4 == 0 && (TBK * ROW4) % NT == 0, "slot layout");
+  static_assert(NT % ROW4 == 0 && (TBK * ROW4) % NT == 0 && WK % 32 == 0, "slot layout");
   constexpr int RSTEP = NT / ROW4;
-  __shared__ float lds[2][TBK * (TM + TN)];
+  extern __shared__ float wg_lds[];                   // [2][TBK * (TM + TN)]
+  float* const lds0 = wg_lds;
+  float* const lds1 = wg_lds + TBK * (TM + TN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave / WNV, wn = wave % WNV;
   const int r = lane & 31, h = lane >> 5;
   const int srow0 = tid / ROW4, scol = (tid % ROW4) * 4;   // a thread stages the SAME four columns in every slot
   const bool isb = scol >= TM;
@@ -537,38 +547,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
         if (ok && gm < mend) rg[i] = *reinterpret_cast<const float4*>(src + (size_t)gm * ld);
       }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](float* buf) {
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
         const float4 v = rg[i];
         if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
-        *reinterpret_cast<float4*>(&lds[buf][(srow0 + i * RSTEP) * (TM + TN) + scol]) = v;
+        *reinterpret_cast<float4*>(&buf[(srow0 + i * RSTEP) * (TM + TN) + scol]) = v;
       }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][TJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     gload(mbeg);
-    lstore(0);
+    lstore(lds0);
     __syncthreads();
     int buf = 0;
     for (int mt = mbeg; mt < mend; mt += TBK) {
       const bool more = mt + TBK < mend;
       if (more) gload(mt + TBK);
-      const float* T = lds[buf] + h * (TM + TN);
-      float fa[2][2][2], fb[2][2][2];   // [stage][step within stage][tile]
-#define PDAE_WG_FREAD(st, t)                                  \
-      {                                                       \
-        const float* row = T + 2 * (t) * (TM + TN);           \
-        fa[st][(t) & 1][0] = row[wm * 64 + r];                \
-        fa[st][(t) & 1][1] = row[wm * 64 + 32 + r];           \
-        fb[st][(t) & 1][0] = row[TM + wn * 64 + r];           \
-        fb[st][(t) & 1][1] = row[TM + wn * 64 + 32 + r];      \
+      const float* T = (buf ? lds1 : lds0) + h * (TM + TN);
+      float fa[2][2][2], fb[2][2][TJ];   // [stage][step within stage][tile]
+#define PDAE_WG_FREAD(st, t)                                        \
+      {                                                             \
+        const float* row = T + 2 * (t) * (TM + TN);                 \
+        fa[st][(t) & 1][0] = row[wm * 64 + r];                      \
+        fa[st][(t) & 1][1] = row[wm * 64 + 32 + r];                 \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j)              \
+          fb[st][(t) & 1][j] = row[TM + wn * WK + j * 32 + r];      \
       }
       PDAE_WG_FREAD(0, 0)
       PDAE_WG_FREAD(0, 1)
@@ -581,28 +591,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][0], fb[cur][q][0], acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][0], fb[cur][q][1], acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][1], fb[cur][q][0], acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][1], fb[cur][q][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][i], fb[cur][q][j], acc[i][j], 0, 0, 0);
         }
         if (tt == 0) __builtin_amdgcn_sched_group_barrier(0x020, SLOTS, 0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4 * TJ; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (tt + 1 < TBK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          else if (q < SLOTS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (tt + 1 < TBK / 4) {
+            if (q < 2 * (2 + TJ)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          } else if (q < SLOTS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
-        if (tt == TBK / 4 - 2 && more) lstore(buf ^ 1);
+        if (tt == TBK / 4 - 2 && more) lstore(buf ? lds0 : lds1);
       }
 #undef PDAE_WG_FREAD
       __syncthreads();
       buf ^= 1;
     }
-    // ---- the partial tile (whole 128 x 128, edges included: the reduction stores what is inside)
+    // ---- the partial tile (whole TM x TN, edges included: the reduction stores what is inside)
     if (P.db != nullptr && bx == 0) {
       // the RSTEP threads that staged the same four columns add up in thread order (fixed)
-      float* red = &lds[0][0];                          // [RSTEP][TM]; the slab buffers are free now
+      float* red = lds0;                                // [RSTEP][TM]; the slab buffers are free now
       if (!isb) *reinterpret_cast<float4*>(red + srow0 * TM + scol) = asum;
       __syncthreads();
       if (tid < TM) {
@@ -614,13 +626,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
       __syncthreads();                                  // red is the next segment's slab buffer
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          slot[row * TN + wn * 64 + j * 32 + r] = acc[i][j][e];
+          slot[row * TN + wn * WK + j * 32 + r] = acc[i][j][e];
         }
   }
 }
@@ -632,10 +644,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 // hundreds (the embedder's first conv: ONE tile, 512 partials -- a single lane walking them took
 // 121 us, PL = 8 takes 15).  Elements outside the weight are skipped.  The blocks with part == 0
 // also reduce the bias-gradient column sums.
-template <int PL>
+template <int PL, int TN>
 __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block) {
   constexpr int EPB = 256 / PL;              // float4 per block
-  constexpr int PARTS = WTM * WTN / 4 / EPB;  // blocks per tile
+  constexpr int PARTS = WTM * TN / 4 / EPB;   // blocks per tile
+  constexpr int WSLOT = wslot(TN);
   static_assert(EPB >= WTM / 4, "the bias sums of a tile fit one block");
   __shared__ float4 red[PL > 1 ? PL : 1][EPB];
   __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
@@ -643,13 +656,13 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   const WgradProb& P = g.p[wg_prob_of_tile(g, tile)];
   const int lt = tile - P.tile0;
   const int bx = lt % P.tk, by = lt / P.tk;
-  const int n0 = by * WTM, k0 = bx * WTN;
+  const int n0 = by * WTM, k0 = bx * TN;
   // blocks whose ranges meet this tile's units
   const long long u0 = P.unit0 + (long long)lt * P.chunks, u1 = u0 + P.chunks - 1;
   const int b0 = (int)(((u0 + 1) * g.blocks - 1) / g.units), b1 = (int)(((u1 + 1) * g.blocks - 1) / g.units);
   const int tid = threadIdx.x, pl = tid / EPB, el = tid % EPB;
-  const int e = (part * EPB + el) * 4;                               // element of the 128 x 128 tile
-  const int row = n0 + e / WTN, col = k0 + e % WTN;
+  const int e = (part * EPB + el) * 4;                               // element of the WTM x TN tile
+  const int row = n0 + e / TN, col = k0 + e % TN;
   const bool valid = row < P.N && col < P.K;
   const bool bias = part == 0 && bx == 0 && P.db && el < WTM / 4 && n0 + el * 4 < P.N;
   // block b's slot that holds this tile: the (tile - first tile of b's range)-th
@@ -666,7 +679,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
         if (b + q * PL <= b1) {
           const float* src = src_of(b + q * PL);
           if (valid) v[q] = *reinterpret_cast<const float4*>(src + e);
-          if (bias) w[q] = *reinterpret_cast<const float4*>(src + WTM * WTN + el * 4);
+          if (bias) w[q] = *reinterpret_cast<const float4*>(src + WTM * TN + el * 4);
         }
       }
 #pragma unroll
@@ -694,9 +707,9 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   if (bias) *reinterpret_cast<float4*>(P.db + n0 + el * 4) = bs;
 }
 
-template <int PL>
+template <int PL, int TN>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs g) {
-  wgrad_reduce_body<PL>(g, blockIdx.x);
+  wgrad_reduce_body<PL, TN>(g, blockIdx.x);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -899,7 +912,16 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   return check_launch("rows_gemm");
 }
 
-static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g) {
+// the wide tile when every layer's K is a multiple of 384 (the Transformer blocks: 384, 1536)
+static int wgrad_tile_width(int nprob, const int* Ks) {
+  static const char* force = getenv("PDAE_WGRAD_TN");       // A/B switch (tools/lab/ab.sh): 128 forces the narrow tile
+  if (force && atoi(force) == 128) return 128;
+  for (int q = 0; q < nprob; ++q)
+    if (Ks[q] % 384 != 0) return 128;
+  return 384;
+}
+
+static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g, int WTN) {
   int tiles = 0;
   long long units = 0;
   for (int q = 0; q < nprob; ++q) {
@@ -917,11 +939,12 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
     units += (long long)t * P.chunks;
   }
   g->nprob = nprob, g->tiles = tiles, g->units = units;
-  // one residency of the chip: 256 CUs x 2 blocks (32 KB of LDS, 212 registers each)
+  // one residency of the chip: 256 CUs x 2 blocks of 4 waves (128-wide tiles), x 1 block of 8 waves (384-wide)
 #ifdef PDAE_LAB_PLAN
-  static const int wg_blocks = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 512;
+  static const int wg_force = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 0;
+  const int wg_blocks = wg_force ? wg_force : (WTN == 384 ? 256 : 512);
 #else
-  constexpr int wg_blocks = 512;
+  const int wg_blocks = WTN == 384 ? 256 : 512;
 #endif
   g->blocks = (int)(units < wg_blocks ? units : wg_blocks);
   // slots per block: the most tiles one block's unit range touches (ranges are [b units / B, (b + 1) units / B))
@@ -951,10 +974,28 @@ int rows_wgrad_flush(hipStream_t) { return PDAE_OK; }
 extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats) {
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !Ns || !Ks || !floats) return bad_arg("rows_wgrad_multi_workspace: bad argument");
   static WgradArgs g;                      // (3 KB: off the stack; host-side query, one thread at a time like the plan cache)
-  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g);
+  const int tn = wgrad_tile_width(nprob, Ks);
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn);
   if (rc) return rc;
-  *floats = (long long)g.blocks * g.slots * WSLOT;
+  *floats = (long long)g.blocks * g.slots * wslot(tn);
   return PDAE_OK;
+}
+
+template <int TN>
+static void wgrad_launch(const WgradArgs& g, int pl, hipStream_t s) {
+  constexpr int NT = TN == 384 ? 512 : 256;
+  constexpr int PARTS1 = WTM * TN / 4 / 256;
+  const size_t lds = sizeof(float) * 2 * TBK * (WTM + TN);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<TN, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<TN, NT>), dim3(g.blocks), dim3(NT), lds, s, g);
+  if (pl == 1) hipLaunchKernelGGL((wgrad_reduce_kernel<1, TN>), dim3(g.tiles * PARTS1), dim3(256), 0, s, g);
+  else if (pl == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, TN>), dim3(g.tiles * PARTS1 * 4), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<8, TN>), dim3(g.tiles * PARTS1 * 8), dim3(256), 0, s, g);
 }
 
 extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X,
@@ -962,7 +1003,8 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
                                      float* workspace, pdae_stream_t stream) {
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !dY || !X || !dW || !Ns || !Ks) return bad_arg("rows_wgrad_multi: bad argument");
   WgradArgs g = {};
-  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g);
+  const int tn = wgrad_tile_width(nprob, Ks);
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn);
   if (rc) return rc;
   for (int q = 0; q < nprob; ++q) {
     if (!dW[q] || !dY[q] || !X[q]) return bad_arg("rows_wgrad_multi: null pointer");
@@ -971,20 +1013,14 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   if (!workspace) return bad_arg("rows_wgrad_multi: null workspace");
   hipStream_t s = as_stream(stream);
   g.partials = workspace;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(g.blocks), dim3(256), 0, s, g);
-  // partial lanes of the reduction by the most partials a tile can have: the shortest reduction spans the fewest
-  // units, the block ranges are units / blocks long
-  int min_chunks = g.p[0].chunks, max_chunks = g.p[0].chunks;
-  for (int q = 1; q < nprob; ++q) {
-    min_chunks = g.p[q].chunks < min_chunks ? g.p[q].chunks : min_chunks;
-    max_chunks = g.p[q].chunks > max_chunks ? g.p[q].chunks : max_chunks;
-  }
+  // partial lanes of the reduction by the most partials a tile can have: the longest reduction spans the most
+  // blocks, the block ranges are units / blocks long
+  int max_chunks = g.p[0].chunks;
+  for (int q = 1; q < nprob; ++q) max_chunks = g.p[q].chunks > max_chunks ? g.p[q].chunks : max_chunks;
   const long long most = (max_chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
-  (void)min_chunks;
-  if (pl == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(g.tiles * 16), dim3(256), 0, s, g);
-  else if (pl == 4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(g.tiles * 64), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(g.tiles * 128), dim3(256), 0, s, g);
+  if (tn == 384) wgrad_launch<384>(g, pl, s);
+  else wgrad_launch<128>(g, pl, s);
   return check_launch("rows_wgrad_multi");
 }
 

@@ -406,6 +406,9 @@ def _sink_views(tags, weights):
     return owner, idx, [owner.grad_views[i] for i in idx]
 
 
+WGRAD_PER_BLOCK = __import__('os').environ.get('PDAE_WGRAD_PER_BLOCK', '0') != '0'     # lab: one grouped launch per block
+
+
 def flush_wgrad_queue(owner):
     """Issue the queued weight gradients of an armed FlatDataParallel (see _TransformerBlock.backward).
     With `owner.wgrad_stream` set (graph_step: PDAE_WGRAD_SIDE=1) the launch goes to that side stream behind an event
@@ -717,7 +720,7 @@ class _TransformerBlock(torch.autograd.Function):
                                   (da2, h, views[3], None)]
             owner.sink_written.update(sink[1])
             first_of_stack = ctx.pos_grad is None or ctx.pos_grad[1] == 0
-            if first_of_stack:
+            if first_of_stack or WGRAD_PER_BLOCK:
                 flush_wgrad_queue(owner)
             dwqkv = dwproj = dw1 = dw2 = dbf1 = None
         elif tail:                             # two row counts: two groups
