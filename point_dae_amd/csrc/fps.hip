@@ -20,7 +20,6 @@
 // get key 0; if every point is skipped the reference returns index 0 and so
 // does key 0.
 #include <cmath>
-#include <cstdlib>
 
 #include "common.h"
 
@@ -164,13 +163,7 @@ extern "C" int pdae_furthest_point_sampling(int b, int n, int m, const float* da
   else if (n <= 128) launch_fps<64, 2>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
   else if (n <= 256) launch_fps<128, 2>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
   else if (n <= 512) launch_fps<256, 2>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
-  else if (n <= 1024) {
-    static const int lab_t = getenv("PDAE_FPS_T") ? atoi(getenv("PDAE_FPS_T")) : 0;     // lab: threads per cloud
-    if (lab_t == 64) launch_fps<64, 16>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
-    else if (lab_t == 128) launch_fps<128, 8>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
-    else if (lab_t == 512) launch_fps<512, 2>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
-    else launch_fps<256, 4>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
-  }
+  else if (n <= 1024) launch_fps<256, 4>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
   else if (n <= 2048) launch_fps<512, 4>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
   else if (n <= 4096) launch_fps<1024, 4>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
   else if (n <= 8192) launch_fps<1024, 8>(b, n, m, bs_log2, cols, dataset, idxs, centres, s);
