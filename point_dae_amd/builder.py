@@ -108,12 +108,23 @@ def build_opti_sche(base_model, config):
         scheduler = CosineLRScheduler(optimizer, t_initial=kw.get('t_max', kw.epochs), lr_min=min_lr,
                                       decay_rate=0.1, warmup_lr_init=kw.get('warmup_lr', 1.0e-6),
                                       warmup_t=kw.get('warmup_epochs', 0))
+    elif sc.type == 'LambdaLR':
+        # utils/misc.py:26-32 build_lambda_sche: lr x max(lr_decay ** (epoch / decay_step), lowest_decay)
+        if kw.get('decay_step') is None:
+            raise NotImplementedError('LambdaLR without decay_step')
+        scheduler = torch.optim.lr_scheduler.LambdaLR(
+            optimizer, lambda e: max(kw.lr_decay ** (e / kw.decay_step), kw.lowest_decay))
     elif sc.type == 'StepLR':
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, **kw)
     elif sc.type == 'function':
         scheduler = None
     else:
         raise NotImplementedError(sc.type)
+    if config.get('bnmscheduler') is not None:
+        # builder.py:147-151 adds a BatchNorm-momentum schedule (utils/misc.py:34-40, :97-127); no shipped pretraining
+        # YAML has one, and the captured step graphs bake the momentum into their kernel arguments: refused rather
+        # than silently ignored
+        raise NotImplementedError('bnmscheduler: BatchNorm momentum schedules are not supported by the graphed steps')
     return optimizer, scheduler
 
 

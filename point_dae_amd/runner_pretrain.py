@@ -164,8 +164,9 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
                     log('[Epoch %d/%d][Batch %d/%d] %.1f clouds/s Lossxyz = %.4f Lossnormal = %.4f lr = %.6f' % (
                         epoch, config.max_epoch, idx + 1, len(train_loader),
                         n * clean.shape[0] * world / dt, vals[0], vals[1], optimizer.param_groups[0]['lr']))
-        if scheduler is not None:
-            scheduler.step(epoch)
+        for item in (scheduler if isinstance(scheduler, list) else [scheduler]):      # runner_pretrain.py:237-241
+            if item is not None:
+                item.step(epoch)
         if val is not None and epoch % max(int(getattr(args, 'val_freq', 1)), 1) == 0:
             metrics = validate(base_model, val[0], val[1], epoch, config, log=log)
             if metrics.better_than(best_metrics):

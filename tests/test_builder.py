@@ -181,3 +181,21 @@ def test_writes_the_reference_checkpoint_layout(tmp_path):
     assert mine == LAYOUT['optimizer']['group_names']
     assert sorted({k for st in sd['optimizer']['state'].values() for k in st}) == LAYOUT['optimizer']['state_keys']
     assert len(sd['optimizer']['state']) == LAYOUT['optimizer']['state_entries']
+
+
+def test_lambda_lr_schedule_and_refused_bn_momentum_schedule():
+    """builder.py:117-118 -> utils/misc.py:26-32: lr(e) = lr * max(lr_decay ** (e / decay_step), lowest_decay)."""
+    from point_dae_amd.config import cfg_from_yaml_file
+    config = cfg_from_yaml_file(os.path.join(
+        ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.scheduler.type = 'LambdaLR'
+    config.scheduler.kwargs = type(config.scheduler.kwargs)(decay_step=21, lr_decay=0.76, lowest_decay=0.02)
+    net = torch.nn.Linear(4, 4)
+    opt, sch = builder.build_opti_sche(net, config)
+    lr = config.optimizer.kwargs.lr
+    for e in (0, 1, 21, 100, 400):
+        sch.step(e)
+        assert opt.param_groups[0]['lr'] == pytest.approx(lr * max(0.76 ** (e / 21), 0.02), rel=1e-12)
+    config.bnmscheduler = type(config.scheduler)(type='Lambda', kwargs={})
+    with pytest.raises(NotImplementedError, match='bnmscheduler'):
+        builder.build_opti_sche(net, config)
