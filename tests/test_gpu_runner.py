@@ -164,3 +164,40 @@ def test_resume_keeps_best_metric(tmp_path):
     epoch, best = builder.resume_model(torch.nn.Linear(3, 2), Args)
     assert epoch == 8 and best == pytest.approx(0.75)
     assert not Acc_Metric(0.6).better_than(Acc_Metric(best))
+
+
+def test_graphed_gradient_accumulation_equals_eager_accumulation():
+    """step_per_update = 2 (runner_pretrain.py:188-197): the replayed micro-steps (every replay ASSIGNS the flat gradient;
+    a second flat buffer carries the sum; the closing step adds it back and updates) against the plain eager path
+    (autograd accumulates into the flat buffer, train_step(update=False / True)), deterministic mode, two updates."""
+    from point_dae_amd import _lib, builder
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.runner_pretrain import train_step
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = _tiny_transformer_cfg()
+    config.step_per_update = 2
+    _lib.set_deterministic(True)
+    try:
+        torch.manual_seed(0)
+        net_a = builder.model_builder(config.model).cuda().train()
+        net_b = copy.deepcopy(net_a)
+        B = 8
+        x = torch.from_numpy(shapenet_like_clouds(B * 4, 1024, seed=6)).cuda().split(B)
+        model_a, model_b = FlatDataParallel(net_a), FlatDataParallel(net_b)
+        opt_a, _ = builder.build_opti_sche(model_a, config)
+        opt_b, _ = builder.build_opti_sche(model_b, config)
+        model_a.zero_grad()
+        _seed(21)
+        for i in range(4):
+            train_step(model_a, opt_a, config, x[i], x[i], update=(i % 2 == 1))
+        step = GraphedTrainStep(model_b, opt_b, config, B, 1024, warmup_eager=1)
+        assert step.spu == 2 and step.accum is not None
+        _seed(21)
+        for i in range(4):
+            step(x[i])
+        assert step.micro == 0
+        diff = (model_a.flat_param - model_b.flat_param).abs().max().item()
+        assert diff <= 2e-5 * model_a.flat_param.abs().max().item(), diff
+    finally:
+        _lib.set_deterministic(False)
