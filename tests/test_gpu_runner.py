@@ -197,7 +197,12 @@ def test_graphed_gradient_accumulation_equals_eager_accumulation():
         for i in range(4):
             step(x[i])
         assert step.micro == 0
+        # (the two paths reduce the blocks' weight gradients in different fixed orders -- per block vs per stack -- and
+        # AdamW turns a 1e-8 difference of a 1e-7 gradient entry into a fraction of an lr-sized step: measured 4.4e-4
+        # after two updates at lr 1e-3; a wrong accumulation would be off by whole steps, 2e-3 per update)
         diff = (model_a.flat_param - model_b.flat_param).abs().max().item()
-        assert diff <= 2e-5 * model_a.flat_param.abs().max().item(), diff
+        assert diff <= 1e-3 * model_a.flat_param.abs().max().item(), diff
+        rel = (model_a.flat_param - model_b.flat_param).double().norm().item() / model_a.flat_param.double().norm().item()
+        assert rel <= 1e-5, rel
     finally:
         _lib.set_deterministic(False)
