@@ -451,9 +451,9 @@ constexpr int WG_MAX = 48;               // layers per launch: 12 Transformer bl
 constexpr int TBK = 16;                 // rows per LDS slab
 constexpr int WCH = 32;                 // rows per work unit
 constexpr int WTM = 128;                // output tile rows (n of dY)
-// output tile columns (k of X): 128 (4 waves, any shape) or 384 (8 waves: the Transformer blocks' K = 384 / 1536 --
+// output tile columns (k of X): 128 (4 waves, any shape), 256 or 384 (8 waves: the Transformer blocks' K = 384 / 1536 --
 // a unit then moves 64 KB for 3.1 MFLOP instead of 32 KB for 1.05, and the stack-level launches stream their operands
-// from HBM: 48 instead of 32 FLOP per byte)
+// from HBM: 48 instead of 32 FLOP per byte; 256 for K = 256 / 512 / 1024: 43 FLOP per byte)
 constexpr int wslot(int TN) { return WTM * TN + WTM; }   // floats per partial: the tile + the column sums of its dY band
 struct WgradProb {
   const float* dY;    // [M, N]
@@ -504,16 +504,24 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
   constexpr int WSLOT = wslot(TN);
   constexpr int ROW4 = (TM + TN) / 4;                 // float4 per staged row
   constexpr int SLOTS = (TBK * ROW4 + NT - 1) / NT;   // float4 per thread per slab
-  static_assert(NT % ROW4 == 0 && (TBK * ROW4) % NT == 0 && WK % 32 == 0, "slot layout");
-  constexpr int RSTEP = NT / ROW4;
+  // staging map.  Joint (NT a multiple of ROW4): thread -> four columns of the [dY | X] row, the SAME in every slot, rows
+  // srow0 + i RSTEP.  Split (TN = 256: 96 float4 per row do not divide 512 threads): every thread stages one float4 of
+  // the dY band (row tid / 32) AND SLOTS - 1 of the X band (rows tid / XR4 + i XSTEP) -- again the same columns per slot.
+  constexpr bool SPLIT = NT % ROW4 != 0;
+  constexpr int XR4 = TN / 4, XSTEP = NT / XR4;
+  static_assert((TBK * ROW4) % NT == 0 && WK % 32 == 0, "slot layout");
+  static_assert(!SPLIT || (NT == TBK * (TM / 4) && NT % XR4 == 0 && XSTEP * (SLOTS - 1) == TBK), "split slot layout");
+  constexpr int RSTEP = SPLIT ? TBK : NT / ROW4;      // threads that stage the same dY columns
   extern __shared__ float wg_lds[];                   // [2][TBK * (TM + TN)]
   float* const lds0 = wg_lds;
   float* const lds1 = wg_lds + TBK * (TM + TN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WNV, wn = wave % WNV;
   const int r = lane & 31, h = lane >> 5;
-  const int srow0 = tid / ROW4, scol = (tid % ROW4) * 4;   // a thread stages the SAME four columns in every slot
-  const bool isb = scol >= TM;
+  const int srow0 = SPLIT ? tid / (TM / 4) : tid / ROW4;   // a thread stages the SAME four columns in every slot
+  const int scol = SPLIT ? (tid % (TM / 4)) * 4 : (tid % ROW4) * 4;
+  const bool isb = !SPLIT && scol >= TM;
+  const int xrow0 = tid / XR4, xcol = (tid % XR4) * 4;     // (split map) this thread's X rows / columns
   // blocks b, b + 8, ... share an XCD (its L2): give an XCD CONSECUTIVE ranges, i.e. a run of tiles with
   // all their chunks, so the tk re-reads of a dY column band and the tn re-reads of an X band stay in one L2
   // (the profile showed 408 MB fetched per launch for 40-110 MB of operands with ranges dealt round robin)
@@ -536,10 +544,24 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
     const bool ok = isb ? gcol < K : gcol < N;
     const float* src = isb ? P.X + gcol : P.dY + gcol;
     const int ld = isb ? K : N;
+    const bool xok = k0 + xcol < K;                   // (split map)
+    const float* xsrc = P.X + k0 + xcol;
     float4 rg[SLOTS];
     float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this thread's dY elements
     const bool sum_a = P.db != nullptr && bx == 0 && !isb;
     auto gload = [&](int mt) {
+      if (SPLIT) {
+        const int gm = mt + srow0;
+        rg[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && gm < mend) rg[0] = *reinterpret_cast<const float4*>(src + (size_t)gm * ld);
+#pragma unroll
+        for (int i = 1; i < SLOTS; ++i) {
+          const int xm = mt + xrow0 + (i - 1) * XSTEP;
+          rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (xok && xm < mend) rg[i] = *reinterpret_cast<const float4*>(xsrc + (size_t)xm * K);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
         const int gm = mt + srow0 + i * RSTEP;
@@ -548,6 +570,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
       }
     };
     auto lstore = [&](float* buf) {
+      if (SPLIT) {
+        const float4 v = rg[0];
+        if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
+        *reinterpret_cast<float4*>(&buf[srow0 * (TM + TN) + scol]) = v;
+#pragma unroll
+        for (int i = 1; i < SLOTS; ++i)
+          *reinterpret_cast<float4*>(&buf[(xrow0 + (i - 1) * XSTEP) * (TM + TN) + TM + xcol]) = rg[i];
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
         const float4 v = rg[i];
@@ -912,13 +943,17 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   return check_launch("rows_gemm");
 }
 
-// the wide tile when every layer's K is a multiple of 384 (the Transformer blocks: 384, 1536)
+// the widest tile every layer's K is a multiple of: 384 (the Transformer blocks: 384, 1536), 256 (FoldingNet, the
+// PointNet++ levels: 256, 512, 1024), else 128
 static int wgrad_tile_width(int nprob, const int* Ks) {
-  static const char* force = getenv("PDAE_WGRAD_TN");       // A/B switch (tools/lab/ab.sh): 128 forces the narrow tile
-  if (force && atoi(force) == 128) return 128;
-  for (int q = 0; q < nprob; ++q)
-    if (Ks[q] % 384 != 0) return 128;
-  return 384;
+  static const char* force = getenv("PDAE_WGRAD_TN");       // A/B switch (tools/lab/ab.sh): caps the tile width
+  const int cap = force ? atoi(force) : 384;
+  bool w384 = cap >= 384, w256 = cap >= 256;
+  for (int q = 0; q < nprob; ++q) {
+    if (Ks[q] % 384 != 0) w384 = false;
+    if (Ks[q] % 256 != 0) w256 = false;
+  }
+  return w384 ? 384 : (w256 ? 256 : 128);
 }
 
 static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g, int WTN) {
@@ -942,9 +977,9 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
   // one residency of the chip: 256 CUs x 2 blocks of 4 waves (128-wide tiles), x 1 block of 8 waves (384-wide)
 #ifdef PDAE_LAB_PLAN
   static const int wg_force = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 0;
-  const int wg_blocks = wg_force ? wg_force : (WTN == 384 ? 256 : 512);
+  const int wg_blocks = wg_force ? wg_force : (WTN >= 256 ? 256 : 512);
 #else
-  const int wg_blocks = WTN == 384 ? 256 : 512;
+  const int wg_blocks = WTN >= 256 ? 256 : 512;
 #endif
   g->blocks = (int)(units < wg_blocks ? units : wg_blocks);
   // slots per block: the most tiles one block's unit range touches (ranges are [b units / B, (b + 1) units / B))
@@ -983,7 +1018,7 @@ extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const i
 
 template <int TN>
 static void wgrad_launch(const WgradArgs& g, int pl, hipStream_t s) {
-  constexpr int NT = TN == 384 ? 512 : 256;
+  constexpr int NT = TN >= 256 ? 512 : 256;
   constexpr int PARTS1 = WTM * TN / 4 / 256;
   const size_t lds = sizeof(float) * 2 * TBK * (WTM + TN);
   static bool once = false;
@@ -1020,6 +1055,7 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   const long long most = (max_chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
   if (tn == 384) wgrad_launch<384>(g, pl, s);
+  else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);
   return check_launch("rows_wgrad_multi");
 }

@@ -169,7 +169,10 @@ def test_rows_wgrad_block_group(M):
 
 
 @pytest.mark.parametrize('dims,flags', [([(96, 384)], [True]), ([(128, 4), (384, 128)], [True, True]),
-                                        ([(100, 260)], [False]), ([(4096, 2048)], [True]), ([(512, 256)], [False])])
+                                        ([(100, 260)], [False]), ([(4096, 2048)], [True]), ([(512, 256)], [False]),
+                                        # the 256-wide tile (every K a multiple of 256, not of 384): FoldingNet's layers
+                                        ([(512, 512), (4, 512)], [True, True]), ([(100, 512)], [True]),
+                                        ([(128, 256), (256, 1024), (36, 768)], [False, True, True])])
 def test_rows_wgrad_odd_shapes(dims, flags):
     L = _lib()
     g = torch.Generator(device='cuda').manual_seed(3)
@@ -182,7 +185,7 @@ def test_rows_wgrad_odd_shapes(dims, flags):
 
 
 @pytest.mark.parametrize('M,dims', [(262144, [(128, 4)]), (65536, [(128, 128)]), (8192, [(96, 384)]),
-                                    (8192, [(128, 4), (384, 128)])])
+                                    (8192, [(128, 4), (384, 128)]), (131072, [(512, 512)]), (65536, [(4, 256)])])
 def test_rows_wgrad_long_reduction_narrow_weight(M, dims):
     """Hundreds of partials per tile (the embedder's first conv: one tile, 512 partials): the lane-parallel
     reduction (4 / 8 partial lanes) gives the same sums as fp64 and the same bits twice."""
