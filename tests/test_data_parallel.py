@@ -31,7 +31,7 @@ def _data():
 
 
 def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+    os.environ.update(MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from point_dae_amd.data_parallel import FlatDataParallel
@@ -129,7 +129,7 @@ def test_late_parameters_sit_at_the_ends():
 
 
 def _slices_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+    os.environ.update(MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from point_dae_amd.data_parallel import FlatDataParallel
@@ -161,7 +161,7 @@ def test_sliced_allreduce_equals_one_flat_allreduce(tmp_path):
 
 
 def _accum_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+    os.environ.update(MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from point_dae_amd.data_parallel import FlatDataParallel

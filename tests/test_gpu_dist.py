@@ -22,11 +22,51 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, split=None, det=False):
+def _rank_env(rank, world, port):
+    """Rendezvous of a spawned rank: loopback only (gloo otherwise resolves the box's hostname, which need not resolve),
+    and a rank that is stuck dumps every thread's stack and exits instead of hanging the suite."""
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK='0', GLOO_SOCKET_IFNAME='lo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+
+
+def _init(backend, rank, world):
+    import datetime
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+
+
+def _spawn(fn, args, nprocs, limit=180):
+    """mp.spawn with a bounded join: ranks still alive after `limit` seconds are killed.  One re-run on such a
+    time-out, with a warning -- a stuck rendezvous once stalled the whole suite for 19 minutes on one box and never
+    again in ten loops; a failure of the ranks themselves (exception, wrong result) is never retried."""
+    import time
+    import warnings
+    for attempt in (0, 1):
+        ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+        deadline = time.monotonic() + limit
+        timed_out = False
+        while not ctx.join(timeout=5):
+            if time.monotonic() > deadline:
+                timed_out = True
+                for proc in ctx.processes:
+                    if proc.is_alive():
+                        proc.kill()
+                for proc in ctx.processes:
+                    proc.join(10)
+                break
+        if not timed_out:
+            return
+        if attempt == 0:
+            warnings.warn('%s: ranks still running after %d s, killed; running them once more' % (fn.__name__, limit))
+            args = tuple(_free_port() if i == 1 else a for i, a in enumerate(args))     # a fresh rendezvous port
+    raise AssertionError('%s: ranks still running after %d s, twice' % (fn.__name__, limit))
+
+
+def _worker(rank, world, port, out, split=None, det=False):
+    _rank_env(rank, world, port)
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init('gloo', rank, world)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import sys
     sys.path.insert(0, root)
@@ -68,7 +108,7 @@ def _worker(rank, world, port, out, split=None, det=False):
 
 def test_two_ranks_graphed_step_stay_in_sync(tmp_path):
     out = str(tmp_path / 'r.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    _spawn(_worker, (2, _free_port(), out), 2)
     r = torch.load(out)
     assert r['same'], 'replicas diverged'
     assert r['graphs'] >= 1
@@ -83,7 +123,7 @@ def test_two_ranks_split_step_overlapped_allreduce(tmp_path):
     res = {}
     for split in (True, False):
         out = str(tmp_path / ('r%d.pt' % split))
-        mp.spawn(_worker, args=(2, _free_port(), out, split, True), nprocs=2, join=True)
+        _spawn(_worker, (2, _free_port(), out, split, True), 2)
         res[split] = torch.load(out)
         assert res[split]['same'], 'replicas diverged (split=%s)' % split
         assert res[split]['split'] == split and res[split]['graphs'] >= 1
@@ -103,7 +143,7 @@ def test_bench_two_ranks_code_path(launcher):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PDAE_BENCH_BACKEND='gloo')
+    env = dict(os.environ, PDAE_BENCH_BACKEND='gloo', GLOO_SOCKET_IFNAME='lo')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '8',
@@ -136,10 +176,9 @@ def test_bench_refuses_more_ranks_than_gpus():
 
 
 def _nccl_one_rank(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    _rank_env(0, 1, port)
     torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1)
+    _init('nccl', 0, 1)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import sys
     sys.path.insert(0, root)
@@ -173,7 +212,7 @@ def test_rccl_backend_runs_the_average_path(tmp_path):
     multi-GPU step -- graph_step._start_average on slices (async_op, ReduceOp.AVG) and _average_gradients: RCCL links,
     initialises a communicator, accepts AVG on fp32 views of the flat gradient buffer and returns it unchanged."""
     out = str(tmp_path / 'rccl.pt')
-    mp.spawn(_nccl_one_rank, args=(1, _free_port(), out), nprocs=1, join=True)
+    _spawn(_nccl_one_rank, (1, _free_port(), out), 1)
     r = torch.load(out)
     assert r['backend'] == 'nccl'
     assert r['equal'], 'an average over one rank changed the gradients'
@@ -181,10 +220,9 @@ def test_rccl_backend_runs_the_average_path(tmp_path):
 
 
 def _sync_bn_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+    _rank_env(rank, world, port)
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init('gloo', rank, world)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import sys
     sys.path.insert(0, root)
@@ -238,7 +276,7 @@ def test_two_ranks_sync_bn_statistics_span_the_replicas(tmp_path):
     Two ranks with half of the groups each reproduce ONE process running the fused embedder on all groups: tokens,
     running estimates and (summed over the ranks) every parameter gradient."""
     out = str(tmp_path / 'sbn.pt')
-    mp.spawn(_sync_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    _spawn(_sync_bn_worker, (2, _free_port(), out), 2)
     r = torch.load(out)
 
     gmax = max(g.abs().max().item() for g in r['lay_g'])
