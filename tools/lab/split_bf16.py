@@ -25,10 +25,15 @@ SO2 = os.path.join(ROOT, 'gpurun_out', 'libsplit_bf16_2.so')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC',
                        os.path.join(ROOT, 'tools', 'lab', 'split_bf16_gemm2.hip'), '-o', SO2])
 lab2 = ctypes.CDLL(SO2)
+SO3 = os.path.join(ROOT, 'gpurun_out', 'libsplit_bf16_3.so')
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC',
+                       os.path.join(ROOT, 'tools', 'lab', 'split_bf16_gemm3.hip'), '-o', SO3])
+lab3 = ctypes.CDLL(SO3)
 vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 lab.lab_split3.argtypes = [i64, vp, vp, vp]
 lab.lab_gemm_bf16x3.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp]
 lab2.lab_gemm_split.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp]
+lab3.lab_gemm_split3.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp]
 
 
 def stream():
@@ -79,6 +84,14 @@ def main():
         row += f" {ts:10.1f} || in-kernel split:"
         for nprod in (6, 3, 1):
             f = lambda: lab2.lab_gemm_split(M, N, K, A.data_ptr(), W.data_ptr(), C.data_ptr(), nprod, stream())
+            C.zero_()
+            t = timed(f)
+            f()
+            err = (C.double() - ref).abs().max().item() / scale
+            row += f" x{nprod} {t:7.1f} us {err:8.1e}"
+        row += " || interleaved:"
+        for nprod in (6, 3, 1):
+            f = lambda: lab3.lab_gemm_split3(M, N, K, A.data_ptr(), W.data_ptr(), C.data_ptr(), nprod, stream())
             C.zero_()
             t = timed(f)
             f()
