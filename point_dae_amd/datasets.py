@@ -33,11 +33,43 @@ from .registry import DATASETS
 from .synthetic import labelled_clouds, shapenet_like_clouds
 
 AFFINE = ('translate', 'scale_nonorm', 'rotate', 'reflection', 'shear')
+AFFINE_V2 = ('translate', 'scale_nonorm', 'rotate_level1', 'reflection', 'shear_1p')        # corrupt_util.py:1043
+# 'affine_rN[_v2]' of corrupt_util.corrupt_data (:1053-1088): 1..N distinct maps of the pool in random order
+_AFFINE_SETS = {'affine_r3': (AFFINE, 3), 'affine_r5': (AFFINE, 5), 'affine_r3_v2': (AFFINE_V2, 3), 'affine_r5_v2': (AFFINE_V2, 5)}
+# the single maps of the reference's `corruptions` table (corrupt_util.py:984-1038) as (kind, parameter); the parameter
+# ranges are pinned on the live functions' recorded draws (tests/golden/make_loader_variant_fixtures.py)
+_MAP_PARAMS = {
+    'translate': ('translate', 0.5), 'translate_tiny': ('translate', 0.1), 'translate_middle': ('translate', 0.3),
+    'translate_too_large': ('translate', 0.8),                                              # x + U(-s, s)^3       :130-177
+    'scale_nonorm': ('scale', 2.0), 'scale_nonorm_1p5': ('scale', 1.5), 'scale_nonorm_4': ('scale', 4.0),
+    'scale_nonorm_10': ('scale', 10.0),                                                     # x * U(1/s, s)^3      :82-128
+    'rotate': ('rotate', math.pi),                                                          # Rz Ry Rx, U(-c, c)^3 :241-263
+    'rotate_level0': ('rotate', math.pi / 5), 'rotate_level1': ('rotate', 2 * math.pi / 5),
+    'rotate_level2': ('rotate', 3 * math.pi / 5), 'rotate_level3': ('rotate', 4 * math.pi / 5),
+    'rotate_level4': ('rotate', math.pi),                                                   # c = pi / 5 (l + 1)   :265-388
+    'rotate_z': ('rotate_z_level', math.pi / 5),                                            # c = pi / 5 (level+1) :537-570
+    'reflection': ('reflection', None),                                                     # diag(+-1)            :390-409
+    'shear': ('shear', 0.5), 'shear_p1': ('shear', 0.1), 'shear_p3': ('shear', 0.3), 'shear_p8': ('shear', 0.8),
+    'shear_1p': ('shear', 1.0), 'shear_2p': ('shear', 2.0),                                 # off-diagonals U(-c, c) :412-518
+    'shear_small': ('shear_level', 0.02),                                                   # c = 0.02 (level + 1) :520-535
+    # augment_data (:1105-1175): PointcloudScale U(2/3, 3/2)^3, PointcloudTranslate U(-.2, .2)^3, full-circle rotations
+    'aug_scale': ('scale', 1.5), 'aug_translate': ('translate', 0.2), 'aug_rotate_z': ('rotate_z', math.pi),
+    'aug_rotate': ('rotate', math.pi),
+}
+_JITTER = {'jitter': None, 'jitter_p01': 0.01, 'jitter_p03': 0.03, 'jitter_p05': 0.05, 'jitter_p1': 0.1}   # :179-239
+# dropout_local variants (:590-828): (drop ratio or None = U(.1, .5), exclusive upper bound of randint(1, hi) clusters or
+# 0 = exactly one cluster without a draw)
+_DROPOUT_LOCAL = {'dropout_local': (None, 8), 'dropout_local_c5d1': (0.1, 5), 'dropout_local_c5d3': (0.3, 5),
+                  'dropout_local_c5d5': (0.5, 5), 'dropout_local_c5d7': (0.7, 5), 'dropout_local_c5d9': (0.9, 5),
+                  'dropout_local_c1d3': (0.3, 0), 'dropout_local_c2d3': (0.3, 2), 'dropout_local_c3d3': (0.3, 3),
+                  'dropout_local_c8d3': (0.3, 8)}
+_SCALE_SINGLE = (1.6, 1.7, 1.8, 1.9, 2.0)                                                   # :71-80, by level
 _PASS = ('clean', 'dropout_patch_pointmae', 'Drop-Patch')
 _AUGS = ('clean', 'norm', 'scale', 'translate', 'rotate_z', 'rotate')          # corrupt_util.augment_data :1155-1175
-_CORRUPTIONS = ('affine_r3', 'dropout_local') + AFFINE + ('rotate_z', 'scale', 'jitter', 'add_global', 'add_local',
-                                                          'nonuniform_density')
-
+_CORRUPTIONS = (tuple(_AFFINE_SETS) + tuple(n for n in _MAP_PARAMS if not n.startswith('aug_')) + tuple(_JITTER)
+                + tuple(_DROPOUT_LOCAL) + ('scale', 'scale_single', 'add_global', 'add_local', 'nonuniform_density'))
+# names some reference YAMLs carry that the reference's own dispatcher does not know (a KeyError there too)
+_UNKNOWN_UPSTREAM = ('affine_r3_tiny', 'affine_r3_middle', 'scan')
 
 
 def _rot(a):
@@ -47,34 +79,53 @@ def _rot(a):
     return Rz @ Ry @ Rx
 
 
-def draw_affine_map(rng, name):
-    """One map x -> x M + tr with the numpy versions' parameters (corrupt_util.py): 'translate' ADDS
-    U(-.5,.5)^3 (:130-141), 'scale_nonorm' U(.5,2)^3 (:82-93), 'rotate' Rz Ry Rx with angles U(-pi,pi)
-    (:241-263), 'rotate_z' (:537-570), 'reflection' diag(+-1) (:390-409), 'shear' U(-.5,.5) off-diagonals
-    (:412-428); the augmentations 'aug_scale' U(2/3,3/2)^3 (:1105-1108), 'aug_translate' U(-.2,.2)^3
-    (:1110-1112)."""
+def map_needs_level(name):
+    return _MAP_PARAMS[name][0] in ('rotate_z_level', 'shear_level')
+
+
+def affine_map_from_draw(name, draw):
+    """(M, tr) of the map `name` for the values the numpy version draws (one uniform / choice call, corrupt_util.py)."""
+    kind = _MAP_PARAMS[name][0]
+    kind = kind[:-6] if kind.endswith('_level') else kind
+    draw = np.asarray(draw, np.float64).reshape(-1)
     M, tr = np.eye(3), np.zeros(3)
-    if name == 'translate':
-        tr = rng.uniform(-0.5, 0.5, 3)
-    elif name == 'aug_translate':
-        tr = rng.uniform(-0.2, 0.2, 3)
-    elif name == 'scale_nonorm':
-        M = np.diag(rng.uniform(0.5, 2.0, 3))
-    elif name == 'aug_scale':
-        M = np.diag(rng.uniform(2.0 / 3.0, 1.5, 3))
-    elif name == 'rotate':
-        M = _rot(rng.uniform(-math.pi, math.pi, 3))
-    elif name == 'rotate_z':
-        a = rng.uniform(-math.pi, math.pi)
+    if kind == 'translate':
+        tr = draw
+    elif kind in ('scale', 'reflection'):
+        M = np.diag(draw)
+    elif kind == 'rotate':
+        M = _rot(draw)
+    elif kind == 'rotate_z':
+        a = draw[0]
         M = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
-    elif name == 'reflection':
-        M = np.diag(rng.choice(np.array([1.0, -1.0]), 3))
-    elif name == 'shear':
-        s = rng.uniform(-0.5, 0.5, 6)
-        M = np.array([[1, s[0], s[1]], [s[2], 1, s[3]], [s[4], s[5], 1]])
-    else:
-        raise NotImplementedError(name)
+    elif kind == 'shear':
+        M = np.array([[1, draw[0], draw[1]], [draw[2], 1, draw[3]], [draw[4], draw[5], 1]])
     return M, tr
+
+
+def draw_affine_map(rng, name, level=None):
+    """One map x -> x M + tr of the table above with the numpy versions' parameters (corrupt_util.py); `level` (0..4,
+    the dispatcher's random.choice, :1090-1092) only matters to 'rotate_z' and 'shear_small' and is drawn here when
+    not given."""
+    if name not in _MAP_PARAMS:
+        raise NotImplementedError(name)
+    kind, par = _MAP_PARAMS[name]
+    if kind.endswith('_level'):
+        level = int(rng.integers(0, 5)) if level is None else int(level)
+        kind, par = kind[:-6], par * (level + 1)
+    if kind == 'translate':
+        draw = rng.uniform(-par, par, 3)
+    elif kind == 'scale':
+        draw = rng.uniform(1.0 / par, par, 3)
+    elif kind == 'rotate':
+        draw = rng.uniform(-par, par, 3)
+    elif kind == 'rotate_z':
+        draw = rng.uniform(-par, par, 1)
+    elif kind == 'reflection':
+        draw = rng.choice(np.array([1.0, -1.0]), 3)
+    else:
+        draw = rng.uniform(-par, par, 6)
+    return affine_map_from_draw(name, draw)
 
 
 def draw_affine(rng, B, names_of):
@@ -89,13 +140,19 @@ def draw_affine(rng, B, names_of):
     return A.astype(np.float32), t.astype(np.float32)
 
 
-def draw_affine_r3(rng, B):
-    """'affine_r3' of corrupt_util.corrupt_data (:1062-1070) for B clouds: per cloud 1-3 distinct maps of
-    AFFINE in random order."""
+def draw_affine_set(rng, B, item='affine_r3'):
+    """'affine_r3' / 'affine_r5' / '..._v2' of corrupt_util.corrupt_data (:1053-1088) for B clouds: per cloud 1-N distinct
+    maps of the pool in random order."""
+    pool, most = _AFFINE_SETS[item]
+
     def names(r):
-        number = int(r.integers(1, 4))
-        return [AFFINE[int(i)] for i in r.choice(len(AFFINE), size=number, replace=False)]
+        number = int(r.integers(1, most + 1))
+        return [pool[int(i)] for i in r.choice(len(pool), size=number, replace=False)]
     return draw_affine(rng, B, names)
+
+
+def draw_affine_r3(rng, B):
+    return draw_affine_set(rng, B, 'affine_r3')
 
 
 
@@ -108,16 +165,18 @@ def sphere_points(rng, B, n):
                           axis=2).astype(np.float32)
 
 
-def draw_dropout_local(rng, B, P):
-    """The draws of corrupt_dropout_local (:590-612) for B clouds of P points: ratio U(.1,.5), 1-7
-    clusters, sizes = counts of `total` uniform cluster labels, and per cluster the seed as a rank among
-    the survivors (a shuffle's first element).  -> nclusters (B,), seed_rank (B,8), sizes (B,8) int32."""
+def draw_dropout_local(rng, B, P, item='dropout_local'):
+    """The draws of corrupt_dropout_local (:590-612) and its _cXdY variants (:614-828) for B clouds of P points: ratio
+    U(.1,.5) or the variant's constant, 1..hi-1 clusters, sizes = counts of `total` uniform cluster labels, and per
+    cluster the seed as a rank among the survivors (a shuffle's first element).
+    -> nclusters (B,), seed_rank (B,8), sizes (B,8) int32."""
+    ratio, hi = _DROPOUT_LOCAL[item]
     ncl = np.zeros(B, np.int32)
     rank = np.zeros((B, 8), np.int32)
     sizes = np.zeros((B, 8), np.int32)
     for b in range(B):
-        total = int(P * rng.uniform(0.1, 0.5))
-        n = int(rng.integers(1, 8))
+        total = int(P * (rng.uniform(0.1, 0.5) if ratio is None else ratio))
+        n = int(rng.integers(1, hi)) if hi else 1
         counts = np.bincount(rng.integers(0, n, total), minlength=n)
         alive = P
         ncl[b] = n
@@ -236,6 +295,9 @@ class ShapeNet:
         self.pc_path, self.data_path = config.get('PC_PATH'), config.get('DATA_PATH')
         self.whole = bool(config.get('whole', False))
         for item in self.corrupt_type:
+            if item in _UNKNOWN_UPSTREAM:
+                raise NotImplementedError('loader-side corruption %r: the reference\'s own dispatcher (corrupt_util.py:984-1096) '
+                                          'has no such entry either (KeyError there)' % item)
             if not (item in _PASS or 'dropout_global' in item or item in _CORRUPTIONS):
                 raise NotImplementedError('loader-side corruption %r (implemented: %s)' % (item, ', '.join(_CORRUPTIONS)))
         for item in self.aug_type:
@@ -282,9 +344,8 @@ class ShapeNet:
                 x = pipeline_norm_affine(x, True, maps if any(maps) else None)
                 maps = [[] for _ in range(B)]
                 continue
-            name = 'aug_' + item if item in ('scale', 'translate') else item
             for b in range(B):
-                maps[b].append(draw_affine_map(rng, name))
+                maps[b].append(draw_affine_map(rng, 'aug_' + item))
         while max(len(m) for m in maps) > 3:                        # more than three augmentation maps: extra passes
             x = pipeline_norm_affine(x, norm_first, [m[:3] for m in maps])
             maps, norm_first = [m[3:] for m in maps], False
@@ -300,23 +361,35 @@ class ShapeNet:
         sigma = noise = None
         tail = []
         for item in items:                                          # the affine maps and jitter of the list: one launch
-            if item == 'affine_r3':
+            if item in _AFFINE_SETS or item in _MAP_PARAMS:
+                if noise is not None or tail:
+                    raise NotImplementedError('an affine map behind jitter / an add / a drop in one corrupt_type list')
                 for b in range(B):
-                    number = int(rng.integers(1, 4))
-                    for i in rng.choice(len(AFFINE), size=number, replace=False):
-                        maps[b].append(draw_affine_map(rng, AFFINE[int(i)]))
-            elif item in AFFINE or item == 'rotate_z':
-                for b in range(B):
-                    maps[b].append(draw_affine_map(rng, item))
-            elif item == 'jitter' and not tail:                     # sigma = 0.01 (level + 1), level in 0..4 (:1090-1092)
-                sigma = _dev((0.01 * (rng.integers(0, 5, B) + 1.0)).astype(np.float32), dev)
+                    if item in _AFFINE_SETS:
+                        pool, most = _AFFINE_SETS[item]
+                        number = int(rng.integers(1, most + 1))
+                        for i in rng.choice(len(pool), size=number, replace=False):
+                            maps[b].append(draw_affine_map(rng, pool[int(i)]))
+                    else:
+                        maps[b].append(draw_affine_map(rng, item))
+            elif item in _JITTER and not tail and noise is None:
+                # sigma = 0.01 (level + 1), level in 0..4 (:179-191, :1090-1092), or the variant's constant
+                fixed = _JITTER[item]
+                sig = 0.01 * (rng.integers(0, 5, B) + 1.0) if fixed is None else np.full(B, fixed)
+                sigma = _dev(sig.astype(np.float32), dev)
                 noise = torch.randn((B, P, 3), device=dev, generator=self.gen)
+            elif item in _JITTER:
+                raise NotImplementedError('jitter behind an add / a drop / another jitter in one corrupt_type list')
             else:
                 tail.append(item)
-        if max(len(m) for m in maps) > 3:
-            raise NotImplementedError('more than three affine maps in one corrupt_type list')
-        y = pipeline_norm_affine(data[:, :P].contiguous() if stride != P else data, False, maps if any(maps) else None,
-                                 sigma, noise, stride) if (any(maps) or noise is not None or stride != P) else data
+        y = data
+        if any(maps) or noise is not None or stride != P:
+            passes = max(1, -(-max(len(m) for m in maps) // 3))      # three maps per launch ('affine_r5': up to two)
+            for c in range(passes):
+                last = c == passes - 1
+                part = [m[3 * c:3 * c + 3] for m in maps]
+                y = pipeline_norm_affine(y, False, part if any(part) else None, sigma if last else None,
+                                         noise if last else None, stride if last else None)
         cur, alive = P, None                                        # rows in use; survivors
         for item in tail:
             if item in ('add_global', 'add_local') and (alive is not None or cur != P):
@@ -347,13 +420,22 @@ class ShapeNet:
                 gate = rng.integers(0, 5, B) / 4.0 + 0.1
                 pipeline_density(y, cur, _dev(v.astype(np.float32), dev), _dev(gate.astype(np.float32), dev),
                                  torch.rand((B, cur), device=dev, generator=self.gen), alive)
-            elif item == 'dropout_local':
-                if cur != P or stride != P:
-                    raise NotImplementedError('dropout_local after an add in one corrupt_type list')
-                keep = dropout_local(y, *draw_dropout_local(rng, B, P)).to(torch.uint8)
-                alive = keep if alive is None else (alive & keep)
-            elif item == 'scale':                                   # U(.5,2)^3 then re-normalised (:59-69)
-                y = pipeline_norm_affine(pipeline_norm_affine(y, False, [[draw_affine_map(rng, 'scale_nonorm')] for _ in range(B)]), True)
+            elif item in _DROPOUT_LOCAL:
+                if cur != P or stride != P or alive is not None:
+                    raise NotImplementedError('%s after an add / another drop in one corrupt_type list' % item)
+                alive = dropout_local(y, *draw_dropout_local(rng, B, P, item)).to(torch.uint8)
+            elif item in ('scale', 'scale_single'):
+                # 'scale' U(.5,2)^3 (:59-69); 'scale_single' ONE factor U(1/s, s), s by level (:71-80); both re-normalised
+                if cur != P or stride != P or alive is not None:
+                    raise NotImplementedError('%s after an add / a drop in one corrupt_type list' % item)
+                if item == 'scale':
+                    ms = [[draw_affine_map(rng, 'scale_nonorm')] for _ in range(B)]
+                else:
+                    ms = []
+                    for b in range(B):
+                        s_ = _SCALE_SINGLE[int(rng.integers(0, 5))]
+                        ms.append([(np.eye(3) * rng.uniform(1.0 / s_, s_), np.zeros(3))])
+                y = pipeline_norm_affine(pipeline_norm_affine(y, False, ms), True)
             else:
                 raise NotImplementedError(item)
         if cur != P:                                                # rows behind P + added[b] are not part of cloud b

@@ -39,8 +39,9 @@ def test_draws_follow_the_reference_distributions():
 def test_unimplemented_loader_corruption_is_refused():
     """A corrupt_type the device pipeline does not implement must raise, never train on clean == corrupted."""
     from point_dae_amd.datasets import ShapeNet
-    with pytest.raises(NotImplementedError):
-        ShapeNet({'corrupt_type': ['scan'], 'device': 'cpu'})
+    for name in ('scan', 'affine_r3_tiny', 'affine_r3_middle', 'no_such_corruption'):
+        with pytest.raises(NotImplementedError):
+            ShapeNet({'corrupt_type': [name], 'device': 'cpu'})
     with pytest.raises(NotImplementedError):
         ShapeNet({'aug_type': ['jitter'], 'device': 'cpu'})
 
@@ -322,3 +323,133 @@ def test_hip_subset_edge_cases():
         assert torch.equal(out[b], y[b, order[torch.arange(12, device='cuda') % 5]])
     none = torch.zeros((B, P), dtype=torch.uint8, device='cuda')
     assert D.pipeline_subset(y, P, 8, keys, none).abs().max().item() == 0.0
+
+
+# ---- every entry of the reference's corruption table (tests/golden/make_loader_variant_fixtures.py) -------------------
+def _variants():
+    import json
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'loader_variants_ref.npz'))
+    return d, json.loads(str(d['meta']))
+
+
+def _uniform_call(call):
+    """(low, high, size) of a recorded np.random.uniform call."""
+    tag, args, kw = call
+    assert tag == 'np.uniform', call
+    low = kw['low'] if 'low' in kw else args[0]
+    high = kw['high'] if 'high' in kw else args[1]
+    size = kw['size'] if 'size' in kw else args[2]
+    return float(low), float(high), int(np.prod(size))
+
+
+def test_loader_tables_carry_the_reference_parameters():
+    """point_dae_amd/datasets.py's tables against the draws the LIVE reference functions made (arguments recorded):
+    every name of corrupt_util.corruptions (:984-1038) is implemented with the reference's ranges, the affine sets use
+    the reference's pools and counts, and the YAML names the reference itself cannot dispatch are refused as such."""
+    from point_dae_amd import datasets as D
+    _, meta = _variants()
+    table, P = meta['table'], 128
+    assert set(table) <= set(D._CORRUPTIONS), sorted(set(table) - set(D._CORRUPTIONS))
+    assert sorted(meta['unknown_upstream']) == sorted(D._UNKNOWN_UPSTREAM)
+    for item, rec in meta['sets'].items():
+        pool, most = D._AFFINE_SETS[item]
+        assert list(pool) == rec['pool'] and list(range(1, most + 1)) == rec['numbers'], item
+    assert set(meta['sets']) == set(D._AFFINE_SETS)
+    want_size = {'translate': 3, 'scale': 3, 'rotate': 3, 'rotate_z': 1, 'shear': 6}
+    for name, (kind, par) in D._MAP_PARAMS.items():
+        if name.startswith('aug_'):
+            continue
+        for level in range(5):
+            call = table[name][str(level)]['calls'][0]
+            k, c = kind, par
+            if kind.endswith('_level'):
+                k, c = kind[:-6], par * (level + 1)
+            if k == 'reflection':
+                assert call[0] == 'np.choice' and sorted(call[1][0]) == [-1, 1] and call[2]['size'] == 3, (name, call)
+                continue
+            low, high, size = _uniform_call(call)
+            lo_w, hi_w = (1.0 / c, c) if k == 'scale' else (-c, c)
+            assert size == want_size[k] and abs(low - lo_w) < 1e-12 and abs(high - hi_w) < 1e-12, (name, level, call)
+    for level in range(5):
+        low, high, size = _uniform_call(table['scale_single'][str(level)]['calls'][0])
+        s = D._SCALE_SINGLE[level]
+        assert size == 1 and abs(low - 1 / s) < 1e-12 and abs(high - s) < 1e-12
+        assert _uniform_call(table['scale'][str(level)]['calls'][0]) == (0.5, 2.0, 3)
+    for name, fixed in D._JITTER.items():
+        for level in range(5):
+            want = 0.01 * (level + 1) if fixed is None else fixed
+            assert abs(table[name][str(level)]['sigma'] - want) < 1e-9, (name, level)
+    for name, (ratio, hi) in D._DROPOUT_LOCAL.items():
+        for level in range(5):
+            calls = table[name][str(level)]['calls']
+            i = 0
+            if ratio is None:
+                assert _uniform_call(calls[0]) == (0.1, 0.5, 1), (name, calls[0])
+                i = 1
+            if hi:
+                assert calls[i][0] == 'np.randint' and calls[i][1] == [1, hi], (name, calls[i])
+                i += 1
+            labels = calls[i]                               # _gen_random_cluster_sizes: randint(num_clusters, size=total)
+            assert labels[0] == 'np.randint' and (hi or labels[1] == [1]), (name, labels)
+            if ratio is not None:
+                assert labels[2]['size'] == int(P * ratio), (name, labels)
+
+
+def test_affine_sets_draw_from_their_pools():
+    from point_dae_amd import datasets as D
+    rng = np.random.default_rng(5)
+    for item, (pool, most) in D._AFFINE_SETS.items():
+        counts = set()
+        for _ in range(200):
+            number = int(rng.integers(1, most + 1))
+            counts.add(number)
+        assert counts == set(range(1, most + 1))
+        A, t = D.draw_affine_set(rng, 64, item)
+        assert np.isfinite(A).all() and np.abs(np.linalg.det(A)).min() > 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_single_maps_reproduce_the_live_reference_functions():
+    """every single-map entry of the table, every level: the device kernel applied to the map built from the draw the
+    LIVE function made == that function's output (fp64 there, fp32 here: 2e-6 of the cloud's extent)."""
+    import torch
+    from point_dae_amd import datasets as D
+    d, meta = _variants()
+    cloud = torch.from_numpy(d['cloud']).cuda()[None]
+    checked = 0
+    for name in D._MAP_PARAMS:
+        if name.startswith('aug_'):
+            continue
+        for level in range(5):
+            draw, want = d['%s/%d/draw' % (name, level)], d['%s/%d/out' % (name, level)]
+            got = D.pipeline_norm_affine(cloud, False, [[D.affine_map_from_draw(name, draw)]])[0].cpu().numpy()
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (name, level)
+            checked += 1
+    for name in ('scale', 'scale_single'):                  # a scale, then re-normalised (corrupt_scale / _single)
+        for level in range(5):
+            draw, want = d['%s/%d/draw' % (name, level)], d['%s/%d/out' % (name, level)]
+            M = np.diag(draw) if name == 'scale' else np.eye(3) * draw[0]
+            got = D.pipeline_norm_affine(D.pipeline_norm_affine(cloud, False, [[(M, np.zeros(3))]]), True)[0].cpu().numpy()
+            assert np.abs(got - want).max() <= 2e-6, (name, level)
+            checked += 1
+    assert checked == 5 * (len([n for n in D._MAP_PARAMS if not n.startswith('aug_')]) + 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cor', [['affine_r5'], ['affine_r3_v2', 'dropout_local_c5d3'], ['affine_r5_v2', 'dropout_local_c5d3'],
+                                 ['jitter_p03'], ['scale_single'], ['shear_small'], ['rotate_z'], ['dropout_local_c1d3'],
+                                 ['dropout_local_c8d3'], ['translate_too_large'], ['scale_nonorm_10'], ['rotate_level2']])
+def test_device_dataset_runs_every_family_of_the_table(cor):
+    """the remaining names of the reference's table through ShapeNet.batch end to end (shapes, finiteness, survivor
+    counts of the fixed-ratio drops)"""
+    import torch
+    from point_dae_amd.datasets import ShapeNet
+    ds = ShapeNet({'npoints': 512, 'N_POINTS': 2048, 'bs': 6, 'steps_per_epoch': 2, 'device': 'cuda', 'seed': 4,
+                   'aug_type': ['norm'], 'corrupt_type': cor})
+    for _, _, corrupted, clean in ds:
+        assert corrupted.shape == (6, 512, 3) and clean.shape == (6, 512, 3)
+        assert torch.isfinite(corrupted).all() and not torch.equal(corrupted, clean)
+        if cor == ['scale_single']:
+            assert (corrupted.norm(dim=-1).amax(dim=1) <= 1 + 1e-5).all()
+        if cor in (['rotate_z'], ['rotate_level2'], ['dropout_local_c1d3'], ['dropout_local_c8d3']):
+            assert (corrupted.norm(dim=-1).amax(dim=1) <= 1 + 1e-4).all()      # rigid maps / drops stay in the unit sphere
