@@ -461,6 +461,17 @@ int pdae_rows_wgrad(int M, int nprob, const float* const* dY,
  * two large launches (decoder stack, encoder stack) instead of one small launch per block.  Output tiles are 128 x 384
  * when every K of the group is a multiple of 384 (8 waves per block), 128 x 128 otherwise. */
 int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats);
+/* One weight gradient dW[N,K] = sum_m dY[rowA(m)]^T x(X[rowB(m)]) with the patch embedder's operand forms (Encoder,
+ * models/PointCAE_transformer.py:37-51; its conv layers' weight gradients, which autograd computes with cuDNN/cuBLAS in
+ * the reference): whole 32-row groups gathered on either operand (rowA(m) = a_groups[m/32]*32 + m%32; lists nullable =
+ * compact operand; M % 32 == 0 with a list) and x = relu(X * scale[k] + shift[k]) when scale / shift are given
+ * (BatchNorm + ReLU recomputed while X is staged).  db nullable: column sums of dY.  On the grouped weight-gradient
+ * kernel: partial tiles in `workspace` (pdae_rows_wgrad_workspace(M, 1, &N, &K) floats), ordered reduction -- no
+ * atomics, no memset, bit-identical run to run. */
+int pdae_rows_wgrad_listed(int M, int N, int K, const float* dY, const int32_t* a_groups /*nullable*/, const float* X,
+                           const int32_t* b_groups /*nullable*/, const float* scale /*nullable*/,
+                           const float* shift /*nullable*/, float* dW, float* db /*nullable*/, float* workspace,
+                           pdae_stream_t stream);
 int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X, float* const* dW,
                           float* const* db, const int* Ns, const int* Ks, float* workspace, pdae_stream_t stream);
 

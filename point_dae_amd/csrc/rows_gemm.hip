@@ -470,6 +470,14 @@ struct WgradArgs {
   int nprob, tiles, blocks, slots;              // grid; slots per block
   long long units;
   float* partials;                              // [blocks][slots][wslot(TN)]
+  // the embedder's forms (patch_embed.py; one problem per launch): whole 32-row groups gathered on either operand (row m
+  // of the product = row groups[m / 32] * 32 + m % 32 of the stored matrix), and X := relu(X * scale[k] + shift[k])
+  // while it is staged (BatchNorm + ReLU recomputed instead of stored); all null for the Transformer blocks.  (Here and
+  // not per problem: 48 problems x 4 pointers would push the by-value argument past the 4 KB kernarg limit.)
+  const int* a_groups;
+  const int* b_groups;
+  const float* scale;
+  const float* shift;
   WgradProb p[WG_MAX];
 };
 
@@ -549,24 +557,54 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
     float4 rg[SLOTS];
     float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this thread's dY elements
     const bool sum_a = P.db != nullptr && bx == 0 && !isb;
+    // listed operands: a slab of TBK = 16 rows lies inside ONE 32-row group (units are 32-row chunks), so the stored
+    // row of product row m is m + rowoff with ONE block-uniform offset per slab and operand
+    const int* const grp_a = g.a_groups;
+    const int* const grp_b = g.b_groups;
+    const bool listed = grp_a != nullptr || grp_b != nullptr;
+    // BatchNorm + ReLU producer on this thread's X columns (the same in every slot)
+    const bool bnrelu = g.scale != nullptr;
+    float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bnrelu) {
+      const int xc = SPLIT ? k0 + xcol : gcol;
+      if ((SPLIT ? xok : (isb && ok))) {
+        bsc = *reinterpret_cast<const float4*>(g.scale + xc);
+        bsh = *reinterpret_cast<const float4*>(g.shift + xc);
+      }
+    }
+    auto producer = [&](float4 v) {
+      v.x = fmaxf(v.x * bsc.x + bsh.x, 0.f), v.y = fmaxf(v.y * bsc.y + bsh.y, 0.f);
+      v.z = fmaxf(v.z * bsc.z + bsh.z, 0.f), v.w = fmaxf(v.w * bsc.w + bsh.w, 0.f);
+      return v;
+    };
+    bool rv[SLOTS];                                   // slot holds a row inside the matrix (the producer skips the zero fill)
     auto gload = [&](int mt) {
+      int offa = 0, offb = 0;                         // stored row - product row, this slab
+      if (listed) {
+        const int gq = mt >> 5;
+        if (grp_a) offa = (grp_a[gq] - gq) * 32;
+        if (grp_b) offb = (grp_b[gq] - gq) * 32;
+      }
       if (SPLIT) {
         const int gm = mt + srow0;
         rg[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && gm < mend) rg[0] = *reinterpret_cast<const float4*>(src + (size_t)gm * ld);
+        if (ok && gm < mend) rg[0] = *reinterpret_cast<const float4*>(src + (size_t)(gm + offa) * ld);
 #pragma unroll
         for (int i = 1; i < SLOTS; ++i) {
           const int xm = mt + xrow0 + (i - 1) * XSTEP;
           rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (xok && xm < mend) rg[i] = *reinterpret_cast<const float4*>(xsrc + (size_t)xm * K);
+          rv[i] = xok && xm < mend;
+          if (rv[i]) rg[i] = *reinterpret_cast<const float4*>(xsrc + (size_t)(xm + offb) * K);
         }
         return;
       }
+      const int off = isb ? offb : offa;
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
         const int gm = mt + srow0 + i * RSTEP;
         rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && gm < mend) rg[i] = *reinterpret_cast<const float4*>(src + (size_t)gm * ld);
+        rv[i] = ok && gm < mend;
+        if (rv[i]) rg[i] = *reinterpret_cast<const float4*>(src + (size_t)(gm + off) * ld);
       }
     };
     auto lstore = [&](float* buf) {
@@ -575,12 +613,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
         if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
         *reinterpret_cast<float4*>(&buf[srow0 * (TM + TN) + scol]) = v;
 #pragma unroll
-        for (int i = 1; i < SLOTS; ++i)
+        for (int i = 1; i < SLOTS; ++i) {
+          if (bnrelu && rv[i]) rg[i] = producer(rg[i]);   // (rows past the end stay zero: relu(shift) is not)
           *reinterpret_cast<float4*>(&buf[(xrow0 + (i - 1) * XSTEP) * (TM + TN) + TM + xcol]) = rg[i];
+        }
         return;
       }
 #pragma unroll
       for (int i = 0; i < SLOTS; ++i) {
+        if (bnrelu && isb && rv[i]) rg[i] = producer(rg[i]);
         const float4 v = rg[i];
         if (sum_a) asum.x += v.x, asum.y += v.y, asum.z += v.z, asum.w += v.w;
         *reinterpret_cast<float4*>(&buf[(srow0 + i * RSTEP) * (TM + TN) + scol]) = v;
@@ -1058,6 +1099,31 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);
   return check_launch("rows_wgrad_multi");
+}
+
+// One weight gradient with the embedder's operand forms (point_dae_amd/patch_embed.py): whole 32-row groups gathered on
+// either operand and / or BatchNorm + ReLU recomputed on X while it is staged.  Same kernel, same ordered reduction (no
+// atomics, no memset) as the Transformer blocks' grouped launches; workspace = pdae_rows_wgrad_workspace(M, 1, &N, &K).
+extern "C" int pdae_rows_wgrad_listed(int M, int N, int K, const float* dY, const int32_t* a_groups, const float* X,
+                                      const int32_t* b_groups, const float* scale, const float* shift, float* dW,
+                                      float* db, float* workspace, pdae_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW || !workspace) return bad_arg("rows_wgrad_listed: bad argument");
+  if ((a_groups || b_groups) && M % 32 != 0) return bad_arg("rows_wgrad_listed: listed operands need M % 32 == 0 (whole groups)");
+  if ((scale == nullptr) != (shift == nullptr)) return bad_arg("rows_wgrad_listed: scale and shift come together");
+  WgradArgs g = {};
+  const int tn = wgrad_tile_width(1, &K);
+  int rc = wgrad_layout(1, &M, &N, &K, &g, tn);
+  if (rc) return rc;
+  g.p[0].dY = dY, g.p[0].X = X, g.p[0].dW = dW, g.p[0].db = db;
+  g.a_groups = a_groups, g.b_groups = b_groups, g.scale = scale, g.shift = shift;
+  g.partials = workspace;
+  const long long most = (g.p[0].chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
+  const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
+  hipStream_t s = as_stream(stream);
+  if (tn == 384) wgrad_launch<384>(g, pl, s);
+  else if (tn == 256) wgrad_launch<256>(g, pl, s);
+  else wgrad_launch<128>(g, pl, s);
+  return check_launch("rows_wgrad_listed");
 }
 
 extern "C" int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks, long long* floats) {

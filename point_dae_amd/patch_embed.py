@@ -62,6 +62,32 @@ def _gemm(x, w, w_kn=False, bias=None):
     return y
 
 
+# the embedder's own weight gradients (group-listed operands, BatchNorm + ReLU recomputed) on the grouped kernel of
+# csrc/rows_gemm.hip (ordered reduction, no atomics, no memset); PDAE_EMBED_WGRAD=tn: round 1's gemm_tn kernels (A/B)
+WGRAD_ROWS = os.environ.get('PDAE_EMBED_WGRAD', 'rows') != 'tn'
+
+
+def _wgrad_listed(M, dy, a_groups, x, b_groups, scale=None, shift=None, bias=False):
+    """dW (N, K) = sum over the M listed rows of dy^T . relu(x * scale + shift) [-> (dW, column sums of dy or None)]."""
+    N, K = dy.shape[1], x.shape[1]
+    dw = _empty((N, K), x)
+    db = _empty((N,), x) if bias else None
+    if WGRAD_ROWS:
+        ws = _empty((max(_lib.rows_wgrad_workspace(M, [N], [K]), 1),), x)
+        probed_family('rows_wgrad', 2.0 * M * N * K,
+                      lambda: _lib.call('pdae_rows_wgrad_listed', x, M, N, K, _lib.ptr(dy), _lib.ptr(a_groups), _lib.ptr(x),
+                                        _lib.ptr(b_groups), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dw), _lib.ptr(db),
+                                        _lib.ptr(ws)))
+    elif scale is not None:
+        assert a_groups is None
+        _lib.call('pdae_bnrelu_linear_backward_weight', x, M, N, K, _lib.ptr(dy), _lib.ptr(x), _lib.ptr(scale),
+                  _lib.ptr(shift), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(b_groups))
+    else:
+        _lib.call('pdae_linear_backward_weight_listed', x, M, N, K, _lib.ptr(dy), _lib.ptr(a_groups), _lib.ptr(x),
+                  _lib.ptr(b_groups), _lib.ptr(dw), _lib.ptr(db))
+    return dw, db
+
+
 def _wgrad(dy, x):
     """dy^T . x on the grouped weight-gradient kernel (one problem)."""
     M = dy.shape[0]
@@ -203,11 +229,8 @@ class PatchEmbedFunction(torch.autograd.Function):
         _lib.call('pdae_group_sum_listed', x, Gm, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(fsum_m))
         xe = torch.addcmul(u, gb.index_select(0, masked.long()), v)   # u + v * gb_g  (Gm, 512)
         # ---- weight gradient: dW_visible + diag(v) W Gram + xe^T fsum   (u (x) sum f rides in xe)
-        dwl, gram = _empty((c3, c2), x), _empty((c2, c2), x)
-        _lib.call('pdae_linear_backward_weight_listed', x, Rv, c3, c2, _lib.ptr(d3c), None, _lib.ptr(f),
-                  _lib.ptr(groups), _lib.ptr(dwl), None)
-        _lib.call('pdae_linear_backward_weight_listed', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(f),
-                  _lib.ptr(masked), _lib.ptr(gram), None)
+        dwl, _ = _wgrad_listed(Rv, d3c, None, f, groups)
+        gram, _ = _wgrad_listed(Rm, f, masked, f, masked)
         dwl.addcmul_(v.unsqueeze(1), _gemm(wl, gram)).add_(_wgrad(xe, fsum_m))      # (Gram is symmetric)
         # ---- per-group sums of the masked groups (the global half of the split concat weight)
         hs = _gemm(fsum_m, wl)                                        # the group's summed conv output, bias term apart
@@ -238,9 +261,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         dy4 = _empty((Rv, c4), x)
         _lib.call('pdae_group_max_scatter', x, Gv, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
         db4 = _colsum(dtok)
-        dw4 = _empty((c4, c3), x)
-        _lib.call('pdae_bnrelu_linear_backward_weight', x, Rv, c4, c3, _lib.ptr(dy4), _lib.ptr(h3),
-                  _lib.ptr(sc2), _lib.ptr(sh2), _lib.ptr(dw4), None, _lib.ptr(groups))
+        dw4, _ = _wgrad_listed(Rv, dy4, None, h3, groups, sc2, sh2)
         d3c = _gemm(dy4, w4m, True)                               # (Rv, 512) grad of relu(bn2(h3)) rows
         del dy4
         if ctx.algebra:
@@ -270,10 +291,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         dg = _gemm(dgb, wg, True)                                 # (BG, 256) -> arg-max rows of f
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
-        dw2 = _empty((c2, c1), x)
-        db2 = _empty((c2,), x)                                    # column sums of df, from the same kernel
-        _lib.call('pdae_bnrelu_linear_backward_weight', x, R, c2, c1, _lib.ptr(df), _lib.ptr(y1),
-                  _lib.ptr(sc1), _lib.ptr(sh1), _lib.ptr(dw2), _lib.ptr(db2), None)
+        dw2, db2 = _wgrad_listed(R, df, None, y1, None, sc1, sh1, bias=True)    # db2: column sums of df, same kernel
         d1 = _gemm(df, w2m, True)                                 # (R, 128)
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)

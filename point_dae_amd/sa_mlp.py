@@ -22,7 +22,7 @@ ATen ran ~7 passes per layer forward (stats, transform, clamp) and ~6 backward.
 import torch
 
 from . import _lib
-from .patch_embed import _bn_finalize, _empty, _gemm, _wgrad
+from .patch_embed import _bn_finalize, _empty, _gemm, _wgrad, _wgrad_listed
 
 
 # Parity-test hook (None in production): called as ARG_HOOK(arg) with the (groups, C) uint8 winners of a level's
@@ -102,10 +102,8 @@ class SharedMLPMaxFunction(torch.autograd.Function):
             if l > 0:
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
                 K = ws[l].shape[1]
-                dw = _empty((N, K), x)
-                _lib.call('pdae_bnrelu_linear_backward_weight', x, R, N, K, _lib.ptr(d), _lib.ptr(ys[l - 1]),
-                          _lib.ptr(psc), _lib.ptr(psh), _lib.ptr(dw), None, None)
-                grads[3 * l] = dw
+                # BatchNorm + ReLU of the previous layer recomputed while its raw output is staged (patch_embed._wgrad_listed)
+                grads[3 * l] = _wgrad_listed(R, d, None, ys[l - 1], None, psc, psh)[0]
                 d = _gemm(d, ws[l], True)                                        # gradient of relu(bn(y_{l-1}))
             else:
                 grads[0] = _wgrad(d, x)

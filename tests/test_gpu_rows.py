@@ -312,3 +312,50 @@ def test_fold_out_backward(rows, C):
     _close(res[0][0], (dy.double() @ w.double()) * (h2 > 0), 2e-5)
     _close(res[0][1].sum(0), dy.double().t() @ h2.double(), 2e-5)
     assert (res[0][0][h2 == 0] == 0).all()
+
+
+@pytest.mark.parametrize('M,N,K,la,lb,bn,bias', [
+    (8192, 384, 512, False, True, True, False),      # conv4: compact dY, listed BatchNorm+ReLU input
+    (8192, 512, 256, False, True, False, False),     # conv3's local half on the visible groups
+    (4096, 256, 256, True, True, False, False),      # the masked groups' Gram matrix (dY = X, one list)
+    (16384, 256, 128, False, False, True, True),     # conv2: every row, BatchNorm+ReLU input, bias sums
+    (96, 128, 512, True, False, True, True),         # a reduction shorter than one block's range; K = 512
+    (4128, 100, 260, True, True, True, True),        # edges in N and K (narrow tile), M = 129 groups
+    (32, 384, 768, False, True, False, True)])       # the 384-wide tile, one group
+def test_rows_wgrad_listed(M, N, K, la, lb, bn, bias):
+    """pdae_rows_wgrad_listed: the embedder's weight gradients (group-listed operands, BatchNorm + ReLU recomputed on X)
+    on the grouped kernel, against fp64, and the same bits twice (ordered reduction)."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    G = M // 32
+    stored = (G + 7) * 32
+    dY = torch.randn(stored if la else M, N, device='cuda', generator=g)
+    X = torch.randn(stored if lb else M, K, device='cuda', generator=g)
+    ga = torch.randperm(G + 7, device='cuda', generator=g)[:G].int() if la else None
+    gb = torch.randperm(G + 7, device='cuda', generator=g)[:G].int() if lb else None
+    if la and lb and N == K:                                   # the Gram form: one matrix, one list
+        dY, ga = X, gb
+    sc = (torch.rand(K, device='cuda', generator=g) + 0.5) if bn else None
+    sh = torch.randn(K, device='cuda', generator=g) * 0.3 if bn else None
+
+    def rows(t, lst):
+        return t if lst is None else t.view(-1, 32, t.shape[1])[lst.long()].reshape(M, t.shape[1])
+    a, b = rows(dY, ga).double(), rows(X, gb).double()
+    if bn:
+        b = torch.relu(b * sc.double() + sh.double())
+    want_w, want_b = a.t() @ b, a.sum(0)
+    ws = torch.full((max(L.rows_wgrad_workspace(M, [N], [K]), 1),), float('nan'), device='cuda')
+    outs = []
+    for _ in range(2):
+        dw = torch.full((N, K), float('nan'), device='cuda')
+        db = torch.full((N,), float('nan'), device='cuda') if bias else None
+        L.call('pdae_rows_wgrad_listed', dY, M, N, K, L.ptr(dY), L.ptr(ga), L.ptr(X), L.ptr(gb), L.ptr(sc), L.ptr(sh),
+               L.ptr(dw), L.ptr(db), L.ptr(ws))
+        _close(dw, want_w, 5e-5)
+        if bias:
+            _close(db, want_b, 5e-5)
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and (not bias or torch.equal(outs[0][1], outs[1][1]))
+    with pytest.raises(RuntimeError):                              # a list needs whole groups
+        L.call('pdae_rows_wgrad_listed', dY, 40, N, K, L.ptr(dY), L.ptr(gb if gb is not None else torch.zeros(2, dtype=torch.int32, device='cuda')),
+               L.ptr(X), None, None, None, L.ptr(dw), None, L.ptr(ws))
