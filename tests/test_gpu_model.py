@@ -225,8 +225,8 @@ def test_pointnetv2_product_model_reproduces_reference_fixture():
     # The gradient is discontinuous where a max-pool winner changes: a near-tie resolved the other way by 1 ulp of GEMM
     # rounding moves whole tensors (measured 6.5e-3 of sa2.layer0.bn.bias' scale, tools/dbg_cfg1_noise.py).  So the
     # comparison is made twice.  (1) Like with like: the reference's own winners (captured from the live reference into
-    # the fixture) are injected into the three max-pools' backward, deterministic mode: every tensor within 2e-2, no
-    # exceptions (all but one within 3.2e-3).  (2) With the product's own winners: how many differ is asserted to be a handful, and the old bound
+    # the fixture) are injected into the three max-pools' backward, deterministic mode: every tensor within 5e-3, one
+    # named tensor within 2e-2.  (2) With the product's own winners: how many differ is asserted to be a handful, and the old bound
     # (1e-2, three tensors up to 5e-2) still holds.
     from point_dae_amd import _lib, sa_mlp
     model.zero_grad(set_to_none=True)
@@ -247,8 +247,11 @@ def test_pointnetv2_product_model_reproduces_reference_fixture():
     flips = [int((a != b).sum()) for a, b in zip(mine, want)]
     # exact ties are ball-query's repeated points (identical rows): whichever copy wins, the gradient reaches the same
     # source point -- so count winners that point at DIFFERENT points only through the gradient check below
-    check_grads(model, fx, 2e-2, 'pointnetv2, reference winners injected')     # (measured: 1.5e-2 on sa3.layer1.bn.bias -- the
-                                   # level has 2 groups and 256 rows at B = 2 -- 3.2e-3 or less on every other tensor)
+    # every tensor within 5e-3 (measured <= 3.2e-3); ONE named exception: the last level's middle BatchNorm bias, 1.5e-2 --
+    # that level is group_all, its BatchNorm normalises over B = 2 rows (x_hat = +-1: the worst-conditioned statistics
+    # of the model)
+    check_grads(model, fx, 5e-3, 'pointnetv2, reference winners injected',
+                named={'pointnetv2_encoder.sa3.mlps.0.layer1.bn.bn.bias': 2e-2})
     model.zero_grad(set_to_none=True)
     lc3, lf3 = model(torch.from_numpy(fx['corrupted']).cuda(), torch.from_numpy(fx['clean']).cuda())
     (lc3 + 0.5 * lf3).backward()
