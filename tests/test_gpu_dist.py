@@ -7,6 +7,8 @@ import os
 import socket
 
 import pytest
+
+import proc_util
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -153,7 +155,7 @@ def test_bench_two_ranks_code_path(launcher):
                '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
     else:
         cmd = [sys.executable] + tail
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    r = proc_util.run(cmd, 600, env=env, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     d = json.loads(lines[0])
@@ -170,8 +172,8 @@ def test_bench_refuses_more_ranks_than_gpus():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PDAE_BENCH_BACKEND')}
     want = torch.cuda.device_count() + 1
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(want), '--steps', '1',
-                        '--warmup', '0'], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    r = proc_util.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(want), '--steps', '1',
+                       '--warmup', '0'], 300, env=env, cwd=root)
     assert r.returncode != 0 and '{"metric"' not in r.stdout, (r.returncode, r.stdout[-500:])
 
 

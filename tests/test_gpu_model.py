@@ -8,6 +8,8 @@ a different summation order than the CPU -> 2e-3 of the tensor's max.
 """
 import numpy as np
 import pytest
+
+import proc_util
 import torch
 
 from golden_util import check_grads, fill_state, load_fixture, model_cfg
@@ -508,7 +510,7 @@ def test_main_cli_trains_and_resumes(tmp_path):
     base = [sys.executable, '-m', 'point_dae_amd.main', '--config', str(path), '--total_bs', '8', '--steps_per_epoch', '3',
             '--exp_name', 'ci', '--root_folder', os.path.relpath(str(tmp_path / 'exp'), root)]
     env = dict(os.environ, PYTHONPATH=root)
-    r = subprocess.run(base, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r = proc_util.run(base, 600, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'clouds/s' in r.stdout
     ckpts = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == 'ckpt-last.pth']
@@ -516,7 +518,7 @@ def test_main_cli_trains_and_resumes(tmp_path):
     sd = torch.load(ckpts[0], map_location='cpu')
     assert {'base_model', 'optimizer', 'epoch'} <= set(sd) and sd['epoch'] == 1
     assert 'MAE_encoder.encoder.first_conv.0.weight' in sd['base_model']          # reference key layout
-    r = subprocess.run(base + ['--resume'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r = proc_util.run(base + ['--resume'], 600, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 import pytest
+
+import proc_util
 import torch
 import yaml
 
@@ -110,8 +112,7 @@ def _run_main(tmp_path, cfg, extra=(), steps=4):
     yaml.safe_dump(cfg, open(path, 'w'))
     cmd = [sys.executable, '-m', 'point_dae_amd.main', '--config', str(path), '--total_bs', '4', '--steps_per_epoch',
            str(steps), '--exp_name', 'ci', '--root_folder', os.path.relpath(str(tmp_path / 'exp'), ROOT)] + list(extra)
-    return subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True,
-                          timeout=900)
+    return proc_util.run(cmd, 900, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
 
 
 def test_main_cli_dropout_global_config_trains(tmp_path):
