@@ -31,7 +31,7 @@ for _ in range(3):
     step._phase1(tvis)
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     tvis = step._draw()
     step._phase1(tvis)
     torch.cuda.synchronize()
@@ -43,12 +43,12 @@ for ev in prof.events():
     if all(k.startswith('pdae::') or 'pdae' in k for k in kn):
         continue
     frames = [f for f in (ev.stack or []) if 'point_dae_amd' in f or 'bench' in f][:3]
-    rows.append((ev.time_range.start, ev.name, [k[:60] for k in kn], sum(k.duration for k in ev.kernels), frames))
+    rows.append((ev.time_range.start, ev.name + ' ' + str(getattr(ev, 'input_shapes', ''))[:90], [k[:60] for k in kn], sum(k.duration for k in ev.kernels), frames))
 rows.sort()
 tot = 0.0
 for t, name, kn, dur, frames in rows:
     tot += dur
-    print('%-28s %6.1f us  %s' % (name[:28], dur, ' | '.join(f.replace(ROOT + '/', '') for f in frames)))
+    print('%-120s %6.1f us  %s' % (name[:120], dur, ' | '.join(f.replace(ROOT + '/', '') for f in frames)))
     for k in kn:
         print('      -> ' + k)
 print('glue launches', sum(len(r[2]) for r in rows), 'device us', tot, 'tvis', tvis)
