@@ -503,8 +503,15 @@ __device__ __forceinline__ int wg_tile_of_unit(const WgradArgs& g, long long u) 
   return P.tile0 + (int)((u - P.unit0) / P.chunks);
 }
 
+#ifdef PDAE_ROWS_STAMPS
+__device__ long long g_wg_clk[2];       // diagnostic build: shader-clock cycles / 100 MHz ticks block 0 of the last launch lived
+#endif
+
 template <int TN, int NT>
 __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
+#ifdef PDAE_ROWS_STAMPS
+  const long long lab_c0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int TM = WTM;
   constexpr int WNV = NT / 128;                       // waves along k (two along n)
   constexpr int WK = TN / WNV;                        // columns of a wave: 64 (TN 128) or 96 (TN 384)
@@ -707,6 +714,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
           slot[row * TN + wn * WK + j * 32 + r] = acc[i][j][e];
         }
   }
+#ifdef PDAE_ROWS_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_wg_clk[0] = __builtin_amdgcn_s_memtime() - lab_c0;
+    g_wg_clk[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+  }
+#endif
 }
 
 // dW tile = sum of its partials in a fixed order (=> bit-identical run to run).  A block owns
@@ -919,6 +932,11 @@ static void launch_rows(Args& a, int cfg, int splits, int sb, hipStream_t s) {
 using namespace pdae;
 using namespace pdae::rows;
 
+#ifdef PDAE_ROWS_STAMPS
+extern "C" int pdae_lab_wgrad_clock(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdae::rows::g_wg_clk), 16);
+}
+#endif
 #ifdef PDAE_ROWS_STAMPS
 static long long* g_stamps = nullptr;
 extern "C" void pdae_lab_set_stamps(long long* p) { g_stamps = p; }
