@@ -71,6 +71,10 @@ struct Args {
 #define PDAE_STAMP(i)
 #endif
 
+#ifdef PDAE_LAB_CLOCK
+__device__ long long g_rg_clk[2];       // diagnostic build: shader-clock cycles / 100 MHz ticks block 0 of the last launch lived
+#endif
+
 // Block tile (32 TI WM) x (32 TJ WN), WM x WN waves, every wave TI x TJ MFMA tiles of 32x32.
 // k permutation inside an 8-deep slab as in gemm.hip: lane (r = l & 31, h = l >> 5) supplies
 // k = 8s + 4h + t to MFMA t, so one ds_read_b128 of a K-contiguous operand row feeds four MFMAs.
@@ -84,6 +88,9 @@ struct Args {
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)))
 void rows_gemm_kernel(const Args p) {
+#ifdef PDAE_LAB_CLOCK
+  const long long lab_c0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN, NT = 64 * WM * WN;
   constexpr int LA = (BM * 8) / NT, LB = (BN * 8) / NT;   // float4 per thread and k-tile
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "every thread stages LA + LB float4 per k-tile");
@@ -427,6 +434,12 @@ void rows_gemm_kernel(const Args p) {
   if (u >= uend) break;
   __syncthreads();      // every wave is done with the LDS buffers before the next segment stages into them
   }   // segments
+#ifdef PDAE_LAB_CLOCK
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    g_rg_clk[0] = __builtin_amdgcn_s_memtime() - lab_c0;
+    g_rg_clk[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+  }
+#endif
 #ifdef PDAE_ROWS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PDAE_STAMP(3)
@@ -932,6 +945,22 @@ static void launch_rows(Args& a, int cfg, int splits, int sb, hipStream_t s) {
 using namespace pdae;
 using namespace pdae::rows;
 
+#if defined(PDAE_ROWS_STAMPS) || defined(PDAE_LAB_OCC)
+// diagnostic builds: the runtime's occupancy answer for the 64 x 64 row GEMM at a dynamic LDS size, and the device's LDS
+// (-DPDAE_LAB_OCC alone leaves the kernels exactly as shipped)
+extern "C" int pdae_lab_occupancy(int lds_bytes, int* blocks_per_cu, int* lds_per_cu, int* lds_per_block_max) {
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, 0);
+  *lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor, *lds_per_block_max = (int)prop.sharedMemPerBlock;
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+      blocks_per_cu, reinterpret_cast<const void*>(rows_gemm_kernel<1, 1, 2, 2, false, EPI_STORE>), 256, (size_t)lds_bytes);
+}
+#endif
+#ifdef PDAE_LAB_CLOCK
+extern "C" int pdae_lab_rows_clock(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdae::rows::g_rg_clk), 16);
+}
+#endif
 #ifdef PDAE_ROWS_STAMPS
 extern "C" int pdae_lab_wgrad_clock(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdae::rows::g_wg_clk), 16);

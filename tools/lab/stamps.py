@@ -49,6 +49,11 @@ def run(M, N, K, w_kn, epi, cfg, splits):
     cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
     per = np.bincount(np.unique(cu, return_inverse=True)[1])
     print(f"   distinct CUs {len(per)}  blocks per CU: " + " ".join(f"{k}:{v}" for k, v in zip(*np.unique(per, return_counts=True))))
+    # blocks that started after another block had already ended (a second residency round), and concurrency per CU
+    first_end = end.min()
+    late = start > first_end
+    print(f"   first block ends at {first_end:.1f} us; {int(late.sum())} blocks start after that (second round); "
+          f"late blocks per CU: " + " ".join(f"{k}:{v}" for k, v in zip(*np.unique(np.bincount(np.unique(cu, return_inverse=True)[1], weights=late).astype(int), return_counts=True))))
 
 
 if __name__ == '__main__':
