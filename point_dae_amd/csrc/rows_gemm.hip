@@ -742,13 +742,17 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
 // hundreds (the embedder's first conv: ONE tile, 512 partials -- a single lane walking them took
 // 121 us, PL = 8 takes 15).  Elements outside the weight are skipped.  The blocks with part == 0
 // also reduce the bias-gradient column sums.
+// float4 per thread of the reduction: 8 where a tile has a few partials (one lane: the stacks' launches, 96 -> 38 us),
+// 1 where it has hundreds (the lane-parallel forms want the blocks)
+constexpr int wru(int PL) { return PL == 1 ? 8 : 1; }
 template <int PL, int TN>
 __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block) {
-  constexpr int EPB = 256 / PL;              // float4 per block
-  constexpr int PARTS = WTM * TN / 4 / EPB;   // blocks per tile
+  constexpr int WRU = wru(PL);
+  constexpr int EPB = 256 / PL;                      // threads per partial lane
+  constexpr int PARTS = WTM * TN / 4 / (EPB * WRU);   // blocks per tile
   constexpr int WSLOT = wslot(TN);
-  static_assert(EPB >= WTM / 4, "the bias sums of a tile fit one block");
-  __shared__ float4 red[PL > 1 ? PL : 1][EPB];
+  static_assert(EPB >= WTM / 4 && (WTM * TN / 4) % (EPB * WRU) == 0, "a tile divides into blocks; its bias sums fit one");
+  __shared__ float4 red[PL > 1 ? PL : 1][PL > 1 ? WRU : 1][EPB];
   __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
   const int tile = block / PARTS, part = block % PARTS;
   const WgradProb& P = g.p[wg_prob_of_tile(g, tile)];
@@ -758,50 +762,63 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   // blocks whose ranges meet this tile's units
   const long long u0 = P.unit0 + (long long)lt * P.chunks, u1 = u0 + P.chunks - 1;
   const int b0 = (int)(((u0 + 1) * g.blocks - 1) / g.units), b1 = (int)(((u1 + 1) * g.blocks - 1) / g.units);
-  const int tid = threadIdx.x, pl = tid / EPB, el = tid % EPB;
-  const int e = (part * EPB + el) * 4;                               // element of the WTM x TN tile
-  const int row = n0 + e / TN, col = k0 + e % TN;
-  const bool valid = row < P.N && col < P.K;
+  const int tid = threadIdx.x, pl = PL == 1 ? 0 : tid / EPB, el = tid % EPB;
+  // this thread's WRU float4 of the WTM x TN tile; the locating arithmetic of a partial (which slot of block b holds
+  // this tile: 64-bit divisions and a walk over the problems) is done once per partial and block, not per element
+  int e[WRU];
+  bool valid[WRU];
+  bool any = false;
+#pragma unroll
+  for (int u = 0; u < WRU; ++u) {
+    e[u] = ((part * WRU + u) * EPB + el) * 4;
+    valid[u] = n0 + e[u] / TN < P.N && k0 + e[u] % TN < P.K;
+    any |= valid[u];
+  }
   const bool bias = part == 0 && bx == 0 && P.db && el < WTM / 4 && n0 + el * 4 < P.N;
-  // block b's slot that holds this tile: the (tile - first tile of b's range)-th
-  auto src_of = [&](int b) {
-    return g.partials + ((size_t)b * g.slots + (tile - wg_tile_of_unit(g, wg_start(g, b)))) * WSLOT;
-  };
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), bs = s;
-  if (valid || bias)
-    for (int b = b0 + pl; b <= b1; b += 8 * PL) {
-      float4 v[8], w[8];
+  float4 s[WRU], bs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        v[q] = make_float4(0.f, 0.f, 0.f, 0.f), w[q] = v[q];
-        if (b + q * PL <= b1) {
-          const float* src = src_of(b + q * PL);
-          if (valid) v[q] = *reinterpret_cast<const float4*>(src + e);
-          if (bias) w[q] = *reinterpret_cast<const float4*>(src + WTM * TN + el * 4);
-        }
-      }
+  for (int u = 0; u < WRU; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Which slot of block b holds this tile: the (tile - first tile of b's range)-th.  The range of every block b0 < b <= b1
+  // STARTS inside this tile (ranges are contiguous and b0 holds the tile's first unit), so the tile is their first: slot
+  // 0.  Only b0 may have come from an earlier tile -- one locating computation (64-bit divisions, a walk over the
+  // problems) per reduction block instead of one per partial and thread.
+  const int slot_b0 = tile - wg_tile_of_unit(g, wg_start(g, b0));
+  for (int b = b0 + pl; b <= b1; b += PL) {          // lane pl adds partials b0 + pl, b0 + pl + PL, ... in that order
+    const float* src = g.partials + ((size_t)b * g.slots + (b == b0 ? slot_b0 : 0)) * WSLOT;
+    float4 v[WRU], w = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        s.x += v[q].x, s.y += v[q].y, s.z += v[q].z, s.w += v[q].w;
-        bs.x += w[q].x, bs.y += w[q].y, bs.z += w[q].z, bs.w += w[q].w;
-      }
+    for (int u = 0; u < WRU; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid[u]) v[u] = *reinterpret_cast<const float4*>(src + e[u]);
     }
+    if (bias) w = *reinterpret_cast<const float4*>(src + WTM * TN + el * 4);
+#pragma unroll
+    for (int u = 0; u < WRU; ++u) s[u].x += v[u].x, s[u].y += v[u].y, s[u].z += v[u].z, s[u].w += v[u].w;
+    bs.x += w.x, bs.y += w.y, bs.z += w.z, bs.w += w.w;
+  }
+  (void)any;
   if (PL > 1) {
-    red[pl][el] = s;
+#pragma unroll
+    for (int u = 0; u < WRU; ++u) red[pl][u][el] = s[u];
     if (el < WTM / 4) redb[pl][el] = bs;
     __syncthreads();
     if (pl != 0) return;
 #pragma unroll
     for (int q = 1; q < PL; ++q) {
-      const float4 t = red[q][el];
-      s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+#pragma unroll
+      for (int u = 0; u < WRU; ++u) {
+        const float4 t = red[q][u][el];
+        s[u].x += t.x, s[u].y += t.y, s[u].z += t.z, s[u].w += t.w;
+      }
       if (el < WTM / 4) {
-        const float4 u = redb[q][el];
-        bs.x += u.x, bs.y += u.y, bs.z += u.z, bs.w += u.w;
+        const float4 t = redb[q][el];
+        bs.x += t.x, bs.y += t.y, bs.z += t.z, bs.w += t.w;
       }
     }
   }
-  if (valid) *reinterpret_cast<float4*>(P.dW + (size_t)row * P.K + col) = s;
+#pragma unroll
+  for (int u = 0; u < WRU; ++u)
+    if (valid[u]) *reinterpret_cast<float4*>(P.dW + (size_t)(n0 + e[u] / TN) * P.K + k0 + e[u] % TN) = s[u];
   if (bias) *reinterpret_cast<float4*>(P.db + n0 + el * 4) = bs;
 }
 
@@ -1107,7 +1124,8 @@ extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const i
 template <int TN>
 static void wgrad_launch(const WgradArgs& g, int pl, hipStream_t s) {
   constexpr int NT = TN >= 256 ? 512 : 256;
-  constexpr int PARTS1 = WTM * TN / 4 / 256;
+  constexpr int PARTS1 = WTM * TN / 4 / (256 * wru(1));   // reduction blocks per tile with one partial lane
+  constexpr int PARTSL = WTM * TN / 4 / 256;               // ... per lane-block of the lane-parallel forms
   const size_t lds = sizeof(float) * 2 * TBK * (WTM + TN);
   static bool once = false;
   if (!once) {
@@ -1117,8 +1135,8 @@ static void wgrad_launch(const WgradArgs& g, int pl, hipStream_t s) {
   }
   hipLaunchKernelGGL((wgrad_kernel<TN, NT>), dim3(g.blocks), dim3(NT), lds, s, g);
   if (pl == 1) hipLaunchKernelGGL((wgrad_reduce_kernel<1, TN>), dim3(g.tiles * PARTS1), dim3(256), 0, s, g);
-  else if (pl == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, TN>), dim3(g.tiles * PARTS1 * 4), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((wgrad_reduce_kernel<8, TN>), dim3(g.tiles * PARTS1 * 8), dim3(256), 0, s, g);
+  else if (pl == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, TN>), dim3(g.tiles * PARTSL * 4), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((wgrad_reduce_kernel<8, TN>), dim3(g.tiles * PARTSL * 8), dim3(256), 0, s, g);
 }
 
 extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* const* dY, const float* const* X,
