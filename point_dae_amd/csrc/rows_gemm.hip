@@ -905,11 +905,23 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
     // stream-K on the 64x64 tile: every SIMD carries units / P * 16 MFMAs per resident block
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
     const int kt = (K + BK - 1) / BK;
-    for (int P : {1024, 512, 256}) {
+    // the first grid whose tiles are cut into at most THREE pieces: a slab is a 5.5 MB write for the producer and a
+    // 5.5 MB read for the LayerNorm that adds it (tools/lab/stream_sweep.sh: 4 slabs 12.71, 3 slabs 12.68, 2 slabs
+    // 12.71 ms/step; 768 / 512 blocks at most 12.71-12.73)
+#ifdef PDAE_LAB_PLAN
+    static const int lab_pmax = getenv("PDAE_STREAM_PMAX") ? atoi(getenv("PDAE_STREAM_PMAX")) : 1024;   // largest grid tried
+    static const int lab_smax = getenv("PDAE_STREAM_SMAX") ? atoi(getenv("PDAE_STREAM_SMAX")) : 3;      // most slabs accepted
+    static const bool lab_768 = getenv("PDAE_STREAM_PMAX") != nullptr;
+#else
+    constexpr int lab_pmax = 1024, lab_smax = 3;
+    constexpr bool lab_768 = false;
+#endif
+    for (int P : {1024, 768, 512, 256}) {
+      if (P > lab_pmax || (P == 768 && !lab_768)) continue;
       const long long units = tiles * kt;
       if (units < 2LL * P) continue;
       const int S = stream_slabs(tiles, kt, P);
-      if (S > 4) continue;
+      if (S > lab_smax) continue;
       const double per_simd = (double)((units + P - 1) / P) * 16. * (P / 256);
       const double t = per_simd * (P == 256 ? 1.33 : 1.0) + 110. + 8. * S;
       if (t < best * 0.97) best = t, *cfg = 3, *splits = S, *stream_blocks = P;
