@@ -356,7 +356,7 @@ def draw_drop_path(B, drop_probs, training, keep):
     return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(drop_probs)]
 
 
-def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
+def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False, big_cfg=None):
     """y = epi(x . op(w)) on the row-GEMM family (csrc/rows_gemm.hip, include/pdae.h).
     w_kn False: w is (N, K), torch's (out, in): a Linear's forward; True: w is (K, N): the same
     weight as the data-gradient operand.  epi 0 store (+bias) | 1 bias+ReLU | 2 GELU(z) -> y and
@@ -370,15 +370,25 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False):
         for m0 in range(0, M, rows):
             m1 = min(M, m0 + rows)
             cfg, _, _ = _lib.rows_gemm_plan(m1 - m0, N, K, w_kn, False)
+            if big_cfg is not None and BIG_TILES and m1 - m0 >= BIG_ROWS:
+                cfg = big_cfg
             _lib.call('pdae_rows_gemm', x, m1 - m0, N, K, _lib.ptr(x[m0:m1]), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
                       epi, _lib.ptr(z[m0:m1]) if z is not None else None, _lib.ptr(y[m0:m1]), cfg, 1, 0)
         return y
     cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
+    if big_cfg is not None and M >= BIG_ROWS and splits == 1 and BIG_TILES:
+        cfg = big_cfg         # a caller's measured tile shape for a multi-millisecond product (the plan is calibrated on M <= 8192)
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
     probed_family('rows_gemm', 2.0 * M * N * K,
                   lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
                                     epi, _lib.ptr(z), _lib.ptr(y), cfg, splits, sb))
     return y
+
+
+# Tile shapes for the FoldingNet stage's multi-millisecond products (tools/lab/rows_big.py, 524288 x 512 x 512: bias+ReLU
+# forward 96x128 tiles 126.7 vs 121.9 TFLOP/s on 64x64; ReLU-masked data gradient 128x128 123.0 vs 115.7)
+BIG_ROWS = 1 << 19                 # (the published variant's 190 k-row stages are faster on the planned 64x64 tiles: 17.55 vs 17.63 ms)
+BIG_TILES = os.environ.get('PDAE_BIG_TILES', '1') != '0'
 
 
 # Gradient sink.  FlatDataParallel tags every parameter it owns with (weakref to itself, index); a graphed step
@@ -501,7 +511,7 @@ class _FoldMLP(torch.autograd.Function):
             _lib.call('pdae_fold_input', p, clouds, coarse, cells, C, _lib.ptr(a), _lib.ptr(p), _lib.ptr(gd), _lib.ptr(h1))
         else:      # a per-point term instead of the per-cloud / per-cell ones (the published variant's second stage)
             h1 = torch.relu_(row.reshape(clouds * coarse, cells, C) + p.unsqueeze(1)).reshape(rows, C)
-        h2 = rows_gemm(h1, w2, False, b2, 1)
+        h2 = rows_gemm(h1, w2, False, b2, 1, big_cfg=5)
         y = rows_gemm(h2, w3, False, b3, 0)
         ctx.save_for_backward(h1, h2, w2, w3)
         ctx.dims = (clouds, coarse, cells, C)
@@ -525,7 +535,7 @@ class _FoldMLP(torch.autograd.Function):
             (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
         # (the large product of the stage: the [N,K] form of the kernel is 8 % faster than the [K,N] form at
         #  this size, and transposing the weight costs nothing)
-        d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1)  # gradient of h1's pre-activation
+        d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1, big_cfg=0)  # gradient of h1's pre-activation
         (dw2,), (db2,) = rows_wgrad([d2], [h1], [True])
         del d2
         if ctx.per_row:
