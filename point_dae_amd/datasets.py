@@ -192,15 +192,22 @@ def dropout_local(x, ncl, rank, sizes):
     B, P, _ = x.shape
     dev = x.device
     alive = torch.empty((B, P), dtype=torch.uint8, device=dev)
-    n_d, r_d, s_d = (torch.from_numpy(a).to(dev) for a in (ncl, rank, sizes))
+    n_d, r_d, s_d = (_dev(a, dev) for a in (ncl, rank, sizes))
     _lib.call('pdae_dropout_local', x, B, P, _lib.ptr(x.contiguous()), _lib.ptr(n_d), _lib.ptr(r_d), _lib.ptr(s_d),
               _lib.ptr(alive))
     return alive.bool()
 
 
 def _dev(a, device, dtype=None):
+    """Host draws -> device WITHOUT blocking the host: a pageable source makes .to() a synchronous, stream-ordered copy,
+    i.e. the host would wait for everything queued on the stream (the previous optimisation step) at every small
+    parameter tensor of a batch.  Pinned staging (torch's caching host allocator keeps the block until the copy ran)."""
     t = torch.from_numpy(np.ascontiguousarray(a))
-    return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
+    if dtype is not None:
+        t = t.to(dtype)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 def pipeline_norm_affine(x, normalise=False, maps=None, sigma=None, noise=None, stride=None):
@@ -396,8 +403,11 @@ class ShapeNet:
                 raise NotImplementedError('%s after a drop / another add in one corrupt_type list' % item)
             if item == 'add_global':                                # int(P (level + 1) 0.1) ball points (:830-841)
                 count = (P * (rng.integers(0, 5, B) + 1) * 0.1).astype(np.int32)
+                if getattr(self, '_ball_affine', None) is None:       # (radius, cos theta, phi) ranges of the three uniforms
+                    self._ball_affine = (_dev(np.array([1.0, 2.0, 2.0 * math.pi], np.float32), dev),
+                                         _dev(np.array([0.0, 1.0, 0.0], np.float32), dev))
                 pipeline_add_global(y, P, _dev(count, dev), torch.rand((B, n_add, 3), device=dev, generator=self.gen)
-                                    * torch.tensor([1.0, 2.0, 2.0 * math.pi], device=dev) - torch.tensor([0.0, 1.0, 0.0], device=dev))
+                                    * self._ball_affine[0] - self._ball_affine[1])
                 cur, added = P + n_add, count
             elif item == 'add_local':                               # 1-7 Gaussian clusters on random cloud points (:844-870)
                 count = (P * (rng.integers(0, 5, B) + 1) * 0.1).astype(np.int32)
@@ -459,9 +469,15 @@ class ShapeNet:
             n = order.shape[0]
         else:
             order = self.rng.permutation(n)
+        # The pipeline's launches sit in front of the step on the same stream; what matters is that the HOST never waits:
+        # every small parameter tensor goes through pinned staging (_dev), so the host runs ahead of the GPU and the
+        # pipeline's few small kernels are the only cost (measured end to end through main.py, 300-step epochs: 10 030-10 060
+        # clouds/s = the bare step's rate; with pageable copies the host waited for the previous step at each of them:
+        # 9 500.  Producing the next batch on a side stream as well changed nothing.)
+        dev = self._clouds.device
         for i in range(self.steps):
             sel = order[(np.arange(self.bs) + i * self.bs) % order.shape[0]]
-            corrupted, clean = self.batch(torch.from_numpy(sel).to(self._clouds.device))
+            corrupted, clean = self.batch(_dev(sel, dev))
             yield self.ids[int(sel[0])][0], i, corrupted, clean
 
 
