@@ -29,7 +29,6 @@ normalisation, unbiased for the running estimate, momentum 0.1.
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from .arena import arena

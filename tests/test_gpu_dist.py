@@ -142,7 +142,6 @@ def test_bench_two_ranks_code_path(launcher):
     RCCL needs one device per rank, so this checks the code path, not the collective's speed.
     'self': `python bench.py --gpus 2` with NO launcher must start the two ranks itself."""
     import json
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PDAE_BENCH_BACKEND='gloo', GLOO_SOCKET_IFNAME='lo')
@@ -167,7 +166,6 @@ def test_bench_two_ranks_code_path(launcher):
 
 def test_bench_refuses_more_ranks_than_gpus():
     """`--gpus 8` on a 1-GPU box must fail, not print an n_gpus=1 line (RCCL: one device per rank)."""
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PDAE_BENCH_BACKEND')}

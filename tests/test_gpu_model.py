@@ -495,7 +495,6 @@ def test_bare_model_with_torch_adamw_and_zeroed_grads():
 def test_main_cli_trains_and_resumes(tmp_path):
     """python -m point_dae_amd.main with the reference's flags: one tiny epoch, checkpoint, --resume."""
     import os
-    import subprocess
     import sys
     import yaml
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

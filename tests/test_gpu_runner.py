@@ -3,7 +3,6 @@ configuration gets, the gradient sink's ownership rules, resume of the best metr
 import copy
 import os
 import random
-import subprocess
 import sys
 
 import numpy as np
