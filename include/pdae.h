@@ -122,6 +122,18 @@ int pdae_group_points_grad(int b, int c, int n, int npoints, int nsample,
                            const float* grad_out, const int32_t* idx,
                            float* grad_points, pdae_stream_t stream);
 
+/* QueryAndGroup.forward (extensions/pointnet2/pointnet2_utils.py:345-361) in ROW layout, the set-abstraction MLP's input:
+ *   out[(b*np + p)*ns + s] = [ xyz[b, idx[b,p,s]] - new_xyz[b,p] | 0 | features[b*N + idx[b,p,s], 0:C] ]  (4 + C floats;
+ *   features (B*N, C) rows, nullable with C = 0; C a multiple of 4; the zero column keeps the reduction length of the
+ *   row GEMMs a multiple of 4).  One pass instead of grouping_operation x 2 + subtract + cat.
+ * sa_group_rows_grad: dfeatures[b*N + j, c] = sum of dout[row, 4 + c] over the rows of cloud b whose idx is j (the
+ *   backward of the two grouping_operation calls, group_points_gpu.cu:69-78, for the feature part; coordinates carry no
+ *   gradient on this path).  Fully written (no zero-fill needed); LDS float atomics (order of arrival), N <= 1024. */
+int pdae_sa_group_rows(int B, int N, int np, int ns, int C, const float* xyz, const float* new_xyz,
+                       const int32_t* idx, const float* features /*nullable*/, float* out, pdae_stream_t stream);
+int pdae_sa_group_rows_grad(int B, int N, int np, int ns, int C, const int32_t* idx, const float* dout,
+                            float* dfeatures, pdae_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * k nearest neighbours.  Replaces KNN_CUDA 0.2 `knn(ref, query, k)` as used
  * through KNN(k, transpose_mode=True)(ref, query) at

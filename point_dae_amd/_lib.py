@@ -49,6 +49,8 @@ _SIGNATURES = {
     "pdae_rows_wgrad": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_wgrad_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_wgrad_listed": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_sa_group_rows": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_sa_group_rows_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_store_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_conv_groupbias_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_embed_bnrelu_conv_groupmax": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -124,6 +124,97 @@ __global__ void group_points_grad_atomic_kernel(int c, int n, int total,
   atomicAdd(grad_points_all + ((size_t)bi * c + l) * n + idx_all[(size_t)bi * total + t], v);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// QueryAndGroup in ROW layout (extensions/pointnet2/pointnet2_utils.py:345-361: grouping_operation of the coordinates,
+// minus the centre, concatenated with grouping_operation of the features) as ONE pass that writes the set-abstraction
+// MLP's input rows directly:
+//     out[(b np + p) ns + s] = [ xyz[b, idx[b,p,s]] - new_xyz[b,p] | 0 | features[b N + idx[b,p,s], :C] ]   (4 + C floats)
+// (the zero keeps K a multiple of 4 for the row GEMMs).  The PyTorch form was index_select + subtract + zeros + cat +
+// index_select: 0.56 ms at the second level of cfg2; its backward an index_add with global float atomics, 0.50 ms.
+__global__ __launch_bounds__(256) void sa_group_rows_kernel(long long total4, int Q, int N, int np, int ns,
+                                                            const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                            const int32_t* __restrict__ idx, const float* __restrict__ feat,
+                                                            float4* __restrict__ out) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;     // float4 index over (row, q)
+  if (f >= total4) return;
+  const long long r = f / Q;
+  const int q = (int)(f - r * Q);
+  const long long centre = r / ns;                                   // b np + p
+  const long long b = centre / np;
+  const long long src = b * N + idx[r];
+  float4 v;
+  if (q == 0) {
+    const float* a = xyz + src * 3;
+    const float* c = new_xyz + centre * 3;
+    v = make_float4(a[0] - c[0], a[1] - c[1], a[2] - c[2], 0.f);
+  } else {
+    v = *reinterpret_cast<const float4*>(feat + src * (long long)(4 * (Q - 1)) + 4 * (q - 1));
+  }
+  out[f] = v;
+}
+
+// Gradient to the features: dfeat[b N + j, c] = sum over the rows (p, s) of cloud b with idx = j of dout[row, 4 + c].
+// One block per (cloud, 32-channel chunk): the cloud's N x 32 accumulators live in LDS (N <= 1024), rows are added with
+// LDS float atomics (order of arrival, like group_points_grad), one plain store pass writes the result: no global
+// atomics, no zero-fill of dfeat.
+template <int CH>
+__global__ __launch_bounds__(256) void sa_group_rows_grad_kernel(int N, int np, int ns, int C, int W,
+                                                                 const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ dout, float* __restrict__ dfeat) {
+  extern __shared__ float acc[];                 // [N][CH]
+  // (cloud, chunk) -> block id chunk * B + cloud: the chunk blocks of a cloud share an XCD (ids equal mod 8), i.e. an L2
+  const int b = blockIdx.x, c0 = blockIdx.y * CH;
+  constexpr int LPR = CH / 4;                    // lanes per row: a lane owns FOUR channels (one 16-byte load per row)
+  constexpr int SUBS = 256 / LPR;                // balls in flight per block
+  const int tid = threadIdx.x, lane = tid % LPR, sub = tid / LPR;
+  for (int i = tid; i < N * CH; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int c = c0 + 4 * lane;
+  const bool chan_ok = c < C;                    // (C is a multiple of 4)
+  // A sub-group walks WHOLE balls: ball query lists a ball's members in ascending order and pre-fills the rest with the
+  // first hit, so equal indices are adjacent -- they are summed in registers and reach LDS as one add per channel.
+  // (One float per lane and row was instruction-bound: ~40 instructions per 4 bytes, 630-740 us for cfg2's second level
+  // whatever the loads in flight or the block order.)
+  constexpr int UN = 8;
+  for (int p = sub; p < np; p += SUBS) {
+    const long long row0 = ((long long)b * np + p) * ns;
+    const float* src = dout + row0 * W + 4 + c;
+    int jprev = -1;
+    float4 run = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {
+      float* a = &acc[jprev * CH + 4 * lane];
+      atomicAdd(a, run.x), atomicAdd(a + 1, run.y), atomicAdd(a + 2, run.z), atomicAdd(a + 3, run.w);
+    };
+    for (int s0 = 0; s0 < ns; s0 += UN) {
+      int j[UN];
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const bool ok = chan_ok && s0 + u < ns;
+        j[u] = ok ? idx[row0 + s0 + u] : -1;
+        v[u] = ok ? *reinterpret_cast<const float4*>(src + (long long)(s0 + u) * W) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (j[u] < 0) continue;
+        if (j[u] != jprev) {
+          if (jprev >= 0) flush();
+          jprev = j[u], run = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        run.x += v[u].x, run.y += v[u].y, run.z += v[u].z, run.w += v[u].w;
+      }
+    }
+    if (jprev >= 0) flush();
+  }
+  __syncthreads();
+  for (int i = tid; i < N * CH / 4; i += 256) {
+    const int jj = i / LPR, l = i % LPR;
+    if (c0 + 4 * l < C)
+      *reinterpret_cast<float4*>(dfeat + ((long long)b * N + jj) * C + c0 + 4 * l) = *reinterpret_cast<const float4*>(&acc[jj * CH + 4 * l]);
+  }
+}
+
 }  // namespace pdae
 
 extern "C" int pdae_ball_query(int b, int n, int m, float radius, int nsample,
@@ -178,7 +269,7 @@ extern "C" int pdae_group_points_grad(int b, int c, int n, int npoints, int nsam
   const long long total = (long long)npoints * nsample;
   hipStream_t s = as_stream(stream);
   if (total == 0) {
-    hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s);
+    (void)hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s);
     return check_launch("group_points_grad");
   }
   if (!grad_out || !idx) return bad_arg("group_points_grad: null pointer");
@@ -187,7 +278,7 @@ extern "C" int pdae_group_points_grad(int b, int c, int n, int npoints, int nsam
     hipLaunchKernelGGL(group_points_grad_kernel, dim3(c, b), dim3(256), (size_t)n * sizeof(float),
                        s, c, n, (int)total, grad_out, idx, grad_points);
   } else {
-    hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s);
+    (void)hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, s);
     hipLaunchKernelGGL(group_points_grad_atomic_kernel, dim3((unsigned)((total + 255) / 256), c, b),
                        dim3(256), 0, s, c, n, (int)total, grad_out, idx, grad_points);
   }
@@ -205,4 +296,48 @@ extern "C" int pdae_gather_points_grad(int b, int c, int n, int npoints, const f
                                        const int32_t* idx, float* grad_points,
                                        pdae_stream_t stream) {
   return pdae_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+}
+
+
+// Row-layout QueryAndGroup (pointnet2_utils.py:345-361) for the set-abstraction levels: see sa_group_rows_kernel.
+extern "C" int pdae_sa_group_rows(int B, int N, int np, int ns, int C, const float* xyz, const float* new_xyz,
+                                  const int32_t* idx, const float* features, float* out, pdae_stream_t stream) {
+  using namespace pdae;
+  if (B < 0 || N <= 0 || np < 0 || ns < 0 || C < 0) return bad_arg("sa_group_rows: bad size");
+  if (C % 4 != 0) return unsupported("sa_group_rows: the feature width must be a multiple of 4");
+  const long long rows = (long long)B * np * ns;
+  if (rows == 0) return PDAE_OK;
+  if (!xyz || !new_xyz || !idx || !out || (C > 0 && !features)) return bad_arg("sa_group_rows: null pointer");
+  const int Q = 1 + C / 4;
+  const long long total4 = rows * Q;
+  if (total4 > (1ll << 31) * 255) return unsupported("sa_group_rows: size");
+  hipLaunchKernelGGL(sa_group_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), total4, Q,
+                     N, np, ns, xyz, new_xyz, idx, features, reinterpret_cast<float4*>(out));
+  return check_launch("sa_group_rows");
+}
+
+extern "C" int pdae_sa_group_rows_grad(int B, int N, int np, int ns, int C, const int32_t* idx, const float* dout,
+                                       float* dfeatures, pdae_stream_t stream) {
+  using namespace pdae;
+  if (B < 0 || N <= 0 || np < 0 || ns < 0 || C <= 0) return bad_arg("sa_group_rows_grad: bad size");
+  if (B == 0) return PDAE_OK;
+  if (!dfeatures) return bad_arg("sa_group_rows_grad: null pointer");
+  hipStream_t s = as_stream(stream);
+  if ((long long)np * ns == 0) {
+    (void)hipMemsetAsync(dfeatures, 0, sizeof(float) * (size_t)B * N * C, s);
+    return check_launch("sa_group_rows_grad");
+  }
+  if (!idx || !dout) return bad_arg("sa_group_rows_grad: null pointer");
+  constexpr int CH = 32;
+  if ((size_t)N * CH * sizeof(float) > 128 * 1024) return unsupported("sa_group_rows_grad: more than 1024 source points per cloud");
+  if (B > 65535) return unsupported("sa_group_rows_grad: batch size");
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_group_rows_grad_kernel<CH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    once = true;
+  }
+  hipLaunchKernelGGL(sa_group_rows_grad_kernel<CH>, dim3(B, (C + CH - 1) / CH), dim3(256), (size_t)N * CH * sizeof(float), s, N,
+                     np, ns, C, 4 + C, idx, dout, dfeatures);
+  return check_launch("sa_group_rows_grad");
 }

@@ -19,13 +19,14 @@ once per coarse point and once per cloud and added by broadcasting -- the same
 sum, 25.9 -> 8.7 GFLOP per cloud.
 """
 import itertools
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import nn_ops, sa_mlp
+from . import _lib, nn_ops, sa_mlp
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from .pointnet2_utils import ball_query, furthest_point_sample_with_centres
 from .registry import MODELS
@@ -66,6 +67,39 @@ class SharedMLP(nn.Sequential):
             self.add_module('layer{}'.format(i), _ConvBN(spec[i], spec[i + 1]))
 
 
+class _GroupRows(torch.autograd.Function):
+    """QueryAndGroup in row layout (pointnet2_utils.py:345-361) as one kernel each way (csrc/ball_group.hip
+    sa_group_rows*): rows [xyz - centre | 0 | features]; gradient to the features only (coordinates are inputs)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, features):
+        B, N, _ = xyz.shape
+        _, npoint, ns = idx.shape
+        C = 0 if features is None else features.shape[1]
+        out = torch.empty((B * npoint * ns, 4 + C), device=xyz.device, dtype=torch.float32)
+        xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+        feats = features.contiguous() if features is not None else None
+        _lib.call('pdae_sa_group_rows', xyz, B, N, npoint, ns, C, _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(idx),
+                  _lib.ptr(feats), _lib.ptr(out))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, npoint, ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, N, npoint, ns, C = ctx.dims
+        if C == 0 or not ctx.needs_input_grad[3]:
+            return None, None, None, None
+        dout = dout.contiguous()
+        dfeat = torch.empty((B * N, C), device=dout.device, dtype=torch.float32)
+        _lib.call('pdae_sa_group_rows_grad', dout, B, N, npoint, ns, C, _lib.ptr(idx), _lib.ptr(dout), _lib.ptr(dfeat))
+        return None, None, None, dfeat
+
+
+GROUP_FUSED = os.environ.get('PDAE_SA_GROUP', 'fused') != 'torch'      # (A/B: the index_select / cat form)
+
+
 class PointnetSAModule(nn.Module):
     """FPS -> ball query -> group (centre-subtracted xyz || features) -> shared MLP -> max."""
 
@@ -84,11 +118,14 @@ class PointnetSAModule(nn.Module):
             with torch.no_grad():
                 _, new_xyz = furthest_point_sample_with_centres(xyz, self.npoint)
                 idx = ball_query(self.radius, self.nsample, xyz, new_xyz)          # (B,np,ns) i32
+            if GROUP_FUSED and N <= 1024 and (features is None or features.shape[1] % 4 == 0):
+                g = _GroupRows.apply(xyz, new_xyz, idx, features)      # xyz - centre | 0 | features: K a multiple of 4
+            else:
                 flat = (idx.long() + torch.arange(B, device=xyz.device).view(B, 1, 1) * N).reshape(-1)
-            g = xyz.reshape(B * N, 3).index_select(0, flat).reshape(B, self.npoint, self.nsample, 3)
-            g = (g - new_xyz.unsqueeze(2)).reshape(-1, 3)
-            zero = g.new_zeros(g.shape[0], 1)                          # xyz | 0 | features: K a multiple of 4
-            g = torch.cat([g, zero] + ([features.index_select(0, flat)] if features is not None else []), dim=1)
+                g = xyz.reshape(B * N, 3).index_select(0, flat).reshape(B, self.npoint, self.nsample, 3)
+                g = (g - new_xyz.unsqueeze(2)).reshape(-1, 3)
+                zero = g.new_zeros(g.shape[0], 1)
+                g = torch.cat([g, zero] + ([features.index_select(0, flat)] if features is not None else []), dim=1)
             groups, per = B * self.npoint, self.nsample
         else:
             new_xyz = None

@@ -159,3 +159,30 @@ def test_entries_refuse_bad_arguments():
     with pytest.raises(RuntimeError, match='1 MiB'):
         _lib._check(_lib.lib(), 'pdae_set_deterministic', _lib.lib().pdae_set_deterministic(x.data_ptr(), 1024))
     assert not _lib.deterministic()
+
+
+@pytest.mark.parametrize('B,N,npoint,ns,C', [(3, 512, 128, 64, 128), (2, 1024, 512, 32, 0), (2, 100, 7, 5, 8), (1, 64, 3, 4, 36)])
+def test_sa_group_rows_matches_the_index_select_form(B, N, npoint, ns, C):
+    """pdae_sa_group_rows / _grad (QueryAndGroup in row layout, pointnet2_utils.py:345-361) against the PyTorch form it
+    replaces: index_select of coordinates and features, minus the centre, a zero column, cat -- rows bit-equal, the
+    feature gradient to fp32 summation order (repeated indices: ball query pre-fills a ball with its first hit)."""
+    from point_dae_amd.point_cae_pointnetv2 import _GroupRows
+    g = torch.Generator(device='cuda').manual_seed(B * N + C)
+    xyz = torch.rand(B, N, 3, device='cuda', generator=g)
+    new_xyz = torch.rand(B, npoint, 3, device='cuda', generator=g)
+    idx = torch.randint(0, N, (B, npoint, ns), device='cuda', generator=g, dtype=torch.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]                                  # duplicates inside a ball
+    idx[0, 0] = 0                                                        # an empty ball: all zeros
+    feats = torch.randn(B * N, C, device='cuda', generator=g, requires_grad=True) if C else None
+    out = _GroupRows.apply(xyz, new_xyz, idx, feats)
+    flat = (idx.long() + torch.arange(B, device='cuda').view(B, 1, 1) * N).reshape(-1)
+    ref_f = feats.detach().clone().requires_grad_(True) if C else None
+    gx = (xyz.reshape(B * N, 3).index_select(0, flat).reshape(B, npoint, ns, 3) - new_xyz.unsqueeze(2)).reshape(-1, 3)
+    ref = torch.cat([gx, gx.new_zeros(gx.shape[0], 1)] + ([ref_f.index_select(0, flat)] if C else []), dim=1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    if C:
+        w = torch.randn(out.shape, device='cuda', generator=g)
+        (out * w).sum().backward()
+        (ref * w).sum().backward()
+        scale = ref_f.grad.abs().max().item()
+        assert (feats.grad - ref_f.grad).abs().max().item() <= 1e-5 * scale
