@@ -89,6 +89,7 @@ _SIGNATURES = {
     "pdae_pool_bn_backward": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_fold_input_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_fold_input_rows": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_fold_out_backward": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_deferred_flush": [_vp],
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -38,6 +38,21 @@ __global__ __launch_bounds__(256) void fold_input_kernel(long long n4, int coars
   h[i] = o;
 }
 
+// the same first layer with a PER-ROW term instead of the per-cloud / per-cell ones (the published variant's second
+// folding stage, PointCAE_transformer.py:1010-1040: the first fold's points enter the second): h[r] = relu(row[r] + p[r / cells])
+__global__ __launch_bounds__(256) void fold_input_rows_kernel(long long n4, int cells, int C4, const float4* __restrict__ row,
+                                                              const float4* __restrict__ p, float4* __restrict__ h) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long long r = i / C4;
+  const int q = (int)(i - r * C4);
+  const float4 vr = row[i], vp = p[(r / cells) * C4 + q];
+  float4 o = make_float4(vr.x + vp.x, vr.y + vp.y, vr.z + vp.z, vr.w + vp.w);
+  o.x = o.x > 0.f ? o.x : 0.f, o.y = o.y > 0.f ? o.y : 0.f;
+  o.z = o.z > 0.f ? o.z : 0.f, o.w = o.w > 0.f ? o.w : 0.f;
+  h[i] = o;
+}
+
 // block = FG_PAIRS consecutive (cloud, coarse point) pairs; thread = one channel quad x one group of
 // 256 / C4 ... rows.  Layout: tid % C4 = channel quad, tid / C4 = row phase; a phase owns the cells
 // g = phase, phase + PH, ... so its dgd accumulators stay in registers across the block's pairs.
@@ -101,6 +116,19 @@ extern "C" int pdae_fold_input(int clouds, int coarse, int cells, int C, const f
                      coarse, cells, C / 4, reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(p),
                      reinterpret_cast<const float4*>(gd), reinterpret_cast<float4*>(h));
   return check_launch("fold_input");
+}
+
+extern "C" int pdae_fold_input_rows(long long pairs, int cells, int C, const float* row, const float* p, float* h,
+                                    pdae_stream_t stream) {
+  if (pairs < 0 || cells <= 0 || C <= 0 || C % 4 != 0) return bad_arg("fold_input_rows: C must be a positive multiple of 4");
+  if (pairs == 0) return PDAE_OK;
+  if (!row || !p || !h) return bad_arg("fold_input_rows: null pointer");
+  const long long n4 = pairs * cells * (C / 4);
+  if ((n4 + 255) / 256 > 0x7fffffffLL) return unsupported("fold_input_rows: too many elements");
+  hipLaunchKernelGGL(fold_input_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), n4, cells,
+                     C / 4, reinterpret_cast<const float4*>(row), reinterpret_cast<const float4*>(p),
+                     reinterpret_cast<float4*>(h));
+  return check_launch("fold_input_rows");
 }
 
 extern "C" int pdae_fold_input_grad_parts(int clouds, int coarse) {

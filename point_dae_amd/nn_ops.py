@@ -510,7 +510,9 @@ class _FoldMLP(torch.autograd.Function):
             h1 = _empty((rows, C), p)
             _lib.call('pdae_fold_input', p, clouds, coarse, cells, C, _lib.ptr(a), _lib.ptr(p), _lib.ptr(gd), _lib.ptr(h1))
         else:      # a per-point term instead of the per-cloud / per-cell ones (the published variant's second stage)
-            h1 = torch.relu_(row.reshape(clouds * coarse, cells, C) + p.unsqueeze(1)).reshape(rows, C)
+            row = row.contiguous()
+            h1 = _empty((rows, C), p)
+            _lib.call('pdae_fold_input_rows', p, clouds * coarse, cells, C, _lib.ptr(row), _lib.ptr(p), _lib.ptr(h1))
         h2 = rows_gemm(h1, w2, False, b2, 1, big_cfg=5)
         y = rows_gemm(h2, w3, False, b3, 0)
         ctx.save_for_backward(h1, h2, w2, w3)
@@ -538,8 +540,12 @@ class _FoldMLP(torch.autograd.Function):
         d1 = rows_gemm(d2, w2.t().contiguous(), False, None, 4, h1, big_cfg=0)  # gradient of h1's pre-activation
         (dw2,), (db2,) = rows_wgrad([d2], [h1], [True])
         del d2
-        if ctx.per_row:
-            return None, d1.view(clouds * coarse, cells, C).sum(1), None, d1, dw2, db2, dw3, db3, None, None, None
+        if ctx.per_row:        # dp = the pairs' sums over their cells (fold_input_grad's first output; the per-cell partials unused)
+            pairs = clouds * coarse
+            dp = _empty((pairs, C), dy)
+            part = _empty((_lib.lib().pdae_fold_input_grad_parts(1, pairs), cells, C), dy)
+            _lib.call('pdae_fold_input_grad', dy, 1, pairs, cells, C, _lib.ptr(d1), _lib.ptr(dp), _lib.ptr(part))
+            return None, dp, None, d1, dw2, db2, dw3, db3, None, None, None
         parts = _lib.lib().pdae_fold_input_grad_parts(clouds, coarse)
         dp = _empty((clouds * coarse, C), dy)
         part = _empty((parts, cells, C), dy)
