@@ -215,8 +215,8 @@ extern "C" int pdae_emd_approxmatch(int b, int n, int m, const float* xyz1, cons
   if (!xyz1 || !xyz2 || !match) return bad_arg("emd_approxmatch: null pointer");
   const size_t lds = (size_t)(n + m) * (sizeof(float4) + 2 * sizeof(float));
   if (lds > 160 * 1024) return unsupported("emd_approxmatch: n + m > 6826 not implemented");
-  hipFuncSetAttribute(reinterpret_cast<const void*>(approxmatch_kernel),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(approxmatch_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(approxmatch_kernel, dim3(b), dim3(kEmdT), lds, as_stream(stream), n, m, xyz1,
                      xyz2, match);
   return check_launch("emd_approxmatch");
