@@ -128,7 +128,9 @@ int pdae_group_points_grad(int b, int c, int n, int npoints, int nsample,
  *   row GEMMs a multiple of 4).  One pass instead of grouping_operation x 2 + subtract + cat.
  * sa_group_rows_grad: dfeatures[b*N + j, c] = sum of dout[row, 4 + c] over the rows of cloud b whose idx is j (the
  *   backward of the two grouping_operation calls, group_points_gpu.cu:69-78, for the feature part; coordinates carry no
- *   gradient on this path).  Fully written (no zero-fill needed); LDS float atomics (order of arrival), N <= 1024. */
+ *   gradient on this path).  Fully written (no zero-fill needed).  A cloud's rows are ordered by source point with a
+ *   counting sort in LDS (integer atomics), then summed per point in registers: no float atomics; the order of a point's
+ *   rows -- hence of its fp32 sum -- is the sort's order of arrival.  N <= 4096, 4 (2 N + 1 + np ns) <= 150 KB, C <= 1024. */
 int pdae_sa_group_rows(int B, int N, int np, int ns, int C, const float* xyz, const float* new_xyz,
                        const int32_t* idx, const float* features /*nullable*/, float* out, pdae_stream_t stream);
 int pdae_sa_group_rows_grad(int B, int N, int np, int ns, int C, const int32_t* idx, const float* dout,

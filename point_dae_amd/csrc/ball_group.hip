@@ -155,63 +155,71 @@ __global__ __launch_bounds__(256) void sa_group_rows_kernel(long long total4, in
 }
 
 // Gradient to the features: dfeat[b N + j, c] = sum over the rows (p, s) of cloud b with idx = j of dout[row, 4 + c].
-// One block per (cloud, 32-channel chunk): the cloud's N x 32 accumulators live in LDS (N <= 1024), rows are added with
-// LDS float atomics (order of arrival, like group_points_grad), one plain store pass writes the result: no global
-// atomics, no zero-fill of dfeat.
-template <int CH>
-__global__ __launch_bounds__(256) void sa_group_rows_grad_kernel(int N, int np, int ns, int C, int W,
+// LDS FLOAT atomics are the wrong tool here: ds_add_f32 retires about one lane every two cycles per CU -- an accumulator
+// array in LDS fed by 134 M of them took 650 us at cfg2's second level, 119 us with the adds made plain (racy) stores.
+// So the rows of a cloud are first ORDERED BY SOURCE POINT with a counting sort in LDS (integer atomics on 8 k items:
+// histogram, prefix sum, scatter), then every point's rows are summed in registers by one sub-group reading whole
+// 4 C-byte feature rows, and written once: no float atomics, no accumulators in LDS, no zero-fill of dfeat.  SPLIT blocks
+// per cloud share the (cheap) sort and take a range of points each.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void sa_group_rows_grad_kernel(int N, int rows, int C, int W,
                                                                  const int32_t* __restrict__ idx,
                                                                  const float* __restrict__ dout, float* __restrict__ dfeat) {
-  extern __shared__ float acc[];                 // [N][CH]
-  // (cloud, chunk) -> block id chunk * B + cloud: the chunk blocks of a cloud share an XCD (ids equal mod 8), i.e. an L2
-  const int b = blockIdx.x, c0 = blockIdx.y * CH;
-  constexpr int LPR = CH / 4;                    // lanes per row: a lane owns FOUR channels (one 16-byte load per row)
-  constexpr int SUBS = 256 / LPR;                // balls in flight per block
-  const int tid = threadIdx.x, lane = tid % LPR, sub = tid / LPR;
-  for (int i = tid; i < N * CH; i += 256) acc[i] = 0.f;
+  extern __shared__ int lds_i[];                 // cnt[N] | off[N + 1] | list[rows]
+  int* cnt = lds_i;
+  int* off = lds_i + N;
+  int* list = off + N + 1;
+  const int b = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+  const int tid = threadIdx.x;
+  const int32_t* ib = idx + (long long)b * rows;
+  for (int i = tid; i < N; i += 256) cnt[i] = 0;
   __syncthreads();
-  const int c = c0 + 4 * lane;
-  const bool chan_ok = c < C;                    // (C is a multiple of 4)
-  // A sub-group walks WHOLE balls: ball query lists a ball's members in ascending order and pre-fills the rest with the
-  // first hit, so equal indices are adjacent -- they are summed in registers and reach LDS as one add per channel.
-  // (One float per lane and row was instruction-bound: ~40 instructions per 4 bytes, 630-740 us for cfg2's second level
-  // whatever the loads in flight or the block order.)
-  constexpr int UN = 8;
-  for (int p = sub; p < np; p += SUBS) {
-    const long long row0 = ((long long)b * np + p) * ns;
-    const float* src = dout + row0 * W + 4 + c;
-    int jprev = -1;
-    float4 run = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto flush = [&]() {
-      float* a = &acc[jprev * CH + 4 * lane];
-      atomicAdd(a, run.x), atomicAdd(a + 1, run.y), atomicAdd(a + 2, run.z), atomicAdd(a + 3, run.w);
-    };
-    for (int s0 = 0; s0 < ns; s0 += UN) {
-      int j[UN];
-      float4 v[UN];
+  for (int r = tid; r < rows; r += 256) atomicAdd(&cnt[ib[r]], 1);
+  __syncthreads();
+  // exclusive prefix sum of cnt (N <= 4096): one wave, N / 64 entries per lane + a shuffle scan of the lane totals
+  if (tid < 64) {
+    const int per = (N + 63) / 64, j0 = tid * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+      if (j0 + k < N) sum += cnt[j0 + k];
+    int incl = sum;
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const bool ok = chan_ok && s0 + u < ns;
-        j[u] = ok ? idx[row0 + s0 + u] : -1;
-        v[u] = ok ? *reinterpret_cast<const float4*>(src + (long long)(s0 + u) * W) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        if (j[u] < 0) continue;
-        if (j[u] != jprev) {
-          if (jprev >= 0) flush();
-          jprev = j[u], run = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        run.x += v[u].x, run.y += v[u].y, run.z += v[u].z, run.w += v[u].w;
-      }
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (tid >= d) incl += t;
     }
-    if (jprev >= 0) flush();
+    int run = incl - sum;
+    for (int k = 0; k < per; ++k)
+      if (j0 + k < N) {
+        off[j0 + k] = run;
+        run += cnt[j0 + k];
+      }
+    if (tid == 63) off[N] = incl;
   }
   __syncthreads();
-  for (int i = tid; i < N * CH / 4; i += 256) {
-    const int jj = i / LPR, l = i % LPR;
-    if (c0 + 4 * l < C)
-      *reinterpret_cast<float4*>(dfeat + ((long long)b * N + jj) * C + c0 + 4 * l) = *reinterpret_cast<const float4*>(&acc[jj * CH + 4 * l]);
+  for (int i = tid; i < N; i += 256) cnt[i] = off[i];           // cnt becomes the scatter cursor
+  __syncthreads();
+  for (int r = tid; r < rows; r += 256) list[atomicAdd(&cnt[ib[r]], 1)] = r;
+  __syncthreads();
+  // ---- sums: LPR lanes (one channel quad each) per point, SUBS points in flight
+  const int LPR = C / 4, SUBS = 256 / LPR;
+  const int lane = tid % LPR, sub = tid / LPR;
+  if (sub >= SUBS) return;
+  const int jbeg = (int)((long long)N * part / SPLIT), jend = (int)((long long)N * (part + 1) / SPLIT);
+  const float* base = dout + (long long)b * rows * W + 4 + 4 * lane;
+  constexpr int UN = 8;
+  for (int j = jbeg + sub; j < jend; j += SUBS) {
+    const int k0 = off[j], k1 = off[j + 1];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k1; k += UN) {
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long long)list[min(k + u, k1 - 1)] * W);
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (k + u < k1) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+    }
+    *reinterpret_cast<float4*>(dfeat + ((long long)b * N + j) * C + 4 * lane) = s;
   }
 }
 
@@ -320,24 +328,27 @@ extern "C" int pdae_sa_group_rows_grad(int B, int N, int np, int ns, int C, cons
                                        float* dfeatures, pdae_stream_t stream) {
   using namespace pdae;
   if (B < 0 || N <= 0 || np < 0 || ns < 0 || C <= 0) return bad_arg("sa_group_rows_grad: bad size");
+  if (C % 4 != 0 || C > 1024) return unsupported("sa_group_rows_grad: the feature width must be a multiple of 4, at most 1024");
   if (B == 0) return PDAE_OK;
   if (!dfeatures) return bad_arg("sa_group_rows_grad: null pointer");
   hipStream_t s = as_stream(stream);
-  if ((long long)np * ns == 0) {
+  const long long rows = (long long)np * ns;
+  if (rows == 0) {
     (void)hipMemsetAsync(dfeatures, 0, sizeof(float) * (size_t)B * N * C, s);
     return check_launch("sa_group_rows_grad");
   }
   if (!idx || !dout) return bad_arg("sa_group_rows_grad: null pointer");
-  constexpr int CH = 32;
-  if ((size_t)N * CH * sizeof(float) > 128 * 1024) return unsupported("sa_group_rows_grad: more than 1024 source points per cloud");
-  if (B > 65535) return unsupported("sa_group_rows_grad: batch size");
+  const size_t lds = sizeof(int) * ((size_t)2 * N + 1 + (size_t)rows);
+  if (N > 4096 || lds > 150 * 1024) return unsupported("sa_group_rows_grad: a cloud's points / rows do not fit LDS");
+  constexpr int SPLIT = 4;
+  if ((long long)B * SPLIT > 0x7fffffffLL) return unsupported("sa_group_rows_grad: batch size");
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_group_rows_grad_kernel<CH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_group_rows_grad_kernel<SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     once = true;
   }
-  hipLaunchKernelGGL(sa_group_rows_grad_kernel<CH>, dim3(B, (C + CH - 1) / CH), dim3(256), (size_t)N * CH * sizeof(float), s, N,
-                     np, ns, C, 4 + C, idx, dout, dfeatures);
+  hipLaunchKernelGGL(sa_group_rows_grad_kernel<SPLIT>, dim3(B * SPLIT), dim3(256), lds, s, N, (int)rows, C, 4 + C, idx, dout,
+                     dfeatures);
   return check_launch("sa_group_rows_grad");
 }

@@ -118,7 +118,9 @@ class PointnetSAModule(nn.Module):
             with torch.no_grad():
                 _, new_xyz = furthest_point_sample_with_centres(xyz, self.npoint)
                 idx = ball_query(self.radius, self.nsample, xyz, new_xyz)          # (B,np,ns) i32
-            if GROUP_FUSED and N <= 1024 and (features is None or features.shape[1] % 4 == 0):
+            C = 0 if features is None else features.shape[1]
+            if (GROUP_FUSED and C % 4 == 0 and C <= 1024 and N <= 4096 and
+                    4 * (2 * N + 1 + self.npoint * self.nsample) <= 150 * 1024):     # (a cloud's sort lives in LDS)
                 g = _GroupRows.apply(xyz, new_xyz, idx, features)      # xyz - centre | 0 | features: K a multiple of 4
             else:
                 flat = (idx.long() + torch.arange(B, device=xyz.device).view(B, 1, 1) * N).reshape(-1)
