@@ -313,6 +313,130 @@ __global__ void chamfer_bwd_scatter(long long total, int n, int m, const float* 
   atomicAdd(grad_b + o + 2, -(g * (xa[r * 3 + 2] - xb[o + 2])));
 }
 
+// The same scatter for MANY queries onto FEW targets (cfg2's fine loss: 16384 predictions onto 1024 ground-truth points
+// per cloud, 16+ colliding global atomics per address: 600 us of the 687 us this step spent in the kernel above).  A
+// cloud's queries are ordered by target with a counting sort in LDS, then summed run by run (below).
+template <int SPLIT>
+__global__ __launch_bounds__(256) void chamfer_bwd_scatter_sorted(int n, int m, const float* __restrict__ xa,
+                                                                  const float* __restrict__ xb,
+                                                                  const int32_t* __restrict__ idx_a,
+                                                                  const float* __restrict__ g_a, float* __restrict__ grad_b,
+                                                                  int gs, float gdiv_a) {
+  extern __shared__ int cs_lds[];                // cnt[m] | off[m + 1] | list[n]
+  int* cnt = cs_lds;
+  int* off = cs_lds + m;
+  int* list = off + m + 1;
+  const int c = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT, tid = threadIdx.x;
+  const int32_t* ia = idx_a + (size_t)c * n;
+  for (int i = tid; i < m; i += 256) cnt[i] = 0;
+  __syncthreads();
+  // Neighbouring predictions share their nearest target (the folded surface is spatially coherent): lanes of a wave
+  // that hold the same target in a row form a RUN, its first lane does ONE LDS atomic for the run (colliding LDS atomics
+  // serialise: one per lane took 710 us for the fine loss, more than the global float atomics they replaced).
+  auto run_of = [&](int t, bool valid, int& start, int& len) {
+    const int lane = tid & 63;
+    const int prev = __shfl_up(t, 1, 64);
+    const bool head = valid && (lane == 0 || t != prev || !__shfl_up((int)valid, 1, 64));
+    const unsigned long long heads = __ballot(head), live = __ballot(valid);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);           // heads at or below this lane
+    start = 63 - __clzll(below | 1ull);
+    unsigned long long above = heads & ~((2ull << lane) - 1ull);                // next head above
+    const int end_head = above ? __ffsll((long long)above) - 1 : 64;
+    const int last_live = live ? 64 - __clzll(live) : 0;
+    len = (end_head < last_live ? end_head : last_live) - start;
+    return head;
+  };
+  for (int r0 = 0; r0 < n; r0 += 256) {
+    const int r = r0 + tid;
+    const bool valid = r < n;
+    const int t = valid ? ia[r] : -1;
+    int start, len;
+    if (run_of(t, valid, start, len)) atomicAdd(&cnt[t], len);
+  }
+  __syncthreads();
+  if (tid < 64) {                                // exclusive prefix sum: m / 64 entries per lane + a shuffle scan
+    const int per = (m + 63) / 64, j0 = tid * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+      if (j0 + k < m) sum += cnt[j0 + k];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (tid >= d) incl += t;
+    }
+    int run = incl - sum;
+    for (int k = 0; k < per; ++k)
+      if (j0 + k < m) {
+        off[j0 + k] = run;
+        run += cnt[j0 + k];
+      }
+    if (tid == 63) off[m] = incl;
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) cnt[i] = off[i];
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 256) {
+    const int r = r0 + tid;
+    const bool valid = r < n;
+    const int t = valid ? ia[r] : -1;
+    int start, len;
+    int base = 0;
+    if (run_of(t, valid, start, len)) base = atomicAdd(&cnt[t], len);
+    base = __shfl(base, start, 64);                                  // the run's first lane holds its slot base
+    if (valid) list[base + ((tid & 63) - start)] = r;
+  }
+  __syncthreads();
+  // ---- sums.  The counts per target are heavy-tailed (early in training most predictions sit on a few targets): one
+  // thread per target was a serial loop over thousands of terms (741 us).  Instead the SORTED list is walked by position,
+  // 64 entries per wave; equal targets are adjacent, so a segmented shuffle scan leaves every run's total in its last
+  // lane, which adds it to the target's LDS accumulator (a few float atomics per wave, not one per term).
+  float* acc = reinterpret_cast<float*>(list + n);                 // [m][3]
+  for (int i = tid; i < 3 * m; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  // this block's share: the targets whose bins START in its quarter of the list positions -- whole bins (the order
+  // INSIDE a bin is this block's own order of arrival and differs between the blocks of a cloud; the bin boundaries,
+  // off[], do not), so every target has exactly one owner
+  auto first_bin_at_or_after = [&](int pos) {          // lower bound over off[0..m]
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] < pos) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int t_lo = first_bin_at_or_after((int)((long long)n * part / SPLIT));
+  const int t_hi = part == SPLIT - 1 ? m : first_bin_at_or_after((int)((long long)n * (part + 1) / SPLIT));
+  const int k0 = off[t_lo], k1 = off[t_hi];
+  const float* xac = xa + (size_t)c * n * 3;
+  const float* gac = g_a + (size_t)c * n * gs;
+  const float* xbc = xb + (size_t)c * m * 3;
+  for (int kb = k0; kb < k1; kb += 256) {
+    const int k = kb + tid, lane = tid & 63;
+    const bool valid = k < k1;
+    const int r = valid ? list[k] : 0;
+    const int t = valid ? ia[r] : -1;
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    if (valid) {
+      const float g = (gac[(size_t)r * gs] / gdiv_a) * 2;
+      vx = g * (xac[r * 3] - xbc[t * 3]), vy = g * (xac[r * 3 + 1] - xbc[t * 3 + 1]), vz = g * (xac[r * 3 + 2] - xbc[t * 3 + 2]);
+    }
+    int start, len;
+    run_of(t, valid, start, len);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float ux = __shfl_up(vx, d, 64), uy = __shfl_up(vy, d, 64), uz = __shfl_up(vz, d, 64);
+      if (lane - d >= start) vx += ux, vy += uy, vz += uz;
+    }
+    if (valid && lane == start + len - 1) {
+      atomicAdd(&acc[t * 3], vx), atomicAdd(&acc[t * 3 + 1], vy), atomicAdd(&acc[t * 3 + 2], vz);
+    }
+  }
+  __syncthreads();
+  float* gb = grad_b + (size_t)c * m * 3;
+  for (int i = 3 * t_lo + tid; i < 3 * t_hi; i += 256) gb[i] -= acc[i];      // one owner per target: plain update
+}
+
 static bool use_packed_bwd(int n, int m) {
   const long long clouds = (kPackT + n - 1) / n + 1;
   return n <= 256 && m <= 256 && clouds * m * 20ll <= 64 * 1024;
@@ -364,10 +488,27 @@ static int chamfer_backward_impl(int b, int n, const float* xyz1, int m, const f
                        xyz1, xyz2, idx1, grad_dist1, grad_xyz1, gs, div1);
     hipLaunchKernelGGL(chamfer_bwd_own, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2, m, n,
                        xyz2, xyz1, idx2, grad_dist2, grad_xyz2, gs, div2);
-    hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t1 + T - 1) / T)), dim3(T), 0, s, t1,
-                       n, m, xyz1, xyz2, idx1, grad_dist1, grad_xyz2, gs, div1);
-    hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((t2 + T - 1) / T)), dim3(T), 0, s, t2,
-                       m, n, xyz2, xyz1, idx2, grad_dist2, grad_xyz1, gs, div2);
+    // many queries onto few targets: the sorted form (no colliding float atomics); else atomics (few collisions)
+    auto scatter = [&](long long tq, int nq, int mt, const float* xq, const float* xt, const int32_t* iq, const float* gq,
+                       float* grad_t, float div) {
+      constexpr int SPLIT = 4;
+      const size_t lds = sizeof(int) * ((size_t)5 * mt + 1 + nq);
+      if (nq >= 4 * mt && lds <= 150 * 1024 && (long long)b * SPLIT <= 0x7fffffffLL) {
+        static bool once = false;
+        if (!once) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chamfer_bwd_scatter_sorted<SPLIT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          once = true;
+        }
+        hipLaunchKernelGGL(chamfer_bwd_scatter_sorted<SPLIT>, dim3((unsigned)(b * SPLIT)), dim3(256), lds, s, nq, mt, xq, xt,
+                           iq, gq, grad_t, gs, div);
+      } else {
+        hipLaunchKernelGGL(chamfer_bwd_scatter, dim3((unsigned)((tq + T - 1) / T)), dim3(T), 0, s, tq, nq, mt, xq, xt, iq,
+                           gq, grad_t, gs, div);
+      }
+    };
+    scatter(t1, n, m, xyz1, xyz2, idx1, grad_dist1, grad_xyz2, div1);
+    scatter(t2, m, n, xyz2, xyz1, idx2, grad_dist2, grad_xyz1, div2);
   }
   return check_launch(what);
 }

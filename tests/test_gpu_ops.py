@@ -231,7 +231,10 @@ def test_chamfer_forward_ties(oracle_ops):
 
 
 @pytest.mark.parametrize("B,n,m,exact", [(64, 32, 32, True), (37, 36, 32, True), (3, 64, 128, True),
-                                         (2, 1024, 1024, False), (1, 16384, 1024, False)])
+                                         (2, 1024, 1024, False), (1, 16384, 1024, False),
+                                         # many onto few: the counting-sort scatter (n >= 4 m), both argument orders,
+                                         # every prediction on ONE target, more blocks than one per cloud
+                                         (3, 4096, 300, False), (2, 257, 2050, False), (5, 1024, 1, False)])
 def test_chamfer_backward(oracle_ops, B, n, m, exact):
     from point_dae_amd import chamfer_dist
     rng = np.random.default_rng(67)
