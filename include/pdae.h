@@ -448,7 +448,7 @@ int pdae_pool_bn_backward(long long G, int ns, int C, const float* grad, const u
 int pdae_fold_input(int clouds, int coarse, int cells, int C, const float* a, const float* p,
                     const float* gd, float* h, pdae_stream_t stream);
 /*   fold_input_rows: the first layer with a per-ROW term instead of the per-cloud / per-cell ones (the published
- *       variant's second folding stage, models/PointCAE_transformer.py:1010-1040, where the first fold's points are the
+ *       variant's second folding stage, models/PointCAE_transformer.py:1050-1059, where the first fold's points are the
  *       extra input): h[r] = ReLU(row[r] + p[r / cells]); its backward is fold_input_grad's dp (clouds = 1). */
 int pdae_fold_input_rows(long long pairs, int cells, int C, const float* row, const float* p, float* h,
                          pdae_stream_t stream);

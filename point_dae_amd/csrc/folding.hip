@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void fold_input_kernel(long long n4, int coars
 }
 
 // the same first layer with a PER-ROW term instead of the per-cloud / per-cell ones (the published variant's second
-// folding stage, PointCAE_transformer.py:1010-1040: the first fold's points enter the second): h[r] = relu(row[r] + p[r / cells])
+// folding stage, PointCAE_transformer.py:1050-1059: the first fold's points enter the second): h[r] = relu(row[r] + p[r / cells])
 __global__ __launch_bounds__(256) void fold_input_rows_kernel(long long n4, int cells, int C4, const float4* __restrict__ row,
                                                               const float4* __restrict__ p, float4* __restrict__ h) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
