@@ -467,6 +467,20 @@ int pdae_rows_gemm_batched(int batch, int M, int N, int K, const float* X,
                            float* Y, long long strideY, pdae_stream_t stream);
 int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg,
                         int* splits, int* stream_blocks);
+/* GEMM arithmetic of the row-GEMM family (rows_gemm, rows_wgrad*; the Linear layers the reference runs through
+ * cuBLAS sgemm: models/PointCAE_transformer.py:94-158).  Both are fp32 in, fp32 out, fp32 accumulation:
+ *   PDAE_GEMM_BF16X3  (default) every operand element is split EXACTLY into three bf16 terms, x = h + m + l, and a
+ *       product is the sum of the six largest of the nine exact bf16 x bf16 partial products (hh, hm, mh, hl, lh, mm;
+ *       the dropped ones are below 2^-25 of the product) accumulated in fp32 on v_mfma_f32_32x32x16_bf16, the hh
+ *       terms and the small terms in separate accumulators.  Error against fp64 at or below the fp32-input MFMA
+ *       kernels' on every shape of the models (tests/test_gpu_rows3.py), 2.67x their matrix-pipe ceiling.  Reductions
+ *       with K % 32 != 0 run on the fp32-input kernels in either mode.
+ *   PDAE_GEMM_F32MFMA v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain (the reference's arithmetic class bit for bit
+ *       up to summation order).  Also selected by the environment variable PDAE_GEMM=f32mfma at first use.
+ * Set before planning: pdae_rows_gemm_plan / the workspace queries answer for the arithmetic in force. */
+enum { PDAE_GEMM_F32MFMA = 0, PDAE_GEMM_BF16X3 = 1 };
+int pdae_set_gemm_arith(int arith);
+int pdae_gemm_arith(void);
 int pdae_rows_wgrad_workspace(int M, int nprob, const int* Ns, const int* Ks,
                               long long* floats);
 int pdae_rows_wgrad(int M, int nprob, const float* const* dY,

@@ -109,6 +109,8 @@ _HOST = {
     "pdae_fold_out_backward_parts": [ctypes.c_longlong],
     "pdae_pool_bn_backward_workspace": [ctypes.c_longlong, _i],
     "pdae_deterministic": [],
+    "pdae_set_gemm_arith": [_i],
+    "pdae_gemm_arith": [],
 }
 _STR = ("pdae_version", "pdae_last_error")
 
@@ -227,10 +229,15 @@ def require(t, name, dtype=torch.float32, dim=None):
     return t
 
 
+CALL_HOOK = None      # tools / tests: callable(name, args) seen by every C entry call (e.g. tools/dump_gemm_shapes.py)
+
+
 def call(name, on, *args):
     """Invoke one C entry on torch's current stream of `on`'s device; raise on a
     non-zero status."""
     handle = lib()
+    if CALL_HOOK is not None:
+        CALL_HOOK(name, args)
     if not _env_checked:
         _env_mode()
     if on.device.index != torch.cuda.current_device():
@@ -266,6 +273,21 @@ def rows_gemm_plan(M, N, K, w_kn, may_split):
 
 
 _wg_cache = {}
+
+GEMM_F32MFMA, GEMM_BF16X3 = 0, 1
+
+
+def gemm_arith():
+    """The row-GEMM family's arithmetic: GEMM_BF16X3 (exact-split bf16, default) or GEMM_F32MFMA (include/pdae.h)."""
+    return lib().pdae_gemm_arith()
+
+
+def set_gemm_arith(arith):
+    """pdae_set_gemm_arith; the cached plans / workspace sizes answered for the old arithmetic are dropped."""
+    handle = lib()
+    _check(handle, 'pdae_set_gemm_arith', handle.pdae_set_gemm_arith(int(arith)))
+    _plan_cache.clear()
+    _wg_cache.clear()
 
 
 def rows_wgrad_workspace(M, Ns, Ks):

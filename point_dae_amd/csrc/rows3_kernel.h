@@ -1,0 +1,780 @@
+// rows3_kernel.h -- fp32 GEMMs on the bf16 matrix pipe with EXACT-SPLIT operands ("bf16x3, six products").
+//
+// Every fp32 operand element x is split into three bf16 terms, x = h + m + l EXACTLY (h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m); round-to-nearest at each stage, the residuals are exact in fp32).  A product a.b is then the
+// sum of nine bf16 x bf16 products, each EXACT in fp32; the six largest -- hh, hm, mh, hl, lh, mm -- are accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16, the three dropped ones (ml, lm, ll) are below 2^-25 of the product.  hh goes to one
+// accumulator, the five small terms to a second one (the sum of the small terms is 2^-8 of the result: its roundings
+// do not count, and the hh chain sees K / 16 accumulator roundings where v_mfma_f32_32x32x2_f32 sees K / 2), added once
+// in the epilogue: measured error against fp64 is at or below the fp32-input MFMA kernels' (tests/test_gpu_rows3.py).
+// The bf16 pipe runs 16x the fp32-input MFMA rate: six products are 2.67x the fp32 kernels' ceiling.
+//
+// The split happens while a tile is staged: global (fp32) -> registers -> split -> LDS as three bf16 planes
+// [plane][row][32 k], K CONTIGUOUS whatever the operand's layout in memory -- an operand stored along the reduction
+// ([M,K] activations, [N,K] weights) is staged in octets of a row, one stored ACROSS it (the [K,N] weight of a data
+// gradient, both operands of a weight gradient) in patches of 8 k x PW columns that a thread transposes in registers.
+// No divergent branch in any main loop: threads without a piece of their own repeat another thread's (same loads, same
+// stores), rows and columns past an edge are clamped addresses (and zeros by select where they enter a sum).
+// Fragments are then one ds_read_b128 per (32-row tile, plane, 16-deep step) for every form.
+#pragma once
+#include <type_traits>
+
+#include "rows_common.h"
+
+namespace pdae {
+namespace rows3 {
+
+using rows::Args;
+using rows::f32x16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK3 = 32;          // reduction depth of one staged tile (two 16-deep MFMA steps)
+
+// The split of eight fp32 (an octet: 8 k of one row) into three planes of eight bf16, x = h + m + l exactly, cut in
+// eight CHUNKS of 5-6 VALU instructions so that the main loop can place one chunk behind each MFMA: chunks 0-3 take
+// the h term of the pairs (v[2q], v[2q+1]) and leave the residual in v, chunks 4-7 the m and l terms.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  f32x2 x = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+}
+template <int C>
+__device__ __forceinline__ void split_chunk(float (&v)[8], u32x4 (&pk)[3]) {
+  constexpr int q = C & 3;
+  const unsigned t = cvt_pk_bf16(v[2 * q], v[2 * q + 1]);
+  v[2 * q] = v[2 * q] - __uint_as_float(t << 16);
+  v[2 * q + 1] = v[2 * q + 1] - __uint_as_float(t & 0xffff0000u);
+  if (C < 4) {
+    pk[0][q] = t;
+  } else {
+    pk[1][q] = t;
+    pk[2][q] = cvt_pk_bf16(v[2 * q], v[2 * q + 1]);
+  }
+}
+
+// product q (0..5) of one (A tile, B tile) pair and 16-deep step: the five small terms first into `lo`, hh into `hi`
+// (DUAL false: everything into `hi`).  Planes: 0 = h, 1 = m, 2 = l.
+template <bool DUAL, int Q>
+__device__ __forceinline__ void mfma_one(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  if (DUAL && Q < 5) lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[Q]], b[PB[Q]], lo, 0, 0, 0);
+  else hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[Q]], b[PB[Q]], hi, 0, 0, 0);
+}
+
+// compile-time loop: f(integral_constant<int, I>) for I = 0 .. N - 1
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+// C[M,N] = epi(A[M,K] . op(B)), the contract of rows::rows_gemm_kernel (same Args, same epilogues, same split-K /
+// stream-K slab forms) for K % 32 == 0.  Block tile (32 TI WM) x (32 TJ WN), WM WN waves of TI x TJ MFMA tiles; an LDS
+// tile holds KS 16-deep steps of the reduction (KS = 2: 80-B rows; KS = 1: 48-B rows, half the LDS, so that TWO blocks
+// fit a CU and one block's first loads and epilogue run under the other's MFMAs).
+// Pipeline per LDS tile t (double-buffered, ONE barrier per tile), written as S = 6 KS TI TJ SLOTS of one MFMA each
+// with a share of the side work behind it, the order pinned by a sched_barrier per slot (one wave issues in order: an
+// MFMA holds the vector issue port 8 of its 32 cycles, ~5 other instructions ride in its shadow; left to the compiler
+// the split lands behind the MFMAs in one block and the waves of a SIMD alternate between an all-MFMA and an all-VALU
+// phase in lockstep):
+//   slots of step 0 (KS = 2)           + the fragment reads of step 1 (same LDS tile)
+//   slots [0, SB - 1)                  + the split chunks of tile t + 1 (A octets, then B), each plane stored to
+//                                        LDS[buf ^ 1] when complete; an operand's registers are then re-loaded with tile
+//                                        t + 3: TWO register sets, two tiles of global loads in flight
+//   barrier behind slot SB - 1
+//   slots [SB, S)                      + the fragment reads of tile t + 1, step 0
+// Fragments live in two register sets (the stage of a 16-deep step alternates), register sets and fragment stages are
+// indexed statically: the tile loop is unrolled by two.  The loop is branch-free: past the end the last tile is loaded
+// / split / stored again (into the buffer nobody reads).
+template <int TI, int TJ, int WM, int WN, int KS, bool BKN, int EPI, bool DUAL, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
+  constexpr int ROWB = KS == 2 ? 80 : 48;                     // bytes per LDS row: 16 KS bf16 + 16 B
+  constexpr int BKT = 16 * KS;                                // reduction depth of an LDS tile
+  constexpr int OPR = 2 * KS;                                 // octets (8 k) per row and tile
+  constexpr int PLANE = (BM + BN) * ROWB, BUF = 3 * PLANE;
+  constexpr int OA = (BM * OPR + NT - 1) / NT;                // octets of A per thread and tile
+  constexpr int OB = (BN * OPR + NT - 1) / NT;                // octets of B (k-contiguous) / patches (8 k x 1 column)
+  constexpr int G = TI * TJ;
+  static_assert(BM % 8 == 0 && BN % 8 == 0, "staging map");
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+  const int KTA = p.K / BK3;                                  // (work units stay 32 deep: the plan's unit)
+  const long long units = (long long)p.tiles * KTA;
+  long long u = 0, uend = 1;
+  int sb = 0;
+  if (p.stream_blocks) {
+    const int P = p.stream_blocks;
+    sb = (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3);
+    u = sb * units / P, uend = (sb + 1) * units / P;
+    if (u >= uend) return;
+  } else {
+    const int chunk = (p.tiles + 7) >> 3;
+    const int slot = blockIdx.x >> 3;
+    if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
+  }
+  // octet o of an operand tile -> (row, octet of the row): eight consecutive lanes hit eight different 16-B slots of
+  // the 128-B window a ds_write_b128 group covers (80-B rows: two rows four apart; 48-B rows: four rows two apart)
+  auto octet_row = [](int o) { return KS == 2 ? ((o >> 5) << 3) + (((o >> 2) & 1) << 2) + ((o >> 3) & 3)
+                                              : ((o >> 4) << 3) + (((o >> 1) & 3) << 1) + ((o >> 3) & 1); };
+  auto octet_col = [](int o) { return KS == 2 ? (o & 3) : (o & 1); };
+  for (;;) {
+    int tile, kbeg, kend, piece = 0;
+    bool tile_ends = false;
+    if (p.stream_blocks) {
+      tile = (int)(u / KTA);
+      const int k0 = (int)(u % KTA), k1 = (int)min((long long)KTA, k0 + (uend - u));
+      u += k1 - k0;
+      kbeg = k0 * BK3, kend = k1 * BK3;
+      tile_ends = k1 == KTA;
+      const long long uf = (long long)tile * KTA;
+      piece = sb - (int)(((uf + 1) * p.stream_blocks - 1) / units);
+    } else {
+      tile = (int)(blockIdx.x & 7) * ((p.tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+      kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+      piece = blockIdx.y;
+    }
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int KT = (kend - kbeg) / BKT;
+    // 32-bit byte offsets of this thread's staged pieces from the (uniform) operand bases; rows / columns past the
+    // matrix edge are clamped (their products are never stored)
+    unsigned aoff[OA], boff[OB];
+    int alds[OA], blds[OB];
+#pragma unroll
+    for (int i = 0; i < OA; ++i) {
+      const int o = (tid + i * NT) % (BM * OPR), row = octet_row(o), oc = octet_col(o);   // (past the tile: an earlier octet again)
+      aoff[i] = ((unsigned)min(m0 + row, M - 1) * (unsigned)p.lda + oc * 8) * 4u;
+      alds[i] = row * ROWB + oc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < OB; ++i) {
+      const int o = (tid + i * NT) % (BN * OPR);
+      if (BKN) {
+        const int kg = o / BN, col = o % BN;                  // patch: k = 8 kg .. 8 kg + 7 of column col
+        boff[i] = ((unsigned)(8 * kg) * (unsigned)p.ldb + (unsigned)min(n0 + col, N - 1)) * 4u;
+        blds[i] = (BM + col) * ROWB + kg * 16;
+      } else {
+        const int row = octet_row(o), oc = octet_col(o);
+        boff[i] = ((unsigned)min(n0 + row, N - 1) * (unsigned)p.ldb + oc * 8) * 4u;
+        blds[i] = (BM + row) * ROWB + oc * 16;
+      }
+    }
+    const char* Ab = reinterpret_cast<const char*>(p.A + (size_t)blockIdx.z * p.strideA) + (size_t)kbeg * 4;
+    const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)blockIdx.z * p.strideB) +
+                     (BKN ? (size_t)kbeg * p.ldb * 4 : (size_t)kbeg * 4);
+    const size_t bstep = BKN ? (size_t)p.ldb * 4 : 4;         // bytes per unit of k in B
+    const unsigned ldb4 = (unsigned)p.ldb * 4u;
+
+    float ra[2][OA][8], rb[2][OB][8];                         // two register sets of staged fp32
+    u32x4 pka[OA][3], pkb[OB][3];
+    auto gload_a = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const char* Ak = Ab + (size_t)min(kt, KT - 1) * BKT * 4;
+#pragma unroll
+      for (int i = 0; i < OA; ++i) {
+        {
+          const float4 v0 = *reinterpret_cast<const float4*>(Ak + aoff[i]);
+          const float4 v1 = *reinterpret_cast<const float4*>(Ak + aoff[i] + 16);
+          ra[set][i][0] = v0.x, ra[set][i][1] = v0.y, ra[set][i][2] = v0.z, ra[set][i][3] = v0.w;
+          ra[set][i][4] = v1.x, ra[set][i][5] = v1.y, ra[set][i][6] = v1.z, ra[set][i][7] = v1.w;
+        }
+      }
+    };
+    auto gload_b = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const char* Bk = Bb + (size_t)min(kt, KT - 1) * BKT * bstep;
+#pragma unroll
+      for (int i = 0; i < OB; ++i) {
+        {
+          if (BKN) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rb[set][i][q] = *reinterpret_cast<const float*>(Bk + boff[i] + q * ldb4);
+          } else {
+            const float4 v0 = *reinterpret_cast<const float4*>(Bk + boff[i]);
+            const float4 v1 = *reinterpret_cast<const float4*>(Bk + boff[i] + 16);
+            rb[set][i][0] = v0.x, rb[set][i][1] = v0.y, rb[set][i][2] = v0.z, rb[set][i][3] = v0.w;
+            rb[set][i][4] = v1.x, rb[set][i][5] = v1.y, rb[set][i][6] = v1.z, rb[set][i][7] = v1.w;
+          }
+        }
+      }
+    };
+    // chunk c of the side work of one tile: octet c / 8 (A octets first), chunk c % 8 of its split; the h plane is
+    // stored behind chunk 3, the m and l planes behind chunk 7
+    auto side_chunk = [&](auto c_c, auto set_c, int buf, auto abl_c) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8, abl = decltype(abl_c)::value;
+      constexpr int set = decltype(set_c)::value;
+      auto run = [&](float (&v)[8], u32x4 (&pk)[3], char* d) __attribute__((always_inline)) {
+        if constexpr (abl & 2) {                              // (lab) no split arithmetic: the raw bits as "planes"
+          if (ch < 4) pk[0][ch] = __float_as_uint(v[2 * ch]), pk[1][ch] = __float_as_uint(v[2 * ch + 1]), pk[2][ch] = pk[0][ch];
+        } else {
+          split_chunk<ch>(v, pk);
+        }
+        if constexpr (abl & 4) {
+          if (ch == 7) asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]));
+          return;
+        }
+        if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[0];
+        if (ch == 7) {
+          *reinterpret_cast<u32x4*>(d + PLANE) = pk[1];
+          *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[2];
+        }
+      };
+      if constexpr (o < OA) {
+        run(ra[set][o], pka[o], lds3 + buf * BUF + alds[o]);
+      } else {
+        constexpr int i = o - OA;
+        run(rb[set][i], pkb[i], lds3 + buf * BUF + blds[i]);
+      }
+    };
+
+    f32x16 hi[TI][TJ], lo[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+
+    bf16x8 fa[2][TI][3], fb[2][TJ][3];                        // fragments: [stage][tile][plane]
+    const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (BM + wn * TJ * 32 + r) * ROWB + 16 * h;
+    constexpr int NF = 3 * (TI + TJ);                         // fragment reads of one 16-deep step
+    // read f of a step, in the order the MFMAs want them: A0.l B0.h A0.h B0.l A0.m B0.m, then the other tiles
+    auto frag_one = [&](auto f_c, auto st_c, int buf, int s16) __attribute__((always_inline)) {
+      constexpr int f = decltype(f_c)::value, st = decltype(st_c)::value;
+      constexpr int FPL[6] = {2, 0, 0, 2, 1, 1};
+      constexpr bool isa = f < 6 ? (f % 2 == 0) : (f - 6 < 3 * (TI - 1));
+      constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
+      constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
+      const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
+      if (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+      else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
+    };
+    constexpr int S = 6 * G * KS;                             // slots (MFMAs) of a tile
+    constexpr int NR = (NF + 2) / 3;                          // slots behind the barrier: three fragment reads each
+    constexpr int SB = S - NR;                                // the barrier sits behind slot SB - 1
+    constexpr int NC = 8 * (OA + OB);                         // split chunks of a tile
+    constexpr int SC = SB - 1 > 0 ? SB - 1 : 1;               // ... spread over slots [0, SC)
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+
+    // one LDS tile kt of parity P: MFMAs on LDS[P] (fragment stage P for KS = 1; stages 0, 1 for the two steps of
+    // KS = 2), split of register set P ^ 1 (tile kt + 1) into LDS[P ^ 1], loads of tile kt + 3 into that set
+    auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
+      constexpr int P = decltype(par_c)::value;
+      using SetN = std::integral_constant<int, P ^ 1>;
+      static_for<S>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int step = s / (6 * G), g = (s % (6 * G)) / 6, q = s % 6;
+        constexpr int stg = KS == 2 ? step : P;               // fragment stage of this slot's MFMA
+        mfma_one<DUAL, q>(fa[stg][g / TJ], fb[stg][g % TJ], hi[g / TJ][g % TJ], lo[g / TJ][g % TJ]);
+        if constexpr (KS == 2) {                              // fragment reads of step 1: NF reads over the step-0 slots
+          static_for<NF>([&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (f * (6 * G) / NF == s && !(ABL & 16)) frag_one(f_c, C1{}, P, 1);
+          });
+        }
+        static_for<NC>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value;
+          if constexpr (c * SC / NC == s) side_chunk(c_c, SetN{}, P ^ 1, std::integral_constant<int, ABL>{});
+        });
+        if constexpr (s == (8 * OA - 1) * SC / NC && !(ABL & 1)) gload_a(SetN{}, kt + 3);
+        if constexpr (s == (NC - 1) * SC / NC && !(ABL & 1)) gload_b(SetN{}, kt + 3);
+        if constexpr (s == SB - 1 && !(ABL & 8)) __syncthreads();
+        if constexpr (s >= SB) {
+          static_for<NF>([&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (f / 3 == s - SB && !(ABL & 16))
+              frag_one(f_c, std::integral_constant<int, (KS == 2 ? 0 : P ^ 1)>{}, P ^ 1, 0);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    if (KT > 0) {
+      gload_a(C0{}, 0);
+      gload_b(C0{}, 0);
+      gload_a(C1{}, 1);
+      gload_b(C1{}, 1);
+      static_for<NC>([&](auto c_c) { side_chunk(c_c, C0{}, 0, C0{}); });
+      gload_a(C0{}, 2);
+      gload_b(C0{}, 2);
+      __syncthreads();
+      static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
+      for (int kt = 0; kt < KT; kt += 2) {
+        ktile(C0{}, kt);
+        if (kt + 1 < KT) ktile(C1{}, kt + 1);
+      }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    float* Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)piece * p.slab;
+    auto epilogue = [&](auto full_c, auto zero_c) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_c)::value;
+      constexpr bool ZERO = decltype(zero_c)::value;
+      const unsigned ldc = (unsigned)p.ldc;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wn * TJ + j) * 32 + r;
+        const bool colok = FULL || col < N;
+        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int rbase = m0 + (wm * TI + i) * 32 + 4 * h;
+          const size_t off = (size_t)rbase * ldc + col;
+          float zv[16];
+          if ((EPI == rows::EPI_MUL_GELUGRAD || EPI == rows::EPI_MUL_POS) && !ZERO) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int lr = (e & 3) + 8 * (e >> 2);
+              zv[e] = (FULL || (colok && rbase + lr < M)) ? p.Z[off + (unsigned)lr * ldc] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2);
+            if (!FULL && !(colok && rbase + lr < M)) continue;
+            if (ZERO) {
+              Cs[off + (unsigned)lr * ldc] = 0.f;
+              continue;
+            }
+            float v = (DUAL ? hi[i][j][e] + lo[i][j][e] : hi[i][j][e]) + bv;
+            if (EPI == rows::EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+            if (EPI == rows::EPI_BIAS_GELU2) {
+              const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+              const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+              p.Z[off + (unsigned)lr * ldc] = cdf + v * pdf;
+              v = v * cdf;
+            }
+            if (EPI == rows::EPI_MUL_GELUGRAD) v *= zv[e];
+            if (EPI == rows::EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;
+            Cs[off + (unsigned)lr * ldc] = v;
+          }
+        }
+      }
+    };
+    const bool full = m0 + BM <= M && n0 + BN <= N;
+    if (full) epilogue(std::true_type{}, std::false_type{});
+    else epilogue(std::false_type{}, std::false_type{});
+    if (!p.stream_blocks) break;
+    if (tile_ends)
+      for (int q = piece + 1; q < p.slabs; ++q) {
+        Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)q * p.slab;
+        if (full) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::true_type{});
+      }
+    if (u >= uend) break;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradients dW_p[N_p, K_p] = dY_p^T . X_p on the same arithmetic: the work layout, the partial-tile
+// slots and the ordered reduction of rows::wgrad_kernel (rows_common.h), the reduction over rows m in 16-row slabs.
+// Both operands are stored ACROSS the reduction ([m][column]): a thread stages a patch of 8 m x PW columns of the
+// joint [dY band | X band] slab -- eight loads down the rows, the transpose is free in registers -- and writes PW
+// octets per plane, so LDS holds [plane][column][16 m] (48-B rows: ds_read_b128 slots 3 r + h mod 16, conflict-free)
+// and a fragment is one ds_read_b128 exactly as in gemm3_kernel.  Output tile 128 (n) x TN (k), waves 2 x (NT / 128)
+// of 64 x (TN 128 / NT): TI = 2 tile rows, TJ = 2 or 3 tile columns per wave.
+// ONE register set of fragments, refreshed in place: MFMAs run tile row 0 first, the barrier sits behind tile (1, 0),
+// and each fragment of the next slab is read behind the last MFMA that uses the old one (A0 and B0 behind the barrier,
+// B_j behind tile (1, j)); the two that live to the end (A1, B_last) are read at the top of the next slab, ahead of
+// their first use.
+template <int TN, int NT, bool DUAL, bool FORMS>
+__global__ __launch_bounds__(NT, 2) void wgrad3_kernel(const rows::WgradArgs g) {
+  using rows::WgradProb;
+  constexpr int TM = rows::WTM, COLS = TM + TN, SLB = rows::TBK, WCH = rows::WCH;
+  constexpr int WNV = NT / 128;                        // waves along k (two along n)
+  constexpr int TI = 2, TJ = TN / (32 * WNV), G = TI * TJ;
+  constexpr int ROWW = 48;                             // bytes per LDS row: 16 bf16 + 16 B pad
+  constexpr int PLANE = COLS * ROWW, BUF = 3 * PLANE;
+  constexpr int PW = (2 * COLS + NT - 1) / NT;         // columns per patch: a slab is 2 m-octets x COLS columns
+  constexpr int CPP = COLS / PW, NPATCH = 2 * CPP;
+  constexpr int WSLOT = rows::wslot(TN);
+  static_assert(TJ >= 2 && TN % (32 * WNV) == 0 && COLS % PW == 0 && NPATCH <= NT && TM % PW == 0, "tile / patch layout");
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNV, wn = wave % WNV;
+  const int r = lane & 31, h = lane >> 5;
+  // every thread stages a patch: threads past the last patch repeat an earlier one (same loads, same LDS stores of
+  // the same values) -- no divergent branch anywhere in the loop; only the column sums count a patch once
+  const bool active = tid < NPATCH;
+  const int pid = active ? tid : tid - NPATCH;
+  const int mg = pid / CPP, col = (pid % CPP) * PW;    // this thread's patch: rows 8 mg .. 8 mg + 7, columns col ..
+  const bool isb = col >= TM;
+  const int plds = col * ROWW + mg * 16;
+  const int nb8 = g.blocks >> 3;
+  const int sb = g.blocks % 8 == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long u = rows::wg_start(g, sb);
+  const long long uend = rows::wg_start(g, sb + 1);
+  float* slot = g.partials + (size_t)sb * g.slots * WSLOT;
+  const int fa_off = (wm * 64 + r) * ROWW + 16 * h, fb_off = (TM + wn * TJ * 32 + r) * ROWW + 16 * h;
+  for (; u < uend; slot += WSLOT) {
+    const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
+    const long long rel = u - P.unit0;
+    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
+    u += c1 - c0;
+    const int bx = lt % P.tk, by = lt / P.tk;
+    const int n0 = by * TM, k0 = bx * TN;
+    const int mbeg = c0 * WCH, mend = min(P.M, c1 * WCH);
+    const int gcol = isb ? k0 + col - TM : n0 + col;
+    const int glim = isb ? P.K : P.N;                 // (N, K are multiples of 4, col of PW: a patch is inside or outside)
+    const bool ok = gcol < glim;
+    // which band, which m-octet: the same for a whole wave (64 consecutive patches lie in one band) -- row pointers
+    // are then SCALAR (base + row * ld in SGPRs) and a thread carries one 32-bit column offset
+    const bool isb_u = __builtin_amdgcn_readfirstlane((int)isb) != 0;
+    const int mg_u = __builtin_amdgcn_readfirstlane(mg);
+    const float* const base_u = isb_u ? P.X : P.dY;
+    const unsigned ld = isb_u ? P.K : P.N;
+    const unsigned colb = (unsigned)min(gcol, glim - PW);      // columns past the edge: a valid address, zeros staged
+    const bool sum_a = P.db != nullptr && bx == 0 && !isb && active;
+    // FORMS: the embedder's operand forms (listed 32-row groups, BatchNorm + ReLU recomputed on the X band); the
+    // Transformer stacks' instantiation carries none of their registers
+    const int* const grp_a = FORMS ? g.a_groups : nullptr;
+    const int* const grp_b = FORMS ? g.b_groups : nullptr;
+    const bool listed = FORMS && (grp_a != nullptr || grp_b != nullptr);
+    const bool bnrelu = FORMS && g.scale != nullptr;  // (block-uniform)
+    float bsc[PW], bsh[PW], asum[PW];
+    float floor_ = -__builtin_inff();                 // ReLU only on the X band's threads
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+      bsc[c] = 1.f, bsh[c] = 0.f, asum[c] = 0.f;
+      if (bnrelu && isb && ok) bsc[c] = g.scale[gcol + c], bsh[c] = g.shift[gcol + c], floor_ = 0.f;
+    }
+    float v[PW][8];
+    u32x4 pk[PW][3];
+    // eight loads down the rows, unconditional (rows past the end re-read the last row), then zeros by select: a
+    // load behind a per-row branch would cost one memory round trip per row
+    auto gload = [&](int mt) __attribute__((always_inline)) {
+      const int mlast = mend - 1;
+      int off = 0;                                     // stored row - product row of this slab (listed operands)
+      if (listed) {
+        const int gq = min(mt, mlast) >> 5;
+        if (isb_u ? grp_b != nullptr : grp_a != nullptr) off = ((isb_u ? grp_b : grp_a)[gq] - gq) * 32;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = mt + 8 * mg_u + q;                                      // (scalar)
+        const float* sp = base_u + (size_t)(min(m, mlast) + off) * ld + colb;
+        if (PW == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(sp);
+          v[0][q] = t.x, v[PW - 1][q] = t.y;
+        } else {
+          v[0][q] = *sp;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool in = ok && mt + 8 * mg_u + q < mend;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+          float t = v[c][q];
+          if (bnrelu) t = fmaxf(t * bsc[c] + bsh[c], floor_);
+          v[c][q] = in ? t : 0.f;
+        }
+      }
+    };
+    const bool sum_u = __builtin_amdgcn_readfirstlane((int)sum_a) != 0;   // (a wave stages one band: scalar branch)
+    auto colsums = [&]() __attribute__((always_inline)) {
+      if (sum_u) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) asum[c] += v[c][q];
+      }
+    };
+    auto side_chunk = [&](auto c_c, int buf) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8;
+      char* d = lds3 + buf * BUF + plds + o * ROWW;
+      split_chunk<ch>(v[o], pk[o]);
+      if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[o][0];
+      if (ch == 7) {
+        *reinterpret_cast<u32x4*>(d + PLANE) = pk[o][1];
+        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[o][2];
+      }
+    };
+    f32x16 hi[TI][TJ], lo[DUAL ? TI : 1][DUAL ? TJ : 1];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          hi[i][j][e] = 0.f;
+          if (DUAL) lo[DUAL ? i : 0][DUAL ? j : 0][e] = 0.f;
+        }
+    bf16x8 fa[TI][3], fb[TJ][3];
+    auto read_a = [&](int i, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fa[i][pl] = *reinterpret_cast<const bf16x8*>(lds3 + buf * BUF + pl * PLANE + fa_off + i * 32 * ROWW);
+    };
+    auto read_b = [&](int j, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fb[j][pl] = *reinterpret_cast<const bf16x8*>(lds3 + buf * BUF + pl * PLANE + fb_off + j * 32 * ROWW);
+    };
+    constexpr int S = 6 * G;                           // slots (MFMAs) of a slab
+    constexpr int SBW = 6 * TJ + 6;                    // the barrier sits behind slot SBW - 1: tile row 0 and tile (1, 0) done
+    constexpr int NC = 8 * PW, SC = SBW - 1;           // split chunks of a slab, spread over slots [0, SC)
+    const int nslab = (mend - mbeg + SLB - 1) / SLB;
+    gload(mbeg);
+    colsums();
+    static_for<NC>([&](auto c_c) { side_chunk(c_c, 0); });
+    gload(mbeg + SLB);
+    __syncthreads();
+    read_a(0, 0);
+#pragma unroll
+    for (int j = 0; j < TJ - 1; ++j) read_b(j, 0);
+    int buf = 0;
+    for (int sl = 0; sl < nslab; ++sl) {
+      const bool more1 = sl + 1 < nslab;
+      // the two fragments that lived to the end of the previous slab
+      read_a(1, buf);
+      read_b(TJ - 1, buf);
+      if (more1) colsums();
+      static_for<S>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int gi = s / 6, q = s % 6, i = gi / TJ, j = gi % TJ;
+        mfma_one<DUAL, q>(fa[i], fb[j], hi[i][j], lo[DUAL ? i : 0][DUAL ? j : 0]);
+        static_for<NC>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value;
+          if constexpr (c * SC / NC == s) side_chunk(c_c, buf ^ 1);
+        });
+        if constexpr (s == (NC - 1) * SC / NC) gload(mbeg + (sl + 2) * SLB);
+        if constexpr (s == SBW - 1) {
+          __syncthreads();
+          read_a(0, buf ^ 1);                          // tile row 0 and tile (1, 0) are done: A0 and B0 are free
+          read_b(0, buf ^ 1);
+        }
+        // behind the last MFMA of tile (1, j): B_j is free (the last one is read at the top of the next slab)
+        if constexpr (s >= SBW && q == 5 && j < TJ - 1) read_b(j, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      buf ^= 1;
+    }
+    // ---- the partial tile (whole TM x TN, edges included: the reduction stores what is inside)
+    __syncthreads();                                   // (the refresh reads above touched the buffer nobody needs)
+    if (P.db != nullptr && bx == 0) {
+      float* red = reinterpret_cast<float*>(lds3);     // [2 m-octets][TM]; the slab buffers are free now
+      if (active && !isb) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c) red[mg * TM + col + c] = asum[c];
+      }
+      __syncthreads();
+      if (tid < TM) slot[TM * TN + tid] = red[tid] + red[TM + tid];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          slot[row * TN + wn * TJ * 32 + j * 32 + r] =
+              DUAL ? hi[i][j][e] + lo[DUAL ? i : 0][DUAL ? j : 0][e] : hi[i][j][e];
+        }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same weight gradients on gemm3_kernel's pipeline: output tile 128 (n) x 128 (k), eight waves of 32 x 64, 32-row
+// LDS tiles (two 16-deep steps per barrier), fragments in two register sets, TWO register sets of staged fp32 (two
+// tiles of global loads in flight: the single-set kernel above waits for every slab's loads).  Both bands are staged
+// in patches of 8 m x 1 column: thread -> (m-octet tid / 128, column tid % 128) of the dY band AND of the X band, row
+// pointers scalar, one 32-bit column offset per band.  Rows past the end of a segment, columns past the matrix edge,
+// the BatchNorm + ReLU producer and the column sums are applied to a register set right before it is split
+// (`fixup`, skipped by a block-uniform branch on whole tiles without a producer).
+template <bool FORMS>
+__global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
+  using rows::WgradProb;
+  constexpr int TM = rows::WTM, TN = 128, WCH = rows::WCH, BKT = 32, ROWB = 80;
+  constexpr int PLANE = (TM + TN) * ROWB, BUF = 3 * PLANE;
+  constexpr int TI = 1, TJ = 2, G = TI * TJ, WN = 2;
+  constexpr int WSLOT = rows::wslot(TN);
+  constexpr bool DUAL = true;
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int col = tid & 127, kg = tid >> 7;
+  const int kg_u = __builtin_amdgcn_readfirstlane(kg);
+  const int alds = col * ROWB + kg * 16, blds = (TM + col) * ROWB + kg * 16;
+  const int nb8 = g.blocks >> 3;
+  const int sb = g.blocks % 8 == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long u = rows::wg_start(g, sb);
+  const long long uend = rows::wg_start(g, sb + 1);
+  float* slot = g.partials + (size_t)sb * g.slots * WSLOT;
+  const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (TM + wn * TJ * 32 + r) * ROWB + 16 * h;
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  for (; u < uend; slot += WSLOT) {
+    const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
+    const long long rel = u - P.unit0;
+    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
+    u += c1 - c0;
+    const int bx = lt % P.tk, by = lt / P.tk;
+    const int n0 = by * TM, k0 = bx * TN;
+    const int mbeg = c0 * WCH, mend = min(P.M, c1 * WCH), mlast = mend - 1;
+    const int KT = (mend - mbeg + BKT - 1) / BKT;
+    const bool aok = n0 + col < P.N, bok = k0 + col < P.K;
+    const unsigned acol = (unsigned)min(n0 + col, P.N - 1), bcol = (unsigned)min(k0 + col, P.K - 1);
+    const unsigned lda = P.N, ldb = P.K;
+    const float* const Ab = P.dY;
+    const float* const Bb = P.X;
+    const bool edge = n0 + TM > P.N || k0 + TN > P.K;             // (block-uniform)
+    const bool sums = P.db != nullptr && bx == 0;
+    const int* const grp_a = FORMS ? g.a_groups : nullptr;
+    const int* const grp_b = FORMS ? g.b_groups : nullptr;
+    const bool bnrelu = FORMS && g.scale != nullptr;
+    float bsc = 1.f, bsh = 0.f, asum = 0.f;
+    if (bnrelu && bok) bsc = g.scale[k0 + col], bsh = g.shift[k0 + col];
+
+    float ra[2][8], rb[2][8];
+    u32x4 pka[3], pkb[3];
+    auto gload = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const int mt = mbeg + min(kt, KT - 1) * BKT;
+      int offa = 0, offb = 0;                          // stored row - product row of this tile (listed operands)
+      if (FORMS) {
+        const int gq = mt >> 5;
+        if (grp_a) offa = (grp_a[gq] - gq) * 32;
+        if (grp_b) offb = (grp_b[gq] - gq) * 32;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = min(mt + 8 * kg_u + q, mlast);   // (scalar; rows past the end re-read the last row)
+        ra[set][q] = *(Ab + (size_t)(m + offa) * lda + acol);
+        rb[set][q] = *(Bb + (size_t)(m + offb) * ldb + bcol);
+      }
+    };
+    // what a register set still needs before it is split: producer, zeros past the edges, the column sums
+    auto fixup = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const int mt = mbeg + kt * BKT;
+      const bool live = kt < KT;                       // (tiles past the end are split into the buffer nobody reads)
+      if (bnrelu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rb[set][q] = fmaxf(rb[set][q] * bsc + bsh, 0.f);
+      }
+      if (edge || mt + BKT > mend) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool in = mt + 8 * kg_u + q < mend;
+          ra[set][q] = (in && aok) ? ra[set][q] : 0.f;
+          rb[set][q] = (in && bok) ? rb[set][q] : 0.f;
+        }
+      }
+      if (sums && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += ra[set][q];
+        asum += t;
+      }
+    };
+    auto side_chunk = [&](auto c_c, auto set_c, int buf) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8, set = decltype(set_c)::value;
+      auto run = [&](float (&v)[8], u32x4 (&pk)[3], char* d) __attribute__((always_inline)) {
+        split_chunk<ch>(v, pk);
+        if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[0];
+        if (ch == 7) {
+          *reinterpret_cast<u32x4*>(d + PLANE) = pk[1];
+          *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[2];
+        }
+      };
+      if constexpr (o == 0) run(ra[set], pka, lds3 + buf * BUF + alds);
+      else run(rb[set], pkb, lds3 + buf * BUF + blds);
+    };
+    f32x16 hi[TI][TJ], lo[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+    bf16x8 fa[2][TI][3], fb[2][TJ][3];
+    constexpr int NF = 3 * (TI + TJ);
+    auto frag_one = [&](auto f_c, auto st_c, int buf, int s16) __attribute__((always_inline)) {
+      constexpr int f = decltype(f_c)::value, st = decltype(st_c)::value;
+      constexpr int FPL[6] = {2, 0, 0, 2, 1, 1};
+      constexpr bool isa = f < 6 ? (f % 2 == 0) : (f - 6 < 3 * (TI - 1));
+      constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
+      constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
+      const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
+      if (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+      else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
+    };
+    constexpr int S = 12 * G, NR = (NF + 2) / 3, SB = S - NR, NC = 16, SC = SB - 1;
+    auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
+      constexpr int P2 = decltype(par_c)::value;
+      using SetN = std::integral_constant<int, P2 ^ 1>;
+      fixup(SetN{}, kt + 1);
+      static_for<S>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int step = s / (6 * G), gi = (s % (6 * G)) / 6, q = s % 6;
+        mfma_one<DUAL, q>(fa[step][gi / TJ], fb[step][gi % TJ], hi[gi / TJ][gi % TJ], lo[gi / TJ][gi % TJ]);
+        static_for<NF>([&](auto f_c) {
+          constexpr int f = decltype(f_c)::value;
+          if constexpr (f * (6 * G) / NF == s) frag_one(f_c, C1{}, P2, 1);
+        });
+        static_for<NC>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value;
+          if constexpr (c * SC / NC == s) side_chunk(c_c, SetN{}, P2 ^ 1);
+        });
+        if constexpr (s == (NC - 1) * SC / NC) gload(SetN{}, kt + 3);
+        if constexpr (s == SB - 1) __syncthreads();
+        if constexpr (s >= SB) {
+          static_for<NF>([&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (f / 3 == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    gload(C0{}, 0);
+    gload(C1{}, 1);
+    fixup(C0{}, 0);
+    static_for<NC>([&](auto c_c) { side_chunk(c_c, C0{}, 0); });
+    gload(C0{}, 2);
+    __syncthreads();
+    static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
+    for (int kt = 0; kt < KT; kt += 2) {
+      ktile(C0{}, kt);
+      if (kt + 1 < KT) ktile(C1{}, kt + 1);
+    }
+    // ---- the partial tile (whole TM x TN, edges included: the reduction stores what is inside)
+    __syncthreads();
+    if (sums) {
+      float* red = reinterpret_cast<float*>(lds3);     // [4 m-octets][TM]; the tile buffers are free now
+      red[kg * TM + col] = asum;
+      __syncthreads();
+      if (tid < TM) slot[TM * TN + tid] = (red[tid] + red[TM + tid]) + (red[2 * TM + tid] + red[3 * TM + tid]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          slot[row * TN + (wn * TJ + j) * 32 + r] = hi[i][j][e] + lo[i][j][e];
+        }
+  }
+}
+
+}  // namespace rows3
+}  // namespace pdae

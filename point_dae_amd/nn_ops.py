@@ -420,6 +420,9 @@ def _sink_views(tags, weights):
 
 # lab switch (tools/lab/ab.sh): one grouped launch per block instead of one per stack (measured 0.3 ms slower)
 WGRAD_PER_BLOCK = os.environ.get('PDAE_WGRAD_PER_BLOCK', '0') != '0'
+# blocks per grouped weight-gradient launch (0 = a whole stack): a launch's operands are the activations / gradients of
+# its blocks' backward passes, and a group small enough to still sit in the 256 MB Infinity Cache is read from there
+WGRAD_GROUP = int(os.environ.get('PDAE_WGRAD_GROUP', '0'))
 
 
 def flush_wgrad_queue(owner):
@@ -739,7 +742,7 @@ class _TransformerBlock(torch.autograd.Function):
                                   (da2, h, views[3], None)]
             owner.sink_written.update(sink[1])
             first_of_stack = ctx.pos_grad is None or ctx.pos_grad[1] == 0
-            if first_of_stack or WGRAD_PER_BLOCK:
+            if first_of_stack or WGRAD_PER_BLOCK or (WGRAD_GROUP and len(owner.wgrad_queue) >= 4 * WGRAD_GROUP):
                 flush_wgrad_queue(owner)
             dwqkv = dwproj = dw1 = dw2 = dbf1 = None
         elif tail:                             # two row counts: two groups

@@ -1,0 +1,135 @@
+"""The exact-split bf16 arithmetic of the row-GEMM family (csrc/rows3_kernel.h, include/pdae.h PDAE_GEMM_BF16X3) against
+the fp32-input MFMA kernels it replaces as the default (the reference runs these products through cuBLAS sgemm:
+models/PointCAE_transformer.py:94-158, models/PointCAE_pointnetv2.py:135-173).
+
+Admission gate: on EVERY product of the cfg3, published-variant and cfg2 optimisation steps (tests/golden/
+gemm_shapes.json, recorded at the C boundary by tools/dump_gemm_shapes.py) the error against an fp64 product,
+max |C - C64| / max |C64|, is at or below the fp32-input MFMA kernel's on the same inputs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, 'tests', 'golden', 'gemm_shapes.json')) as _f:
+    _REC = json.load(_f)
+GEMMS = sorted({tuple(s[:4]) for wl in _REC.values() for s in wl['gemm']})          # (M, N, K, w_kn)
+WGRADS = sorted({tuple(s[:3]) for wl in _REC.values() for s in wl['wgrad']})         # (M, N, K)
+F32, BF16X3 = 0, 1
+
+
+def _lib():
+    from point_dae_amd import _lib
+    return _lib
+
+
+@pytest.fixture(autouse=True)
+def _restore_arith():
+    L = _lib()
+    before = L.gemm_arith()
+    yield
+    L.set_gemm_arith(before)
+
+
+def _err(c, ref):
+    return (c.double() - ref).abs().max().item() / ref.abs().max().item()
+
+
+def _gemm(L, arith, x, w, w_kn, cfg=-1):
+    L.set_gemm_arith(arith)
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    y = torch.full((M, N), float('nan'), device='cuda')
+    L.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), int(w_kn), None, 0, None, y.data_ptr(), cfg, 1, 0)
+    return y
+
+
+@pytest.mark.parametrize('M,N,K,w_kn', GEMMS)
+def test_every_step_product_is_at_least_as_accurate_as_the_fp32_mfma_kernel(M, N, K, w_kn):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K + w_kn)
+    rows = min(M, 32768)                     # the error of a row does not depend on the number of rows: bound the fp64 work
+    x = torch.randn(rows, K, device='cuda', generator=g)
+    w = torch.randn((K, N) if w_kn else (N, K), device='cuda', generator=g) / K ** 0.5
+    ref = x.double() @ (w.double() if w_kn else w.double().t())
+    e32 = _err(_gemm(L, F32, x, w, w_kn), ref)
+    cfg, _, _ = L.rows_gemm_plan(rows, N, K, bool(w_kn), False)
+    e3 = _err(_gemm(L, BF16X3, x, w, w_kn), ref)
+    if K % 32 != 0:                          # (the exact-split kernels take whole 32-deep tiles: same kernel either way)
+        assert e3 == e32
+    else:
+        assert L.rows_gemm_plan(rows, N, K, bool(w_kn), False)[0] >= 16, 'the default plan is an exact-split tile shape'
+        assert e3 <= e32, (e3, e32)
+    assert e3 <= 2e-6
+
+
+@pytest.mark.parametrize('M,N,K', WGRADS)
+def test_every_step_weight_gradient_is_at_least_as_accurate(M, N, K):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(M + N * 5 + K * 11)
+    dy = torch.randn(M, N, device='cuda', generator=g)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    ref = dy.double().t() @ x.double()
+    refb = dy.double().sum(0)
+    errs = {}
+    for arith in (F32, BF16X3):
+        L.set_gemm_arith(arith)
+        dw = torch.full((N, K), float('nan'), device='cuda')
+        db = torch.full((N,), float('nan'), device='cuda')
+        L.rows_wgrad_multi([(dy, x, dw, db)])
+        errs[arith] = _err(dw, ref)
+        assert _err(db, refb) <= 2e-6
+    assert errs[BF16X3] <= errs[F32], errs
+
+
+@pytest.mark.parametrize('cfg', [16, 17, 18, 19])
+@pytest.mark.parametrize('M,N,K,w_kn', [(3584, 1152, 384, 0), (300, 100, 64, 0), (2944, 384, 1536, 1), (129, 388, 96, 1)])
+def test_every_tile_shape_against_fp64(cfg, M, N, K, w_kn):
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(cfg + M)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn((K, N) if w_kn else (N, K), device='cuda', generator=g) / K ** 0.5
+    ref = x.double() @ (w.double() if w_kn else w.double().t())
+    assert _err(_gemm(L, BF16X3, x, w, w_kn, cfg), ref) <= 1e-6
+
+
+def test_identity_weight_returns_the_operand_bit_for_bit():
+    """x = h + m + l exactly and 1.0 = (1, 0, 0): the products hh + (mh + lh) reassemble every element of A -- over the
+    whole exponent range, signs, and values with long runs of zero or one bits in the mantissa."""
+    L = _lib()
+    K = 256
+    g = torch.Generator(device='cuda').manual_seed(3)
+    bits = torch.randint(0, 2 ** 31 - 1, (1024, K), device='cuda', generator=g, dtype=torch.int64)
+    expo = torch.randint(20, 235, (1024, K), device='cuda', generator=g, dtype=torch.int64)      # finite, normal
+    mant = bits & 0x7fffff
+    mant[::3] &= 0x7f00ff                    # sparse mantissas: residuals with leading zeros
+    mant[1::3] |= 0x00ffff
+    word = ((bits >> 23) & 1) << 31 | expo << 23 | mant
+    x = word.to(torch.int32).view(torch.float32).contiguous()
+    eye = torch.eye(K, device='cuda')
+    for w_kn in (0, 1):
+        y = _gemm(L, BF16X3, x, eye, w_kn)
+        assert torch.equal(y.view(torch.int32), x.view(torch.int32))
+
+
+def test_fp32_mfma_kernels_stay_selectable():
+    """pdae_set_gemm_arith / PDAE_GEMM=f32mfma: plans answer with the fp32-input tile shapes (cfg < 16), the weight
+    gradients with their 128 x 384 tiles, and a block's products agree with the default arithmetic to rounding."""
+    L = _lib()
+    L.set_gemm_arith(F32)
+    assert L.gemm_arith() == F32 and L.rows_gemm_plan(3584, 1152, 384, False, False)[0] < 16
+    x = torch.randn(3584, 384, device='cuda')
+    w = torch.randn(1152, 384, device='cuda') / 384 ** 0.5
+    a = _gemm(L, F32, x, w, 0)
+    b = _gemm(L, BF16X3, x, w, 0)
+    assert L.rows_gemm_plan(3584, 1152, 384, False, False)[0] >= 16
+    assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+    code = ('import sys; sys.path.insert(0, %r); from point_dae_amd import _lib; '
+            'print(_lib.gemm_arith(), _lib.rows_gemm_plan(3584, 1152, 384, False, False)[0])' % ROOT)
+    env = dict(os.environ, PDAE_GEMM='f32mfma')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == '0' and int(out[1]) < 16

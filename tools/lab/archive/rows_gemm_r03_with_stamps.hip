@@ -28,15 +28,25 @@
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 
-#include "rows_common.h"
+#include "common.h"
 
 namespace pdae {
 namespace rows {
 
 
+#ifdef PDAE_ROWS_STAMPS
+#define PDAE_STAMP(i)                                                                                   \
+  if (p.stamps && threadIdx.x == 0) {                                                                   \
+    p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();  \
+  }
+#else
+#define PDAE_STAMP(i)
+#endif
 
+#ifdef PDAE_LAB_CLOCK
+__device__ long long g_rg_clk[2];       // diagnostic build: shader-clock cycles / 100 MHz ticks block 0 of the last launch lived
+#endif
 
 // Block tile (32 TI WM) x (32 TJ WN), WM x WN waves, every wave TI x TJ MFMA tiles of 32x32.
 // k permutation inside an 8-deep slab as in gemm.hip: lane (r = l & 31, h = l >> 5) supplies
@@ -51,6 +61,9 @@ namespace rows {
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)))
 void rows_gemm_kernel(const Args p) {
+#ifdef PDAE_LAB_CLOCK
+  const long long lab_c0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN, NT = 64 * WM * WN;
   constexpr int LA = (BM * 8) / NT, LB = (BN * 8) / NT;   // float4 per thread and k-tile
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "every thread stages LA + LB float4 per k-tile");
@@ -86,6 +99,18 @@ void rows_gemm_kernel(const Args p) {
     const int slot = blockIdx.x >> 3;
     if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
   }
+#ifdef PDAE_ROWS_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    long long* st = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    st[4] = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    st[5] = ((long long)xcc << 32) | hwid;
+  }
+#endif
+  PDAE_STAMP(0)
   for (;;) {
   int tile, kbeg, kend, piece = 0;
   bool tile_ends = false;
@@ -244,7 +269,9 @@ void rows_gemm_kernel(const Args p) {
           else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
         }
         if (PF == 2 && last && t == 0) {
+#ifndef PDAE_LAB_NOBARRIER
           __syncthreads();
+#endif
 #pragma unroll
           for (int q = 0; q < NF; ++q) frag(An, Bn, nxt, 0, q);
         }
@@ -253,6 +280,7 @@ void rows_gemm_kernel(const Args p) {
           for (int q = 0; q < NF; ++q)
             if ((q * 4) / NF == t) frag(As, Bs, nxt, s + 1, q);
         }
+#ifndef PDAE_LAB_NOGLOAD
         if (!GUARD && s == 0) {
 #pragma unroll
           for (int l = 0; l < NL; ++l)
@@ -261,6 +289,8 @@ void rows_gemm_kernel(const Args p) {
               else ldb_[l - LA] = *reinterpret_cast<const float4*>(Bk + boff[l - LA]);
             }
         }
+#endif
+#ifndef PDAE_LAB_NOLSTORE
         if (s == SST) {
 #pragma unroll
           for (int l = 0; l < NL; ++l)
@@ -270,11 +300,14 @@ void rows_gemm_kernel(const Args p) {
               else *reinterpret_cast<float4*>(Bd + ((tid + (l - LA) * NT) >> 3) * LD + scol) = stb_[l - LA];
             }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (PF == 1) {
+#ifndef PDAE_LAB_NOBARRIER
       __syncthreads();
+#endif
     }
     buf ^= 1;
   };
@@ -291,6 +324,7 @@ void rows_gemm_kernel(const Args p) {
 #pragma unroll
       for (int q = 0; q < NF; ++q) frag(As, Bs, 0, 0, q);
     }
+    PDAE_STAMP(1)
     if (PF == 1) {
       for (int kt = 0; kt < KT; ++kt) ktile(r0a, r0b, r0a, r0b, kt, guard_c);
     } else {
@@ -309,6 +343,7 @@ void rows_gemm_kernel(const Args p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
+  PDAE_STAMP(2)
   // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31,
   // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 16 rows of ONE column.
   float* Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)piece * p.slab;
@@ -372,6 +407,18 @@ void rows_gemm_kernel(const Args p) {
   if (u >= uend) break;
   __syncthreads();      // every wave is done with the LDS buffers before the next segment stages into them
   }   // segments
+#ifdef PDAE_LAB_CLOCK
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    g_rg_clk[0] = __builtin_amdgcn_s_memtime() - lab_c0;
+    g_rg_clk[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+  }
+#endif
+#ifdef PDAE_ROWS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PDAE_STAMP(3)
+  if (p.stamps && threadIdx.x == 0)
+    p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -386,9 +433,15 @@ void rows_gemm_kernel(const Args p) {
 // uniform-split version ran 2 or 4 blocks on a CU: 117 us where the MFMAs need 66).  A block writes
 // the partial tile of every output tile its range touches into its own slots; wgrad_reduce adds a
 // tile's partials in block order: no atomics, bit-identical run to run.
+#ifdef PDAE_ROWS_STAMPS
+__device__ long long g_wg_clk[2];       // diagnostic build: shader-clock cycles / 100 MHz ticks block 0 of the last launch lived
+#endif
 
 template <int TN, int NT>
 __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
+#ifdef PDAE_ROWS_STAMPS
+  const long long lab_c0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int TM = WTM;
   constexpr int WNV = NT / 128;                       // waves along k (two along n)
   constexpr int WK = TN / WNV;                        // columns of a wave: 64 (TN 128) or 96 (TN 384)
@@ -591,6 +644,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
           slot[row * TN + wn * WK + j * 32 + r] = acc[i][j][e];
         }
   }
+#ifdef PDAE_ROWS_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_wg_clk[0] = __builtin_amdgcn_s_memtime() - lab_c0;
+    g_wg_clk[1] = __builtin_amdgcn_s_memrealtime() - lab_r0;
+  }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -655,6 +714,12 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
   static const int order[] = {3, 1, 2, 6, 4, 0, 5, 7};           // ties go to the smaller tile
   double best = 1e300;
   *cfg = 3, *splits = 1, *stream_blocks = 0;
+#ifdef PDAE_LAB_PLAN
+  // lab: PDAE_ROWS_FORCE="cfg,splits,stream" (-1 = planned) overrides the plan of every call
+  static const char* force = getenv("PDAE_ROWS_FORCE");
+  int fc = -1, fs = -1, fb = -1;
+  if (force) sscanf(force, "%d,%d,%d", &fc, &fs, &fb);
+#endif
   for (int c : order)
     for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
       if (s > 1 && K / s < 128) continue;
@@ -668,8 +733,14 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
     // the first grid whose tiles are cut into at most THREE pieces: a slab is a 5.5 MB write for the producer and a
     // 5.5 MB read for the LayerNorm that adds it (tools/lab/stream_sweep.sh: 4 slabs 12.71, 3 slabs 12.68, 2 slabs
     // 12.71 ms/step; 768 / 512 blocks at most 12.71-12.73)
+#ifdef PDAE_LAB_PLAN
+    static const int lab_pmax = getenv("PDAE_STREAM_PMAX") ? atoi(getenv("PDAE_STREAM_PMAX")) : 1024;   // largest grid tried
+    static const int lab_smax = getenv("PDAE_STREAM_SMAX") ? atoi(getenv("PDAE_STREAM_SMAX")) : 3;      // most slabs accepted
+    static const bool lab_768 = getenv("PDAE_STREAM_PMAX") != nullptr;
+#else
     constexpr int lab_pmax = 1024, lab_smax = 3;
     constexpr bool lab_768 = false;
+#endif
     for (int P : {1024, 768, 512, 256}) {
       if (P > lab_pmax || (P == 768 && !lab_768)) continue;
       const long long units = tiles * kt;
@@ -682,6 +753,10 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
       break;
     }
   }
+#ifdef PDAE_LAB_PLAN
+  if (fc >= 0) *cfg = fc, *splits = 1, *stream_blocks = 0;
+  if (fs == 0) *splits = 1, *stream_blocks = 0;      // "x,0,x": no split / stream-K anywhere
+#endif
 }
 
 template <int TI, int TJ, int WM, int WN, bool BKN, int EPI>
@@ -724,65 +799,36 @@ static void launch_rows(Args& a, int cfg, int splits, int sb, hipStream_t s) {
 using namespace pdae;
 using namespace pdae::rows;
 
-
-// ---- GEMM arithmetic of the row-GEMM family: exact-split bf16 (rows3_gemm.hip) unless PDAE_GEMM=f32mfma or
-// pdae_set_gemm_arith(PDAE_GEMM_F32MFMA) asks for the fp32-input MFMA kernels above
-static int g_arith = -1;
-static int gemm_arith() {
-  if (g_arith < 0) {
-    const char* e = getenv("PDAE_GEMM");
-    g_arith = (e && (!strcmp(e, "f32mfma") || !strcmp(e, "f32") || !strcmp(e, "fp32"))) ? PDAE_GEMM_F32MFMA : PDAE_GEMM_BF16X3;
-  }
-  return g_arith;
+#if defined(PDAE_ROWS_STAMPS) || defined(PDAE_LAB_OCC)
+// diagnostic builds: the runtime's occupancy answer for the 64 x 64 row GEMM at a dynamic LDS size, and the device's LDS
+// (-DPDAE_LAB_OCC alone leaves the kernels exactly as shipped)
+extern "C" int pdae_lab_occupancy(int lds_bytes, int* blocks_per_cu, int* lds_per_cu, int* lds_per_block_max) {
+  hipDeviceProp_t prop;
+  (void)hipGetDeviceProperties(&prop, 0);
+  *lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor, *lds_per_block_max = (int)prop.sharedMemPerBlock;
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+      blocks_per_cu, reinterpret_cast<const void*>(rows_gemm_kernel<1, 1, 2, 2, false, EPI_STORE>), 256, (size_t)lds_bytes);
 }
-extern "C" int pdae_set_gemm_arith(int arith) {
-  if (arith != PDAE_GEMM_F32MFMA && arith != PDAE_GEMM_BF16X3) return bad_arg("set_gemm_arith: PDAE_GEMM_F32MFMA or PDAE_GEMM_BF16X3");
-  g_arith = arith;
-  return PDAE_OK;
+#endif
+#ifdef PDAE_LAB_CLOCK
+extern "C" int pdae_lab_rows_clock(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdae::rows::g_rg_clk), 16);
 }
-extern "C" int pdae_gemm_arith(void) { return gemm_arith(); }
-
-// shapes the exact-split kernels take: the reduction in whole 32-deep tiles (every layer of the models but the K = 3
-// / K = 4 ones), 32-bit byte offsets as the fp32 kernels
-static bool gemm3_takes(int N, int K, bool bkn) { return K % 32 == 0 && K >= 32 && (!bkn || N % 4 == 0); }
-
-// Plan of the exact-split family (cfg = CFG3_BASE + tile shape).  Cost in microseconds, calibrated on tools/lab/
-// rows3_lab.py sweeps (M = 1664 .. 65536, the Transformer blocks' N, K): one block per CU at a time, so a launch is
-// ceil(blocks / 256) ROUNDS of [k-tiles x time per 32-deep k-tile + the block's exposed first loads and epilogue],
-// + ~4 us of launch ramp and drain, + a little consumer time per extra slab.
-static double plan3_cost(int M, int N, int K, int c3, int splits) {
-  static const double t_ktile[rows3::NCFG3] = {1.0, 0.66, 1.5, 0.75}, t_fixed[rows3::NCFG3] = {6.0, 4.0, 7.5, 1.5};
-  const rows3::Cfg3& c = rows3::kCfg3[c3];
-  const int bm = 32 * c.ti * c.wm, bn = 32 * c.tj * c.wn;
-  const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splits;
-  const int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
-  const long long rounds = (blocks + 255) / 256;
-  double cost = 4.0 + rounds * (kc / 32 * t_ktile[c3] + t_fixed[c3]);
-  if (splits > 1) cost += 0.7 * (splits - 1);
-  return cost;
+#endif
+#ifdef PDAE_ROWS_STAMPS
+extern "C" int pdae_lab_wgrad_clock(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdae::rows::g_wg_clk), 16);
 }
-static void plan_rows3(int M, int N, int K, bool may_split, int* cfg, int* splits, int* stream_blocks) {
-  double best = 1e300;
-  *cfg = rows3::CFG3_BASE, *splits = 1, *stream_blocks = 0;
-  static const char* force = getenv("PDAE_ROWS3_FORCE");       // lab: "cfg,splits" overrides every plan
-  int fc = -1, fs = -1;
-  if (force) sscanf(force, "%d,%d", &fc, &fs);
-  for (int c = 0; c < rows3::NCFG3; ++c)
-    for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
-      if (s > 1 && K / s < 128) continue;
-      const double t = plan3_cost(M, N, K, c, s);
-      if (t < best * 0.995) best = t, *cfg = rows3::CFG3_BASE + c, *splits = s;
-    }
-  if (fc >= 0) *cfg = rows3::CFG3_BASE + fc;
-  if (fs >= 1 && may_split) *splits = fs;
-}
+#endif
+#ifdef PDAE_ROWS_STAMPS
+static long long* g_stamps = nullptr;
+extern "C" void pdae_lab_set_stamps(long long* p) { g_stamps = p; }
+#endif
 
 extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits,
                                    int* stream_blocks) {
   if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits || !stream_blocks) return bad_arg("rows_gemm_plan: bad argument");
-  if (gemm_arith() == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0))
-    plan_rows3(M > 0 ? M : 1, N, K, may_split != 0, cfg, splits, stream_blocks);
-  else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits, stream_blocks);
+  plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits, stream_blocks);
   return PDAE_OK;
 }
 
@@ -794,22 +840,18 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   if (epi < 0 || epi > 4) return bad_arg("rows_gemm: epi must be 0..4");
   if ((long long)M * (K > N ? K : N) >= (1LL << 30) || (long long)N * K >= (1LL << 30))
     return unsupported("rows_gemm: operands of 4 GB or more (32-bit byte offsets)");
-  const bool fam3 = cfg >= rows3::CFG3_BASE;
-  if ((fam3 ? cfg - rows3::CFG3_BASE >= rows3::NCFG3 : cfg >= NCFG) || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
-  if (fam3 && !gemm3_takes(N, K, w_kn != 0)) return unsupported("rows_gemm: the exact-split bf16 tile shapes need K % 32 == 0");
+  if (cfg >= NCFG || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
   if (cfg < 0 || splits < 0) {
     int c, s, b;
-    if (gemm_arith() == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, false, &c, &s, &b);
-    else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s, &b);
+    plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s, &b);
     if (cfg < 0) cfg = c;
     if (splits < 0) splits = 1, stream_blocks = 0;
   }
   if (stream_blocks < 0 || stream_blocks % 8 != 0) return bad_arg("rows_gemm: stream_blocks must be a multiple of 8");
   if (stream_blocks) {
-    const bool f3 = cfg >= rows3::CFG3_BASE;
-    const int bm = f3 ? 32 * rows3::kCfg3[cfg - rows3::CFG3_BASE].ti * rows3::kCfg3[cfg - rows3::CFG3_BASE].wm : 32 * kCfg[cfg].ti * kCfg[cfg].wm;
-    const int bn = f3 ? 32 * rows3::kCfg3[cfg - rows3::CFG3_BASE].tj * rows3::kCfg3[cfg - rows3::CFG3_BASE].wn : 32 * kCfg[cfg].tj * kCfg[cfg].wn;
-    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const Cfg& c = kCfg[cfg];
+    const long long tiles = (long long)((M + 32 * c.ti * c.wm - 1) / (32 * c.ti * c.wm)) *
+                            ((N + 32 * c.tj * c.wn - 1) / (32 * c.tj * c.wn));
     if (M > 0 && (tiles * ((K + BK - 1) / BK) < stream_blocks ||
                   stream_slabs(tiles, (K + BK - 1) / BK, stream_blocks) > splits))
       return bad_arg("rows_gemm: too few slabs (or units) for this stream-K grid");
@@ -826,11 +868,10 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   Args a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = w_kn ? N : K, a.C = Y, a.ldc = N;
   a.Z = Z, a.bias = bias, a.slab = (long long)M * N;
+#ifdef PDAE_ROWS_STAMPS
+  a.stamps = g_stamps;
+#endif
   hipStream_t s = as_stream(stream);
-  if (cfg >= rows3::CFG3_BASE) {
-    rows3::launch_gemm3(a, cfg - rows3::CFG3_BASE, w_kn != 0, epi, splits, stream_blocks, s);
-    return check_launch("rows_gemm");
-  }
   if (!w_kn) {
     if (epi == EPI_STORE) launch_rows<false, EPI_STORE>(a, cfg, splits, stream_blocks, s);
     else if (epi == EPI_BIAS_RELU) launch_rows<false, EPI_BIAS_RELU>(a, cfg, splits, 0, s);
@@ -847,7 +888,6 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
 // the widest tile every layer's K is a multiple of: 384 (the Transformer blocks: 384, 1536), 256 (FoldingNet, the
 // PointNet++ levels: 256, 512, 1024), else 128
 static int wgrad_tile_width(int nprob, const int* Ks) {
-  if (gemm_arith() == PDAE_GEMM_BF16X3) return 128;         // exact-split kernel: 128 x 128 tiles (two accumulator sets)
   static const char* force = getenv("PDAE_WGRAD_TN");       // A/B switch (tools/lab/ab.sh): caps the tile width
   const int cap = force ? atoi(force) : 384;
   bool w384 = cap >= 384, w256 = cap >= 256;
@@ -877,10 +917,12 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
   }
   g->nprob = nprob, g->tiles = tiles, g->units = units;
   // one residency of the chip: 256 CUs x 2 blocks of 4 waves (128-wide tiles), x 1 block of 8 waves (384-wide)
-  int wg_blocks = (WTN >= 256 || gemm_arith() == PDAE_GEMM_BF16X3) ? 256 : 512;   // (the exact-split kernel: 8 waves, 122 KB of LDS)
-  // (lab) PDAE_WGRAD_BPT=k: k blocks per output tile instead of one residency of the chip
-  static const int bpt = getenv("PDAE_WGRAD_BPT") ? atoi(getenv("PDAE_WGRAD_BPT")) : 0;
-  if (bpt > 0) wg_blocks = (bpt * tiles + 7) / 8 * 8;
+#ifdef PDAE_LAB_PLAN
+  static const int wg_force = getenv("PDAE_WGRAD_BLOCKS") ? atoi(getenv("PDAE_WGRAD_BLOCKS")) : 0;
+  const int wg_blocks = wg_force ? wg_force : (WTN >= 256 ? 256 : 512);
+#else
+  const int wg_blocks = WTN >= 256 ? 256 : 512;
+#endif
   g->blocks = (int)(units < wg_blocks ? units : wg_blocks);
   // slots per block: the most tiles one block's unit range touches (ranges are [b units / B, (b + 1) units / B))
   auto tile_of = [&](long long u) {
@@ -955,8 +997,7 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   for (int q = 1; q < nprob; ++q) max_chunks = g.p[q].chunks > max_chunks ? g.p[q].chunks : max_chunks;
   const long long most = (max_chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
-  if (gemm_arith() == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
-  else if (tn == 384) wgrad_launch<384>(g, pl, s);
+  if (tn == 384) wgrad_launch<384>(g, pl, s);
   else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);
   return check_launch("rows_wgrad_multi");
@@ -981,8 +1022,7 @@ extern "C" int pdae_rows_wgrad_listed(int M, int N, int K, const float* dY, cons
   const long long most = (g.p[0].chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
   hipStream_t s = as_stream(stream);
-  if (gemm_arith() == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
-  else if (tn == 384) wgrad_launch<384>(g, pl, s);
+  if (tn == 384) wgrad_launch<384>(g, pl, s);
   else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);
   return check_launch("rows_wgrad_listed");
