@@ -42,10 +42,14 @@ import torch.distributed as dist  # noqa: E402
 CFG3 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'
 CFG2 = 'cfgs/pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (AMD's 5 PF headline includes 2:1 sparsity)
+# the row-GEMM family's default arithmetic: fp32 operands split exactly into three bf16 terms, SIX bf16 products per
+# fp32 product (include/pdae.h PDAE_GEMM_BF16X3) => its matrix-pipe ceiling in fp32-equivalent FLOP/s
+BF16X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
                                   # kernels are sub / mul / add / min chains
-ROUND = 3                         # profiles/*_rNN.json this bench refers to
+ROUND = 4                         # profiles/*_rNN.json this bench refers to
 
 
 def parse():
@@ -195,39 +199,54 @@ def ddp_model(table, G, ms_per_step, ranks=(2, 4, 8), allreduce_mb=116.0):
     return out
 
 
-def dominant_roofline(probe, steps):
-    """`roofline_dominant`: the row GEMM family (rows_gemm_kernel: every Linear / 1x1 conv forward and data gradient)
-    and the grouped weight gradients (wgrad_kernel + its reductions) -- the kernels that own ~60 % of the step --
-    as ONE time-weighted figure: all their algorithmic FLOPs over all their launch time, HIP events around every
-    launch of the eager probe steps."""
-    fam = probe.family_summary()
+def dominant_roofline(probe, steps, bf16x3):
+    """The bench line's `roofline`: the row GEMM family (every Linear / 1x1 conv forward and data gradient) and the
+    grouped weight gradients (+ their reductions) -- the kernels that own ~60 % of the step -- as ONE time-weighted
+    figure: all their algorithmic fp32 FLOPs over all their time.  Time = one step's launches of the two families
+    captured into a hipGraph per family and replayed back to back (`timing`), next to HIP events around every eager
+    launch of the probe steps.  Peak: the arithmetic these kernels run -- exact-split bf16 (six bf16 MFMA products per
+    fp32 product: bf16 dense / 6) by default, the fp32-input MFMA peak under PDAE_GEMM=f32mfma; the fraction of the
+    fp32-input MFMA peak is reported alongside either way."""
+    fam = {k: v for k, v in probe.family_summary().items() if k in ('rows_gemm', 'rows_wgrad')}
     if not fam:
         return None
+    peak = BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
     rows = {}
     tot_f = tot_ms = 0.0
     for name, r in fam.items():
         tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        rows[name] = {'launches_per_step': r['launches'] / max(steps, 1), 'ms_per_step': r['ms'] / max(steps, 1),
-                      'gflop_per_step': r['flops'] / max(steps, 1) / 1e9, 'achieved': tf, 'frac': tf / MFMA_F32_PEAK_TFLOPS}
+        rows[name] = {'launches_per_step': r['launches'] / max(steps, 1), 'eager_ms_per_step': r['ms'] / max(steps, 1),
+                      'gflop_per_step': r['flops'] / max(steps, 1) / 1e9, 'eager_achieved': tf}
         tot_f += r['flops']
         tot_ms += r['ms']
-    ach = tot_f / (tot_ms * 1e-3) / 1e12
-    out = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': ach / MFMA_F32_PEAK_TFLOPS, 'ms_per_step': tot_ms / max(steps, 1),
-           'gflop_per_step': tot_f / max(steps, 1) / 1e9, 'families': rows,
-           'timing': 'HIP events around every launch of the two families over %d eager probe steps '
-                     '(launch-to-launch from Python, so each figure carries host launch gaps a hipGraph replay does '
-                     'not pay; `replayed` = the same launches of ONE step captured into a hipGraph per family and '
-                     'replayed back to back; profiles/kernel_summary_r%02d.txt has the in-step durations)' % (steps, ROUND)}
+    gflop = tot_f / max(steps, 1) / 1e9
+    eager_ms = tot_ms / max(steps, 1)
+    ms, timing = eager_ms, 'HIP events around every eager launch of the two families over %d probe steps (host launch gaps included)' % steps
     rep = getattr(probe, 'replay_ms', None)
-    if rep and 'error' not in rep:
-        f1 = sum(r['flops'] for r in fam.values()) / max(steps, 1)
-        ms = sum(rep.get(k, 0.0) for k in fam)
-        out['replayed'] = {'ms_per_step': ms, 'achieved': f1 / (ms * 1e-3) / 1e12, 'frac': f1 / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                           'families_ms': {k: rep.get(k) for k in fam}}
-    elif rep:
-        out['replayed'] = rep
-    return out
+    if rep and 'error' not in rep and all(k in rep for k in fam):
+        ms = sum(rep[k] for k in fam)
+        timing = ('one step\'s launches of the two families (the graphed step\'s own body, run right after the timed region) '
+                  'captured into one hipGraph per family and replayed back to back, HIP events around 10 replays; '
+                  'profiles/kernel_summary_r%02d.txt has the same kernels\' durations inside the step\'s replays' % ROUND)
+        for k in fam:
+            rows[k]['ms_per_step'] = rep[k]
+            rows[k]['achieved'] = rows[k]['gflop_per_step'] / rep[k] / 1e3 if rep[k] > 0 else 0.0
+    ach = gflop / ms / 1e3
+    traffic = traffic_src = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % ROUND)
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get('rows_families_hbm_bytes_per_step')
+        if rec:
+            traffic, traffic_src = rec, 'profiles/pmc_r%02d.json (rocprofv3 --pmc passes of this command, bytes of the two families per STEP)' % ROUND
+    return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+            'traffic': traffic, 'traffic_source': traffic_src,
+            'kernel': 'pdae::rows3::gemm3_kernel + pdae::rows3::wgrad3b_kernel (+ wgrad_reduce_kernel): the row-GEMM family' if bf16x3
+                      else 'pdae::rows::rows_gemm_kernel + pdae::rows::wgrad_kernel (+ wgrad_reduce_kernel): the row-GEMM family',
+            'ms_per_step': ms, 'gflop_per_step': gflop, 'eager_ms_per_step': eager_ms,
+            'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS, 'families': rows, 'timing': timing,
+            'peak_note': ('fp32-equivalent ceiling of the exact-split arithmetic: bf16 MFMA dense peak %.0f TFLOP/s / 6 products '
+                          '(MI355X_MICROARCH.md); the fp32-input MFMA peak is %.1f' % (MFMA_BF16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+                         if bf16x3 else 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
 
 
 def cfg2_leg(args, device, rank):
@@ -355,7 +374,17 @@ def cpu_baseline(config, args):
         done += 1
     dt = time.time() - t0
     args.cpu_steps = done
+    cpu_model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    cpu_model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {'value': args.cpu_batch * args.cpu_steps / dt, 'unit': 'clouds/s', 'cores': cores,
+            'cpu_model': cpu_model, 'threads': cores, 'host_logical_cpus': os.cpu_count(),
             'kind': 'port',
             'sample': '%d steps of B=%d (N=%d, G=%d, k=32) full train step on the CPU oracle '
                       '(oracle/model.py + oracle/pdae_oracle.c), %.1f s' % (
@@ -564,12 +593,17 @@ def main():
                     'avg_us': kern['avg_ms'] * 1e3, 'launches': kern['launches'],
                     'flops_per_launch': kern['flops'], 'timing': probe_mode,
                     'peak_note': 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
+        from point_dae_amd import _lib as _L
+        bf16x3 = _L.gemm_arith() == _L.GEMM_BF16X3
+        best = roof                                   # the single largest hand-written kernel (the embedder's conv3)
+        dom = dominant_roofline(probe, args.probe_steps if not args.eager else args.steps, bf16x3)
         line = {
             'metric': 'pretrain point-clouds/sec (N=%d,G=%d)' % (args.npoints, args.num_group), 'value': clouds_per_s, 'unit': 'clouds/s',
             'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if world > 1 and backend == 'nccl' else (1 if world == 1 else 0)),
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32 (3xbf16 exact-split operands, fp32 accumulate)' if bf16x3 else 'f32', 'data': 'synthetic',
             'config': {'workload': (('model ' + args.model_name + ' on ' if args.model_name else '') +
                                     'cfg3/cfg4: pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml '
                                     if args.workload == 'cfg3' else
@@ -580,14 +614,27 @@ def main():
                        'grad_allreduce': ('none (1 rank)' if world == 1 else
                                           'Transformer slice under the embedder backward (two graphs)' if getattr(step, 'split', False)
                                           else 'one flat all-reduce after the replay'),
-                       'dense_layers': 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
-            'roofline': roof,
+                       'dense_layers': ('hand-written MFMA kernels, no BLAS library in the step: Linear layers and weight gradients on '
+                                        'exact-split bf16 (csrc/rows3_kernel.h: fp32 = three bf16 terms, six products, fp32 accumulate; '
+                                        'PDAE_GEMM=f32mfma selects the fp32-input kernels), the patch embedder on fp32-input MFMA (csrc/gemm.hip)')
+                                       if bf16x3 else 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
+            'roofline': dom if dom else best,
+            'roofline_best': best if dom else None,
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
-        dom = dominant_roofline(probe, args.probe_steps if not args.eager else args.steps)
-        if dom:
-            line['roofline_dominant'] = dom
+        fams = probe.family_summary()
+        if fams and args.probe_steps and not args.eager:
+            gf = sum(r['flops'] for r in fams.values()) / args.probe_steps / 1e9
+            tf = gf / (elapsed / args.steps * 1e3) / 1e3
+            line['whole_step'] = {'gflop_executed': gf, 'achieved': tf, 'unit': 'TFLOP/s',
+                                  'frac_of_f32_mfma_peak': tf / MFMA_F32_PEAK_TFLOPS,
+                                  'frac_of_bf16x3_peak': tf / BF16X3_PEAK_TFLOPS,
+                                  'gflop_by_family': {k: r['flops'] / args.probe_steps / 1e9 for k, r in fams.items()},
+                                  'note': 'fp32 FLOPs of every dense product the step executes (row GEMMs, weight gradients, the '
+                                          "embedder's fused convolutions: counted at the launch sites over the probe steps, which draw "
+                                          'their own mask ratios) over the timed ms/step; the embedder runs on the fp32-input pipe, the rest '
+                                          'on exact-split bf16 unless PDAE_GEMM=f32mfma'}
         if table:
             line['tvis_table'] = {'unit': 'ms per replay (forward + loss + backward graph(s), no AdamW)',
                                   'ms': {str(t): round(v, 4) for t, v in table.items()}}

@@ -305,7 +305,7 @@ def rows_wgrad_workspace(M, Ns, Ks):
     return hit
 
 
-def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace, may_defer=False):
+def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace):
     """pdae_rows_wgrad over lists of tensors (dbs entries may be None)."""
     n = len(dYs)
     parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n

@@ -754,9 +754,12 @@ static double plan3_cost(int M, int N, int K, int c3, int splits) {
   static const double t_ktile[rows3::NCFG3] = {1.0, 0.66, 1.5, 0.75}, t_fixed[rows3::NCFG3] = {6.0, 4.0, 7.5, 1.5};
   const rows3::Cfg3& c = rows3::kCfg3[c3];
   const int bm = 32 * c.ti * c.wm, bn = 32 * c.tj * c.wn;
-  const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splits;
+  // the grid is 8 ceil(tiles / 8) x splits blocks (whole XCD chunks); a grid within a few blocks of 256 does not land
+  // one block per CU (measured: 264 launched / 252 working blocks ran as two rounds), so a round is 248 blocks
+  const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  const long long blocks = (tiles + 7) / 8 * 8 * splits;
   const int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
-  const long long rounds = (blocks + 255) / 256;
+  const long long rounds = (blocks + 247) / 248;
   double cost = 4.0 + rounds * (kc / 32 * t_ktile[c3] + t_fixed[c3]);
   if (splits > 1) cost += 0.7 * (splits - 1);
   return cost;

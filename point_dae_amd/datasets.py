@@ -292,6 +292,7 @@ class ShapeNet:
         # batches per epoch: given, else the reference's len(DataLoader) = ceil(len(set) / (bs * world)) once a listed
         # set is loaded (DistributedSampler shards it, builder.py:19), else 50 synthetic batches
         self.steps = config.get('steps_per_epoch', None)
+        self.shared_seed = config.get('shared_seed', None)
         self.rank, self.world = int(config.get('rank', 0)), max(int(config.get('world', 1)), 1)
         self.seed = config.get('seed', 0)
         self.device = config.get('device', 'cuda')
@@ -328,7 +329,12 @@ class ShapeNet:
         self.gen.manual_seed(self.seed)
         self.listed = bool(listed)
         if self.steps is None:
-            self.steps = -(-clouds.shape[0] // (self.bs * self.world)) if listed else 50
+            if listed:
+                per_rank = -(-clouds.shape[0] // self.world)        # DistributedSampler pads to ceil(N / world)
+                # tools/builder.py:21,28: drop_last = (subset == 'train') => floor for the training loader, ceil otherwise
+                self.steps = max(per_rank // self.bs, 1) if self.subset == 'train' else -(-per_rank // self.bs)
+            else:
+                self.steps = 50
 
     def __len__(self):
         if self.steps is None:
@@ -341,22 +347,27 @@ class ShapeNet:
         x = self._clouds.index_select(0, index)
         B, P, _ = x.shape
         dev, rng = x.device, self.rng
-        # ---- augment_data (:1155-1175), in the configured order: 'norm' and the affine augmentations.  'norm' is
-        # folded into the kernel when it comes first (the shipped configurations); otherwise it is its own pass
+        # ---- augment_data (:1155-1175), strictly in the configured order.  The kernel normalises FIRST and applies its
+        # (<= 3) maps second, so a 'norm' is folded into the launch of the maps that FOLLOW it; maps drawn before a
+        # 'norm' are flushed (normalise off, three per pass) before that 'norm' gets its own launch.
         aug = [a for a in self.aug_type if a != 'clean']
-        norm_first = bool(aug) and aug[0] == 'norm'
         maps = [[] for _ in range(B)]
-        for item in aug[1:] if norm_first else aug:
+        norm_pending = False
+
+        def flush(x, norm_pending, maps):
+            """apply [norm?] + the pending maps in order, three maps per pass -> x"""
+            while norm_pending or any(maps):
+                x = pipeline_norm_affine(x, norm_pending, [m[:3] for m in maps] if any(maps) else None)
+                maps, norm_pending = [m[3:] for m in maps], False
+            return x
+        for item in aug:
             if item == 'norm':
-                x = pipeline_norm_affine(x, True, maps if any(maps) else None)
-                maps = [[] for _ in range(B)]
+                x = flush(x, norm_pending, maps)                     # everything drawn so far comes before this norm
+                maps, norm_pending = [[] for _ in range(B)], True
                 continue
             for b in range(B):
                 maps[b].append(draw_affine_map(rng, 'aug_' + item))
-        while max(len(m) for m in maps) > 3:                        # more than three augmentation maps: extra passes
-            x = pipeline_norm_affine(x, norm_first, [m[:3] for m in maps])
-            maps, norm_first = [m[3:] for m in maps], False
-        data = pipeline_norm_affine(x, norm_first, maps if any(maps) else None)
+        data = flush(x, norm_pending, maps) if (norm_pending or any(maps)) else pipeline_norm_affine(x, False, None)
         clean = pipeline_subset(data, P, self.npoints, torch.rand((B, P), device=dev, generator=self.gen))
         # ---- corrupt_data (:1046-1096) on the whole cloud
         items = [c for c in self.corrupt_type if not (c in _PASS or 'dropout_global' in c)]   # those run in the model's forward
@@ -455,6 +466,10 @@ class ShapeNet:
         corrupted = pipeline_subset(y, cur, self.npoints, torch.rand((B, stride), device=dev, generator=self.gen), alive)
         return corrupted, clean
 
+    def set_epoch(self, epoch):
+        """DistributedSampler.set_epoch: the next iteration draws epoch `epoch`'s shared permutation (resume-safe)."""
+        self._epoch, self._epoch_set = int(epoch), True
+
     def __iter__(self):
         if self._clouds is None:
             self._materialise()
@@ -462,8 +477,14 @@ class ShapeNet:
         if self.listed and self.world > 1:
             # DistributedSampler semantics: ONE permutation per epoch shared by the ranks (seeded without the
             # rank), padded by wrapping to a multiple of world, rank r takes every world-th index
-            self._epoch = getattr(self, '_epoch', -1) + 1
-            shared = np.random.default_rng([self.seed - self.rank, self._epoch]).permutation(n)
+            # `shared_seed` (config; the runner passes args.seed) is the rank-independent base; without it the constructor's
+            # seed is taken to be base + rank (main.py:81 seeds rank r with seed + r).  set_epoch(e) names the epoch
+            # (the reference calls sampler.set_epoch(epoch), runner_pretrain.py:115); otherwise epochs count from 0.
+            if getattr(self, '_epoch_set', None) is None:
+                self._epoch = getattr(self, '_epoch', -1) + 1
+            self._epoch_set = None
+            base = self.shared_seed if self.shared_seed is not None else self.seed - self.rank
+            shared = np.random.default_rng([base, self._epoch]).permutation(n)
             total = -(-n // self.world) * self.world
             order = np.resize(shared, total)[self.rank::self.world]
             n = order.shape[0]

@@ -157,6 +157,10 @@ class GraphedTrainStep:
         self.micro = 0
         self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
 
+    def reset_micro(self):
+        """the reference restarts its micro-step counter at every epoch (runner_pretrain.py:112), gradients carry over"""
+        self.micro = 0
+
     def set_gradual_weight(self, gw):
         """runner_pretrain.py:113-122: the epoch's ramp factor of `xyznormal_gradual` / `xyznormal_warm`."""
         if self.loss_type in ('xyznormal_gradual', 'xyznormal_warm'):
@@ -398,6 +402,9 @@ class GraphedStaticStep:
         self.eager_left = warmup_eager
         self.spu, self.micro = int(step_per_update), 0
         self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
+
+    def reset_micro(self):
+        self.micro = 0
 
     def _fwd_bwd(self):
         m = self.model

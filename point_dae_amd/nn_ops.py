@@ -454,10 +454,9 @@ def join_wgrad_stream(owner):
 
 def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     """Weight (and bias) gradients of a group of Linear layers that share their rows, one grouped
-    launch (+ the ordered slab reduction).  -> ([dW], [db or None]); outs / db_outs: preallocated outputs
-    (db_outs: one per True in with_bias).  When EVERY output is preallocated by the caller -- the flat gradient
-    views of an armed FlatDataParallel (_sink_views), which autograd never sees -- the reduction may be parked until
-    _lib.deferred_flush; a tensor handed to autograd may be cloned by it on the spot and must be complete."""
+    launch (+ the ordered slab reduction, complete when the call returns to the stream).  -> ([dW], [db or None]);
+    outs / db_outs: preallocated outputs (db_outs: one per True in with_bias), e.g. the flat gradient views of an armed
+    FlatDataParallel (_sink_views)."""
     M = dys[0].shape[0]
     Ns, Ks = [t.shape[1] for t in dys], [t.shape[1] for t in xs]
     ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dys[0])
@@ -465,8 +464,7 @@ def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     it = iter(db_outs) if db_outs is not None else None
     dbs = [(next(it) if it is not None else _empty((n,), dys[0])) if f else None for n, f in zip(Ns, with_bias)]
     probed_family('rows_wgrad', 2.0 * M * sum(n * k for n, k in zip(Ns, Ks)),
-                  lambda: _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws,
-                                          may_defer=outs is not None and (db_outs is not None or not any(with_bias))))
+                  lambda: _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws))
     return dws, dbs
 
 

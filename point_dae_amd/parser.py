@@ -25,8 +25,9 @@ def get_args(argv=None):
     # synthetic-data controls (no dataset ships with this repo)
     p.add_argument('--max_epoch', type=int, default=-1, help='override config.max_epoch')
     p.add_argument('--steps_per_epoch', type=int, default=None,
-                   help='batches per epoch; default: ceil(len(dataset) / total_bs) for a listed .npy set (the '
-                        "reference's DataLoader length), 50 for the synthetic one")
+                   help='batches per epoch; default for a listed .npy set: the reference\'s DataLoader length -- '
+                        'floor(ceil(N / world) / bs) for the training subset (drop_last, tools/builder.py:21,28), ceil '
+                        'otherwise; 50 for the synthetic set')
     args = p.parse_args(argv)
     if args.resume and args.start_ckpts is not None:
         raise ValueError('--resume and --start_ckpts cannot be both activate')

@@ -160,8 +160,9 @@ class PatchEmbedFunction(torch.autograd.Function):
         f = _empty((R, c2), x)
         g = _empty((BG, c2), x)
         arg2 = _empty((BG, c2), x, torch.uint8)
-        _lib.call('pdae_embed_bnrelu_conv_store_groupmax', x, R, c2, c1, _lib.ptr(y1), _lib.ptr(sc1),
-                  _lib.ptr(sh1), _lib.ptr(w2m), _lib.ptr(b2), _lib.ptr(f), _lib.ptr(g), _lib.ptr(arg2))
+        probed_family('embed_gemm', 2.0 * R * c2 * c1, lambda: _lib.call(
+            'pdae_embed_bnrelu_conv_store_groupmax', x, R, c2, c1, _lib.ptr(y1), _lib.ptr(sc1),
+            _lib.ptr(sh1), _lib.ptr(w2m), _lib.ptr(b2), _lib.ptr(f), _lib.ptr(g), _lib.ptr(arg2)))
         # conv3 on concat([g, f]): global half once per group, local half as the GEMM
         wg = w3m[:, :c2].contiguous()
         wl = w3m[:, c2:].contiguous()
@@ -169,10 +170,11 @@ class PatchEmbedFunction(torch.autograd.Function):
         h3 = _empty((R, c3), x)
         stats = _empty((8, 2, c3), x)
         # the largest hand-written kernel of the step: bench.py's roofline kernel
-        probed('gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS> patch_embed.second_conv[0] fwd %dx%dx%d' % (R, c3, c2),
-               2.0 * R * c3 * c2,
-               lambda: _lib.call('pdae_embed_conv_groupbias_stats', x, R, c3, c2, _lib.ptr(f), _lib.ptr(wl),
-                                 _lib.ptr(gb), _lib.ptr(h3), _lib.ptr(stats)))
+        probed_family('embed_gemm', 2.0 * R * c3 * c2, lambda: probed(
+            'gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS> patch_embed.second_conv[0] fwd %dx%dx%d' % (R, c3, c2),
+            2.0 * R * c3 * c2,
+            lambda: _lib.call('pdae_embed_conv_groupbias_stats', x, R, c3, c2, _lib.ptr(f), _lib.ptr(wl),
+                              _lib.ptr(gb), _lib.ptr(h3), _lib.ptr(stats))))
         if training:
             sc2, sh2, mean2, is2 = _bn_finalize(second_conv[1], R, x, partials=stats)
         else:
@@ -193,8 +195,9 @@ class PatchEmbedFunction(torch.autograd.Function):
         tok = _empty((Gv, c4), x)
         arg4 = _empty((Gv, c4), x, torch.uint8)
         # the largest GEMM of the step: bench.py's roofline kernel
-        _lib.call('pdae_embed_bnrelu_conv_groupmax', x, Rv, c4, c3, _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
-                  _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4), _lib.ptr(groups))
+        probed_family('embed_gemm', 2.0 * Rv * c4 * c3, lambda: _lib.call(
+            'pdae_embed_bnrelu_conv_groupmax', x, Rv, c4, c3, _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+            _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4), _lib.ptr(groups)))
         ctx.save_for_backward(x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
                               w1m, w2m, wg, wl, w4m, g1, g2, groups, inv)
         ctx.training = training
@@ -239,10 +242,13 @@ class PatchEmbedFunction(torch.autograd.Function):
         q = _wgrad(wl * v.unsqueeze(1), wl)                           # W^T diag(v) W  (symmetric)
         e = _gemm(xe, wl, True)                                       # (gb_g * v + u) W   (Gm, 256)
         df = _empty((R, c2), x)
-        _lib.call('pdae_group_gemm_scatter', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(q), _lib.ptr(e),
-                  _lib.ptr(df), c2, _lib.ptr(masked))
-        _lib.call('pdae_group_gemm_scatter', x, Rv, c2, c3, _lib.ptr(d3c), None, _lib.ptr(wl.t().contiguous()), None,
-                  _lib.ptr(df), c2, _lib.ptr(groups))
+        probed_family('embed_gemm', 2.0 * Rm * c2 * c2, lambda: _lib.call(
+            'pdae_group_gemm_scatter', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(q), _lib.ptr(e),
+            _lib.ptr(df), c2, _lib.ptr(masked)))
+        wlt = wl.t().contiguous()
+        probed_family('embed_gemm', 2.0 * Rv * c2 * c3, lambda: _lib.call(
+            'pdae_group_gemm_scatter', x, Rv, c2, c3, _lib.ptr(d3c), None, _lib.ptr(wlt), None,
+            _lib.ptr(df), c2, _lib.ptr(groups)))
         return dwl, dgb, df, S2[0], S2[1]
 
     @staticmethod

@@ -40,7 +40,8 @@ class Probe:
         out = {}
         for fam, fns in self.calls.items():
             g = torch.cuda.CUDAGraph()
-            for fn in fns:                                         # warm (allocations inside the closures: none)
+            for fn in fns:                                         # warm (the weight-gradient closure allocates its workspace
+                                                                   # per call: torch's graph-private pool serves it under capture)
                 fn()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):

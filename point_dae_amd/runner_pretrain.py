@@ -69,7 +69,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     use_created_stream(device)
     ds_cfg = dict(config.dataset.train._base_)          # NAME, N_POINTS, PC_PATH, DATA_PATH (reference schema)
     ds_cfg.update(dict(config.dataset.train.others))
-    ds_cfg.update(seed=args.seed + rank, device=device, steps_per_epoch=getattr(args, 'steps_per_epoch', None),
+    ds_cfg.update(seed=args.seed + rank, shared_seed=args.seed, device=device, steps_per_epoch=getattr(args, 'steps_per_epoch', None),
                   rank=rank, world=world)
     ds_cfg.setdefault('bs', config.total_bs // world)
     train_loader = DATASETS.build(ds_cfg)
@@ -137,6 +137,11 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
 
     for epoch in range(start_epoch, config.max_epoch + 1):
         model.train()
+        num_iter = 0                                   # runner_pretrain.py:112: the micro-step counter restarts every epoch
+        if graphed is not None and hasattr(graphed, 'reset_micro'):
+            graphed.reset_micro()                      # (gradients accumulated so far are kept, as in the reference)
+        if hasattr(train_loader, 'set_epoch'):
+            train_loader.set_epoch(epoch)              # :115 sampler.set_epoch(epoch)
         gw = gradual_weight_of(config, epoch)
         gw_dev.fill_(float(gw))
         if isinstance(graphed, GraphedTrainStep):

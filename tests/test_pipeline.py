@@ -118,7 +118,8 @@ def test_device_dataset_end_to_end(tmp_path):
                                      (['norm', 'rotate'], ['dropout_local']), (['norm'], ['add_global']),
                                      (['norm', 'rotate_z'], ['nonuniform_density']), (['norm'], ['shear']),
                                      (['norm'], ['scale']), (['norm', 'translate', 'scale'], ['affine_r3', 'dropout_local']), (['norm'], ['add_local']),
-                                     (['norm'], ['affine_r3', 'add_local']), (['norm'], ['rotate', 'nonuniform_density'])])
+                                     (['norm'], ['affine_r3', 'add_local']), (['norm'], ['rotate', 'nonuniform_density']),
+                                     (['scale', 'norm'], ['clean']), (['translate', 'scale', 'rotate', 'scale', 'norm'], ['clean'])])
 def test_device_dataset_augmentations_and_corruptions(aug, cor):
     """every loader-side augmentation / corruption the device pipeline implements (the reference's pretrain YAMLs
     use these names: aug ['norm','scale','translate'] in 25 of them) -> finite (B, npoints, 3) batches with the
@@ -133,7 +134,9 @@ def test_device_dataset_augmentations_and_corruptions(aug, cor):
         r = clean.norm(dim=-1).amax(dim=1)
         if aug == ['norm']:
             assert (r <= 1 + 1e-5).all()
-        if 'scale' in aug:
+        if aug[-1] == 'norm':                  # augment_data applies the list in order (corrupt_util.py:1155-1175): a closing
+            assert (r <= 1 + 1e-5).all() and (r >= 1 - 1e-4).all()      # 'norm' leaves the unit sphere whatever came before
+        elif 'scale' in aug:
             assert (r <= 1.5 * 1.001 + 0.2 * 3 ** 0.5).all() and (r >= 2 / 3 - 0.2 * 3 ** 0.5 - 1e-3).all()
         if 'rotate' in aug or 'rotate_z' in aug:
             assert (r <= 1 + 1e-4).all() and (r >= 0.8).all()                 # rotations keep the unit sphere
