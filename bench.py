@@ -230,8 +230,8 @@ def dominant_roofline(probe, steps, bf16x3):
                   'profiles/kernel_summary_r%02d.txt has the same kernels\' durations inside the step\'s replays' % ROUND)
         for k in fam:
             rows[k]['ms_per_step'] = rep[k]
-            rows[k]['achieved'] = rows[k]['gflop_per_step'] / rep[k] / 1e3 if rep[k] > 0 else 0.0
-    ach = gflop / ms / 1e3
+            rows[k]['achieved'] = rows[k]['gflop_per_step'] / rep[k] if rep[k] > 0 else 0.0      # GFLOP / ms = TFLOP/s
+    ach = gflop / ms                                  # GFLOP / ms = TFLOP/s
     traffic = traffic_src = None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % ROUND)
     if os.path.exists(pmc):
@@ -626,7 +626,7 @@ def main():
         fams = probe.family_summary()
         if fams and args.probe_steps and not args.eager:
             gf = sum(r['flops'] for r in fams.values()) / args.probe_steps / 1e9
-            tf = gf / (elapsed / args.steps * 1e3) / 1e3
+            tf = gf / (elapsed / args.steps * 1e3)            # GFLOP / ms = TFLOP/s
             line['whole_step'] = {'gflop_executed': gf, 'achieved': tf, 'unit': 'TFLOP/s',
                                   'frac_of_f32_mfma_peak': tf / MFMA_F32_PEAK_TFLOPS,
                                   'frac_of_bf16x3_peak': tf / BF16X3_PEAK_TFLOPS,

@@ -377,221 +377,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Grouped weight gradients dW_p[N_p, K_p] = dY_p^T . X_p on the same arithmetic: the work layout, the partial-tile
-// slots and the ordered reduction of rows::wgrad_kernel (rows_common.h), the reduction over rows m in 16-row slabs.
-// Both operands are stored ACROSS the reduction ([m][column]): a thread stages a patch of 8 m x PW columns of the
-// joint [dY band | X band] slab -- eight loads down the rows, the transpose is free in registers -- and writes PW
-// octets per plane, so LDS holds [plane][column][16 m] (48-B rows: ds_read_b128 slots 3 r + h mod 16, conflict-free)
-// and a fragment is one ds_read_b128 exactly as in gemm3_kernel.  Output tile 128 (n) x TN (k), waves 2 x (NT / 128)
-// of 64 x (TN 128 / NT): TI = 2 tile rows, TJ = 2 or 3 tile columns per wave.
-// ONE register set of fragments, refreshed in place: MFMAs run tile row 0 first, the barrier sits behind tile (1, 0),
-// and each fragment of the next slab is read behind the last MFMA that uses the old one (A0 and B0 behind the barrier,
-// B_j behind tile (1, j)); the two that live to the end (A1, B_last) are read at the top of the next slab, ahead of
-// their first use.
-template <int TN, int NT, bool DUAL, bool FORMS>
-__global__ __launch_bounds__(NT, 2) void wgrad3_kernel(const rows::WgradArgs g) {
-  using rows::WgradProb;
-  constexpr int TM = rows::WTM, COLS = TM + TN, SLB = rows::TBK, WCH = rows::WCH;
-  constexpr int WNV = NT / 128;                        // waves along k (two along n)
-  constexpr int TI = 2, TJ = TN / (32 * WNV), G = TI * TJ;
-  constexpr int ROWW = 48;                             // bytes per LDS row: 16 bf16 + 16 B pad
-  constexpr int PLANE = COLS * ROWW, BUF = 3 * PLANE;
-  constexpr int PW = (2 * COLS + NT - 1) / NT;         // columns per patch: a slab is 2 m-octets x COLS columns
-  constexpr int CPP = COLS / PW, NPATCH = 2 * CPP;
-  constexpr int WSLOT = rows::wslot(TN);
-  static_assert(TJ >= 2 && TN % (32 * WNV) == 0 && COLS % PW == 0 && NPATCH <= NT && TM % PW == 0, "tile / patch layout");
-  extern __shared__ __attribute__((aligned(16))) char lds3[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WNV, wn = wave % WNV;
-  const int r = lane & 31, h = lane >> 5;
-  // every thread stages a patch: threads past the last patch repeat an earlier one (same loads, same LDS stores of
-  // the same values) -- no divergent branch anywhere in the loop; only the column sums count a patch once
-  const bool active = tid < NPATCH;
-  const int pid = active ? tid : tid - NPATCH;
-  const int mg = pid / CPP, col = (pid % CPP) * PW;    // this thread's patch: rows 8 mg .. 8 mg + 7, columns col ..
-  const bool isb = col >= TM;
-  const int plds = col * ROWW + mg * 16;
-  const int nb8 = g.blocks >> 3;
-  const int sb = g.blocks % 8 == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  long long u = rows::wg_start(g, sb);
-  const long long uend = rows::wg_start(g, sb + 1);
-  float* slot = g.partials + (size_t)sb * g.slots * WSLOT;
-  const int fa_off = (wm * 64 + r) * ROWW + 16 * h, fb_off = (TM + wn * TJ * 32 + r) * ROWW + 16 * h;
-  for (; u < uend; slot += WSLOT) {
-    const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
-    const long long rel = u - P.unit0;
-    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
-    const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
-    u += c1 - c0;
-    const int bx = lt % P.tk, by = lt / P.tk;
-    const int n0 = by * TM, k0 = bx * TN;
-    const int mbeg = c0 * WCH, mend = min(P.M, c1 * WCH);
-    const int gcol = isb ? k0 + col - TM : n0 + col;
-    const int glim = isb ? P.K : P.N;                 // (N, K are multiples of 4, col of PW: a patch is inside or outside)
-    const bool ok = gcol < glim;
-    // which band, which m-octet: the same for a whole wave (64 consecutive patches lie in one band) -- row pointers
-    // are then SCALAR (base + row * ld in SGPRs) and a thread carries one 32-bit column offset
-    const bool isb_u = __builtin_amdgcn_readfirstlane((int)isb) != 0;
-    const int mg_u = __builtin_amdgcn_readfirstlane(mg);
-    const float* const base_u = isb_u ? P.X : P.dY;
-    const unsigned ld = isb_u ? P.K : P.N;
-    const unsigned colb = (unsigned)min(gcol, glim - PW);      // columns past the edge: a valid address, zeros staged
-    const bool sum_a = P.db != nullptr && bx == 0 && !isb && active;
-    // FORMS: the embedder's operand forms (listed 32-row groups, BatchNorm + ReLU recomputed on the X band); the
-    // Transformer stacks' instantiation carries none of their registers
-    const int* const grp_a = FORMS ? g.a_groups : nullptr;
-    const int* const grp_b = FORMS ? g.b_groups : nullptr;
-    const bool listed = FORMS && (grp_a != nullptr || grp_b != nullptr);
-    const bool bnrelu = FORMS && g.scale != nullptr;  // (block-uniform)
-    float bsc[PW], bsh[PW], asum[PW];
-    float floor_ = -__builtin_inff();                 // ReLU only on the X band's threads
-#pragma unroll
-    for (int c = 0; c < PW; ++c) {
-      bsc[c] = 1.f, bsh[c] = 0.f, asum[c] = 0.f;
-      if (bnrelu && isb && ok) bsc[c] = g.scale[gcol + c], bsh[c] = g.shift[gcol + c], floor_ = 0.f;
-    }
-    float v[PW][8];
-    u32x4 pk[PW][3];
-    // eight loads down the rows, unconditional (rows past the end re-read the last row), then zeros by select: a
-    // load behind a per-row branch would cost one memory round trip per row
-    auto gload = [&](int mt) __attribute__((always_inline)) {
-      const int mlast = mend - 1;
-      int off = 0;                                     // stored row - product row of this slab (listed operands)
-      if (listed) {
-        const int gq = min(mt, mlast) >> 5;
-        if (isb_u ? grp_b != nullptr : grp_a != nullptr) off = ((isb_u ? grp_b : grp_a)[gq] - gq) * 32;
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int m = mt + 8 * mg_u + q;                                      // (scalar)
-        const float* sp = base_u + (size_t)(min(m, mlast) + off) * ld + colb;
-        if (PW == 2) {
-          const float2 t = *reinterpret_cast<const float2*>(sp);
-          v[0][q] = t.x, v[PW - 1][q] = t.y;
-        } else {
-          v[0][q] = *sp;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const bool in = ok && mt + 8 * mg_u + q < mend;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) {
-          float t = v[c][q];
-          if (bnrelu) t = fmaxf(t * bsc[c] + bsh[c], floor_);
-          v[c][q] = in ? t : 0.f;
-        }
-      }
-    };
-    const bool sum_u = __builtin_amdgcn_readfirstlane((int)sum_a) != 0;   // (a wave stages one band: scalar branch)
-    auto colsums = [&]() __attribute__((always_inline)) {
-      if (sum_u) {
-#pragma unroll
-        for (int c = 0; c < PW; ++c)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) asum[c] += v[c][q];
-      }
-    };
-    auto side_chunk = [&](auto c_c, int buf) __attribute__((always_inline)) {
-      constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8;
-      char* d = lds3 + buf * BUF + plds + o * ROWW;
-      split_chunk<ch>(v[o], pk[o]);
-      if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[o][0];
-      if (ch == 7) {
-        *reinterpret_cast<u32x4*>(d + PLANE) = pk[o][1];
-        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[o][2];
-      }
-    };
-    f32x16 hi[TI][TJ], lo[DUAL ? TI : 1][DUAL ? TJ : 1];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          hi[i][j][e] = 0.f;
-          if (DUAL) lo[DUAL ? i : 0][DUAL ? j : 0][e] = 0.f;
-        }
-    bf16x8 fa[TI][3], fb[TJ][3];
-    auto read_a = [&](int i, int buf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        fa[i][pl] = *reinterpret_cast<const bf16x8*>(lds3 + buf * BUF + pl * PLANE + fa_off + i * 32 * ROWW);
-    };
-    auto read_b = [&](int j, int buf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        fb[j][pl] = *reinterpret_cast<const bf16x8*>(lds3 + buf * BUF + pl * PLANE + fb_off + j * 32 * ROWW);
-    };
-    constexpr int S = 6 * G;                           // slots (MFMAs) of a slab
-    constexpr int SBW = 6 * TJ + 6;                    // the barrier sits behind slot SBW - 1: tile row 0 and tile (1, 0) done
-    constexpr int NC = 8 * PW, SC = SBW - 1;           // split chunks of a slab, spread over slots [0, SC)
-    const int nslab = (mend - mbeg + SLB - 1) / SLB;
-    gload(mbeg);
-    colsums();
-    static_for<NC>([&](auto c_c) { side_chunk(c_c, 0); });
-    gload(mbeg + SLB);
-    __syncthreads();
-    read_a(0, 0);
-#pragma unroll
-    for (int j = 0; j < TJ - 1; ++j) read_b(j, 0);
-    int buf = 0;
-    for (int sl = 0; sl < nslab; ++sl) {
-      const bool more1 = sl + 1 < nslab;
-      // the two fragments that lived to the end of the previous slab
-      read_a(1, buf);
-      read_b(TJ - 1, buf);
-      if (more1) colsums();
-      static_for<S>([&](auto s_c) {
-        constexpr int s = decltype(s_c)::value;
-        constexpr int gi = s / 6, q = s % 6, i = gi / TJ, j = gi % TJ;
-        mfma_one<DUAL, q>(fa[i], fb[j], hi[i][j], lo[DUAL ? i : 0][DUAL ? j : 0]);
-        static_for<NC>([&](auto c_c) {
-          constexpr int c = decltype(c_c)::value;
-          if constexpr (c * SC / NC == s) side_chunk(c_c, buf ^ 1);
-        });
-        if constexpr (s == (NC - 1) * SC / NC) gload(mbeg + (sl + 2) * SLB);
-        if constexpr (s == SBW - 1) {
-          __syncthreads();
-          read_a(0, buf ^ 1);                          // tile row 0 and tile (1, 0) are done: A0 and B0 are free
-          read_b(0, buf ^ 1);
-        }
-        // behind the last MFMA of tile (1, j): B_j is free (the last one is read at the top of the next slab)
-        if constexpr (s >= SBW && q == 5 && j < TJ - 1) read_b(j, buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      buf ^= 1;
-    }
-    // ---- the partial tile (whole TM x TN, edges included: the reduction stores what is inside)
-    __syncthreads();                                   // (the refresh reads above touched the buffer nobody needs)
-    if (P.db != nullptr && bx == 0) {
-      float* red = reinterpret_cast<float*>(lds3);     // [2 m-octets][TM]; the slab buffers are free now
-      if (active && !isb) {
-#pragma unroll
-        for (int c = 0; c < PW; ++c) red[mg * TM + col + c] = asum[c];
-      }
-      __syncthreads();
-      if (tid < TM) slot[TM * TN + tid] = red[tid] + red[TM + tid];
-      __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          slot[row * TN + wn * TJ * 32 + j * 32 + r] =
-              DUAL ? hi[i][j][e] + lo[DUAL ? i : 0][DUAL ? j : 0][e] : hi[i][j][e];
-        }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// The same weight gradients on gemm3_kernel's pipeline: output tile 128 (n) x 128 (k), eight waves of 32 x 64, 32-row
-// LDS tiles (two 16-deep steps per barrier), fragments in two register sets, TWO register sets of staged fp32 (two
-// tiles of global loads in flight: the single-set kernel above waits for every slab's loads).  Both bands are staged
+// Grouped weight gradients dW_p[N_p, K_p] = dY_p^T . X_p on the same arithmetic and on gemm3_kernel's pipeline: the work
+// layout, the partial-tile slots and the ordered reduction of rows::wgrad_kernel (rows_common.h); output tile 128 (n)
+// x 128 (k), eight waves of 32 x 64, the reduction over rows m in 32-row LDS tiles (two 16-deep steps per barrier),
+// fragments in two register sets, TWO register sets of staged fp32 (two tiles of global loads in flight; a first
+// version with one set and 64 x 64 wave tiles waited for every tile's loads: 100 vs 130 TFLOP/s).  Both operands are
+// stored ACROSS the reduction ([m][column]): a thread's eight loads run down the rows, the transpose is free in
+// registers, and LDS holds [plane][column][32 m] exactly as gemm3_kernel's tiles.  Both bands are staged
 // in patches of 8 m x 1 column: thread -> (m-octet tid / 128, column tid % 128) of the dY band AND of the X band, row
 // pointers scalar, one 32-bit column offset per band.  Rows past the end of a segment, columns past the matrix edge,
 // the BatchNorm + ReLU producer and the column sums are applied to a register set right before it is split

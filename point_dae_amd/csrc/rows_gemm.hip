@@ -741,6 +741,12 @@ extern "C" int pdae_set_gemm_arith(int arith) {
   return PDAE_OK;
 }
 extern "C" int pdae_gemm_arith(void) { return gemm_arith(); }
+// (lab) PDAE_GEMM_ONLY=rows | wgrad: the exact-split arithmetic for that half of the family only
+static int arith_of(bool wgrad) {
+  static const char* only = getenv("PDAE_GEMM_ONLY");
+  if (only && gemm_arith() == PDAE_GEMM_BF16X3 && (wgrad ? strcmp(only, "wgrad") : strcmp(only, "rows")) != 0) return PDAE_GEMM_F32MFMA;
+  return gemm_arith();
+}
 
 // shapes the exact-split kernels take: the reduction in whole 32-deep tiles (every layer of the models but the K = 3
 // / K = 4 ones), 32-bit byte offsets as the fp32 kernels
@@ -783,7 +789,7 @@ static void plan_rows3(int M, int N, int K, bool may_split, int* cfg, int* split
 extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits,
                                    int* stream_blocks) {
   if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits || !stream_blocks) return bad_arg("rows_gemm_plan: bad argument");
-  if (gemm_arith() == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0))
+  if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0))
     plan_rows3(M > 0 ? M : 1, N, K, may_split != 0, cfg, splits, stream_blocks);
   else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits, stream_blocks);
   return PDAE_OK;
@@ -802,7 +808,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   if (fam3 && !gemm3_takes(N, K, w_kn != 0)) return unsupported("rows_gemm: the exact-split bf16 tile shapes need K % 32 == 0");
   if (cfg < 0 || splits < 0) {
     int c, s, b;
-    if (gemm_arith() == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, false, &c, &s, &b);
+    if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, false, &c, &s, &b);
     else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s, &b);
     if (cfg < 0) cfg = c;
     if (splits < 0) splits = 1, stream_blocks = 0;
@@ -850,7 +856,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
 // the widest tile every layer's K is a multiple of: 384 (the Transformer blocks: 384, 1536), 256 (FoldingNet, the
 // PointNet++ levels: 256, 512, 1024), else 128
 static int wgrad_tile_width(int nprob, const int* Ks) {
-  if (gemm_arith() == PDAE_GEMM_BF16X3) return 128;         // exact-split kernel: 128 x 128 tiles (two accumulator sets)
+  if (arith_of(true) == PDAE_GEMM_BF16X3) return 128;         // exact-split kernel: 128 x 128 tiles (two accumulator sets)
   static const char* force = getenv("PDAE_WGRAD_TN");       // A/B switch (tools/lab/ab.sh): caps the tile width
   const int cap = force ? atoi(force) : 384;
   bool w384 = cap >= 384, w256 = cap >= 256;
@@ -880,7 +886,7 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
   }
   g->nprob = nprob, g->tiles = tiles, g->units = units;
   // one residency of the chip: 256 CUs x 2 blocks of 4 waves (128-wide tiles), x 1 block of 8 waves (384-wide)
-  int wg_blocks = (WTN >= 256 || gemm_arith() == PDAE_GEMM_BF16X3) ? 256 : 512;   // (the exact-split kernel: 8 waves, 122 KB of LDS)
+  int wg_blocks = (WTN >= 256 || arith_of(true) == PDAE_GEMM_BF16X3) ? 256 : 512;   // (the exact-split kernel: 8 waves, 122 KB of LDS)
   // (lab) PDAE_WGRAD_BPT=k: k blocks per output tile instead of one residency of the chip
   static const int bpt = getenv("PDAE_WGRAD_BPT") ? atoi(getenv("PDAE_WGRAD_BPT")) : 0;
   if (bpt > 0) wg_blocks = (bpt * tiles + 7) / 8 * 8;
@@ -958,7 +964,7 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   for (int q = 1; q < nprob; ++q) max_chunks = g.p[q].chunks > max_chunks ? g.p[q].chunks : max_chunks;
   const long long most = (max_chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
-  if (gemm_arith() == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
+  if (arith_of(true) == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
   else if (tn == 384) wgrad_launch<384>(g, pl, s);
   else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);
@@ -984,7 +990,7 @@ extern "C" int pdae_rows_wgrad_listed(int M, int N, int K, const float* dY, cons
   const long long most = (g.p[0].chunks * (long long)g.blocks + g.units - 1) / g.units + 1;
   const int pl = most <= 16 ? 1 : (most <= 64 ? 4 : 8);
   hipStream_t s = as_stream(stream);
-  if (gemm_arith() == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
+  if (arith_of(true) == PDAE_GEMM_BF16X3) rows3::launch_wgrad3(g, tn, pl, s);
   else if (tn == 384) wgrad_launch<384>(g, pl, s);
   else if (tn == 256) wgrad_launch<256>(g, pl, s);
   else wgrad_launch<128>(g, pl, s);

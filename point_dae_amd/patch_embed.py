@@ -64,6 +64,7 @@ def _gemm(x, w, w_kn=False, bias=None):
 # the embedder's own weight gradients (group-listed operands, BatchNorm + ReLU recomputed) on the grouped kernel of
 # csrc/rows_gemm.hip (ordered reduction, no atomics, no memset); PDAE_EMBED_WGRAD=tn: round 1's gemm_tn kernels (A/B)
 WGRAD_ROWS = os.environ.get('PDAE_EMBED_WGRAD', 'rows') != 'tn'
+DEBUG_KEEP = None       # (lab) a dict: the backward keeps clones of its intermediates in it (tools/lab/model_nondet.py)
 
 
 def _wgrad_listed(M, dy, a_groups, x, b_groups, scale=None, shift=None, bias=False):
@@ -298,6 +299,8 @@ class PatchEmbedFunction(torch.autograd.Function):
         # ---- conv2
         dw2, db2 = _wgrad_listed(R, df, None, y1, None, sc1, sh1, bias=True)    # db2: column sums of df, same kernel
         d1 = _gemm(df, w2m, True)                                 # (R, 128)
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.update(df=df.clone(), d1_pre=d1.clone(), dw2=dw2.clone(), y1=y1.clone())
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)
         S1 = _empty((2, c1), x)
@@ -307,6 +310,8 @@ class PatchEmbedFunction(torch.autograd.Function):
         part1 = _empty((_lib.lib().pdae_embed_conv1_backward_weight_parts(R), 3, c1), x)
         _lib.call('pdae_embed_conv1_backward_weight', x, R, c1, _lib.ptr(d1), _lib.ptr(x), _lib.ptr(part1))
         dw1 = part1.sum(0).t().unsqueeze(-1)                          # (c1, 3, 1): one pass over d1, ordered partials
+        if DEBUG_KEEP is not None:
+            DEBUG_KEEP.update(d1_post=d1.clone(), part1=part1.clone(), dw1=dw1.clone(), x=x.clone(), S1=S1.clone())
         db1 = arena.take(c1, x)[0]                                   # exactly zero, as db3 (saves a 134 MB pass)
         return (None, dw1, db1, dg1, dbe1, dw2.unsqueeze(-1), db2, dw3, db3, dg2, dbe2,
                 dw4.unsqueeze(-1), db4, None, None, None, None, None)
