@@ -49,6 +49,7 @@ BF16X3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
                                   # kernels are sub / mul / add / min chains
+EXP_PEAK_TOPS = 9.8               # v_exp_f32 per second (T/s): the transcendental rate VERDICT r3 prices EMD against
 ROUND = 4                         # profiles/*_rNN.json this bench refers to
 
 
@@ -131,6 +132,25 @@ def geometry_rooflines(args, clouds):
     us = _event_time_us(lambda: _lib.call('pdae_chamfer_backward', a, P, k, _lib.ptr(a), k, _lib.ptr(b), _lib.ptr(i1),
                                           _lib.ptr(i2), _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(ga), _lib.ptr(gb)))
     row('chamfer_bwd_packed (%d patches of %dx%d)' % (P, k, k), us, P * (12 * 2 * k + 4 * 2 * k + 4 * 2 * k + 12 * 2 * k), P * 2 * k)
+    # EMD (extensions/emd: the north star names it; no model of the reference calls it): approxmatch = 10 levels x 3
+    # phases over every point pair, one v_exp_f32 and ~13 other vector operations per pair and phase.  Ceilings: the
+    # exp rate (EXP_PEAK: quarter-rate transcendental unit) and the fp32 vector peak.
+    from point_dae_amd import emd
+
+    def emd_row(name, a, b):
+        Bp, n, m = a.shape[0], a.shape[1], b.shape[1]
+        us = _event_time_us(lambda: emd.approxmatch_forward(a, b), iters=10)
+        pairs = Bp * n * m * 30
+        match = emd.approxmatch_forward(a, b)
+        us_cost = _event_time_us(lambda: emd.matchcost_forward(a, b, match), iters=10)
+        out.append({'kernel': name, 'avg_us': us, 'algorithmic_bytes': Bp * (12 * (n + m) + 4 * n * m),
+                    'hbm_frac': Bp * (12 * (n + m) + 4 * n * m) / (us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                    'pair_ops': pairs * 14, 'valu_frac': pairs * 14 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),
+                    'exp_per_s': pairs / (us * 1e-6), 'exp_frac': pairs / (us * 1e-6) / EXP_PEAK_TOPS / 1e12,
+                    'matchcost_avg_us': us_cost})
+    emd_row('emd approxmatch, one wave per pair (%d patches of %dx%d)' % (P, k, k), a, b)
+    big = clouds[:16].contiguous()
+    emd_row('emd approxmatch, one launch per phase (8 clouds of %dx%d)' % (N, N), big[:8].contiguous(), big[8:16].contiguous())
     return out
 
 

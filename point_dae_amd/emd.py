@@ -16,8 +16,11 @@ def approxmatch_forward(xyz1, xyz2):
     B, n, _ = xyz1.shape
     m = xyz2.shape[1]
     match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
+    # the reference's scratch (emd.cpp:12: temp (b, (n + m) * 2)): the remain / ratio vectors of the per-phase launches
+    # that clouds of more than 64 points take; the one-wave-per-pair kernel of small clouds keeps them on chip
+    temp = torch.empty((B, 2 * (n + m)), dtype=torch.float32, device=xyz1.device) if max(n, m) > 64 else None
     _lib.call("pdae_emd_approxmatch", xyz1, B, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2),
-              _lib.ptr(match), None)
+              _lib.ptr(match), _lib.ptr(temp))
     return match
 
 

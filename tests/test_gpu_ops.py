@@ -345,7 +345,8 @@ def test_emd_known_answer_gpu():
     assert abs(earth_mover_distance()(p1, p2).item() - 0.355) < 1e-4
 
 
-@pytest.mark.parametrize("B,n,m", [(4, 32, 32), (2, 256, 256), (2, 100, 300), (1, 1024, 1024), (2, 300, 100)])
+@pytest.mark.parametrize("B,n,m", [(4, 32, 32), (2, 256, 256), (2, 100, 300), (1, 1024, 1024), (2, 300, 100),
+                                   (9, 32, 32), (5, 17, 32), (3, 64, 48), (3, 20, 64), (1, 1, 1), (2, 65, 64), (1, 2048, 512)])
 def test_emd_vs_oracle(oracle_ops, B, n, m):
     from point_dae_amd import emd
     a = make_clouds(81, B, n)
@@ -367,6 +368,20 @@ def test_emd_vs_oracle(oracle_ops, B, n, m):
     got = emd.earth_mover_distance()(dev(a), dev(b)).item()
     want = oracle_ops.earth_mover_distance(a, b)
     assert abs(got - want) <= 1e-3 * abs(want)
+
+
+def test_emd_forms_agree(oracle_ops):
+    """approxmatch's three forms on one input: per-phase launches (scratch given), the one-work-group kernel (no
+    scratch: pdae_emd_approxmatch's temp is nullable) -- same `match` up to the summation order of the sliced sums."""
+    from point_dae_amd import _lib
+    a, b = dev(make_clouds(91, 2, 256)), dev(make_clouds(92, 2, 200))
+    B, n, m = 2, 256, 200
+    out = []
+    for temp in (torch.empty(B, 2 * (n + m), device='cuda'), None):
+        match = torch.full((B, m, n), float('nan'), device='cuda')
+        _lib.call('pdae_emd_approxmatch', a, B, n, m, _lib.ptr(a), _lib.ptr(b), _lib.ptr(match), _lib.ptr(temp))
+        out.append(host(match))
+    np.testing.assert_allclose(out[0], out[1], rtol=2e-3, atol=2e-6)
 
 
 # ------------------------------------------------------ error behaviour ----
