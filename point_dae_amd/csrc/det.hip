@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(int P, int width, const
   T* out = c < n0 ? (o0 ? o0 + c : nullptr)
                   : (c < n0 + n1 ? (o1 ? o1 + (c - n0) : nullptr) : (o2 ? o2 + (c - n0 - n1) : nullptr));
   if (!out) return;
-  // eight independent loads in flight, added in partition order
-  T t = 0;
+  // eight independent loads in flight, added in partition order (in fp64: hundreds of partials of mixed sign)
+  double t = 0;
   int p = 0;
   for (; p + 8 <= P; p += 8) {
     T v[8];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(int P, int width, const
     for (int k = 0; k < 8; ++k) t += v[k];
   }
   for (; p < P; ++p) t += part[(size_t)p * width + c];
-  *out += t;
+  *out += (T)t;
 }
 
 int det_reduce(hipStream_t s, int P, int width, const float* part, float* o0, int n0, float* o1, int n1,

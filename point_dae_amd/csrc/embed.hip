@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c4 = (blockIdx.x * 32 + cl) * 4;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  // (sums over up to a million rows of mixed sign: per-thread chains in fp64, as ATen's CPU kernel accumulates them)
+  double a1x = 0., a1y = 0., a1z = 0., a1w = 0., a2x = 0., a2y = 0., a2z = 0., a2w = 0.;
   if (c4 < C) {
     const float4 sc = *reinterpret_cast<const float4*>(scale + c4);
     const float4 sh = *reinterpret_cast<const float4*>(shift + c4);
@@ -74,13 +75,15 @@ __global__ __launch_bounds__(256) void bnrelu_backward_reduce_kernel(
       const float ty = (x.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
       const float tz = (x.z * sc.z + sh.z > 0.f) ? d.z : 0.f;
       const float tw = (x.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
-      s1.x += tx, s1.y += ty, s1.z += tz, s1.w += tw;
-      s2.x += tx * ((x.x - mu.x) * is.x);
-      s2.y += ty * ((x.y - mu.y) * is.y);
-      s2.z += tz * ((x.z - mu.z) * is.z);
-      s2.w += tw * ((x.w - mu.w) * is.w);
+      a1x += tx, a1y += ty, a1z += tz, a1w += tw;
+      a2x += tx * ((x.x - mu.x) * is.x);
+      a2y += ty * ((x.y - mu.y) * is.y);
+      a2z += tz * ((x.z - mu.z) * is.z);
+      a2w += tw * ((x.w - mu.w) * is.w);
     }
   }
+  const float4 s1 = make_float4((float)a1x, (float)a1y, (float)a1z, (float)a1w);
+  const float4 s2 = make_float4((float)a2x, (float)a2y, (float)a2z, (float)a2w);
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void pool_bn_reduce_kernel(long long G, int ns
   const long long g1 = g0 + PB_GROUPS < G ? g0 + PB_GROUPS : G;
   const float4 mu = mean[q], is = invstd[q];
   const int C = C4 * 4;
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  // the sums run over up to a million rows of mixed sign (the reference's ATen kernel accumulates them in double on the
+  // CPU path the oracle runs): per-thread chains in fp64, the few partials per block / per launch then in fp32 trees
+  double s1x = 0., s1y = 0., s1z = 0., s1w = 0., s2x = 0., s2y = 0., s2z = 0., s2w = 0.;
   for (long long g = g0 + ph; g < g1; g += PH) {
     const float4 d = grad[g * C4 + q];
     const float4 o = out[g * C4 + q];                // the pooled relu(bn(y)): > 0 <=> the ReLU passed
@@ -133,10 +135,12 @@ __global__ __launch_bounds__(256) void pool_bn_reduce_kernel(long long G, int ns
     const float yz = base[(size_t)a.z * C + 2], yw = base[(size_t)a.w * C + 3];
     const float tx = o.x > 0.f ? d.x : 0.f, ty = o.y > 0.f ? d.y : 0.f;
     const float tz = o.z > 0.f ? d.z : 0.f, tw = o.w > 0.f ? d.w : 0.f;
-    s1.x += tx, s1.y += ty, s1.z += tz, s1.w += tw;
-    s2.x += tx * ((yx - mu.x) * is.x), s2.y += ty * ((yy - mu.y) * is.y);
-    s2.z += tz * ((yz - mu.z) * is.z), s2.w += tw * ((yw - mu.w) * is.w);
+    s1x += tx, s1y += ty, s1z += tz, s1w += tw;
+    s2x += tx * ((yx - mu.x) * is.x), s2y += ty * ((yy - mu.y) * is.y);
+    s2z += tz * ((yz - mu.z) * is.z), s2w += tw * ((yw - mu.w) * is.w);
   }
+  float4 s1 = make_float4((float)s1x, (float)s1y, (float)s1z, (float)s1w);
+  float4 s2 = make_float4((float)s2x, (float)s2y, (float)s2z, (float)s2w);
   pb_red[(ph * 2 + 0) * C4 + q] = s1;
   pb_red[(ph * 2 + 1) * C4 + q] = s2;
   __syncthreads();
@@ -156,9 +160,9 @@ __global__ __launch_bounds__(256) void pool_bn_finish_kernel(int P, int n, const
                                                              float* __restrict__ S) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float t = 0.f;
+  double t = 0.;
   for (int p = 0; p < P; ++p) t += part[(size_t)p * n + i];
-  S[i] = t;
+  S[i] = (float)t;
 }
 
 __global__ __launch_bounds__(256) void pool_bn_apply_kernel(long long G, int ns, int C4, float inv_rows,

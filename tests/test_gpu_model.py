@@ -387,14 +387,16 @@ def test_cfg2_mid_batch_gradients_equal_the_oracle():
     assert len(seen) == 3 and all(a.shape == b.shape for a, b in zip(seen, want))
     for got, ref, name in ((m1, o1, 'coarse'), (m2, o2, 'fine')):
         assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item()), (name, got.item(), ref.item())
-    worst = (0.0, '')
+    worst, rels = (0.0, ''), []
     for (n, p), (_, q) in zip(orc.named_parameters(), mine.named_parameters()):
         if p.grad is None:
             continue
         rel = ((q.grad.cpu().double() - p.grad.double()).norm() / p.grad.double().norm().clamp_min(1e-30)).item()
         worst = max(worst, (rel, n))
+        rels.append((rel, n))
+    print('cfg2 B=32: worst gradient tensors', sorted(rels, reverse=True)[:5])
+    for rel, n in rels:
         assert rel <= 5e-3, (n, rel)
-    print('cfg2 B=32: worst gradient tensor', worst)
 
 
 def test_cfg5_shape_runs():
