@@ -46,46 +46,21 @@
 //     B, group-list row gather, fused column sums of A = the bias gradient).
 #include <type_traits>
 #include "common.h"
+#include "nt_args.h"
+
+namespace pdae {
+int gemm_arith_rows();                                   // rows_gemm.hip: PDAE_GEMM_BF16X3 unless the fp32-input kernels were asked for
+namespace rows3 {
+bool conv3_takes(const NtArgs& a, int pro, int epi);    // rows3_gemm.hip: the same contracts on exact-split bf16
+void launch_conv3(NtArgs& a, int pro, int epi, hipStream_t s);
+}  // namespace rows3
+}  // namespace pdae
 
 namespace pdae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBK = 32, GLD = GBK + 4;
-
-enum { PRO_NONE = 0, PRO_BNRELU = 1 };
-enum {
-  EPI_BIAS = 0,
-  EPI_BIAS_RELU = 1,
-  EPI_BIAS_GELU = 2,
-  EPI_GROUPBIAS_STATS = 3,
-  EPI_GROUPMAX = 4,
-  EPI_STORE_GROUPMAX = 5,
-  EPI_STATS = 6,           // C = acc (+ bias); per-column sum / sum of squares like EPI_GROUPBIAS_STATS
-  EPI_GROUP_SCATTER = 7    // C[c_groups[m/32]*32 + m%32] = acc + gbias[m/32] (gbias nullable): whole 32-row groups
-                           // of a compact product land at listed groups of a larger matrix
-};
-
-struct NtArgs {
-  int M, N, K;
-  const float* A;
-  int lda;
-  const float* B;
-  int ldb;
-  float* C;
-  int ldc;
-  const float* bias;       // [N] or null
-  const float* pro_scale;  // [K]  PRO_BNRELU
-  const float* pro_shift;  // [K]
-  const float* gbias;      // [M/32][N]  EPI_GROUPBIAS_STATS
-  float* stats;            // [8][2][N]  per-XCD-slot partial sum / sumsq
-  float* stats_det;        // deterministic mode: [tile rows][2][N] plain-store partials (else null)
-  float* gmax;             // [M/32][N]  EPI_*GROUPMAX
-  unsigned char* garg;     // [M/32][N]
-  const int* a_groups;     // nullable: row m of A is source row a_groups[m/32]*32 + m%32
-  const int* c_groups;     // EPI_GROUP_SCATTER: destination group of tile-row group m/32
-  int tiles_n, tiles, tile_rows;
-};
 
 __device__ __forceinline__ float act_relu(float v) { return v > 0.f ? v : 0.f; }
 __device__ __forceinline__ float act_gelu(float v) {
@@ -607,7 +582,15 @@ static void launch_nt_cfg(NtArgs& a, hipStream_t s) {
 // 256x256 tiles when they fill the chip (>= 3/4 of the 256 CUs busy in the last
 // wave of blocks is not worth modelling: big problems only), else 128x128.
 template <int PRO, int EPI>
+static bool launch_conv3_if(NtArgs& a, hipStream_t s) {
+  if (gemm_arith_rows() != PDAE_GEMM_BF16X3 || !rows3::conv3_takes(a, PRO, EPI)) return false;
+  rows3::launch_conv3(a, PRO, EPI, s);
+  return true;
+}
+
+template <int PRO, int EPI>
 static int launch_nt(NtArgs& a, hipStream_t s) {
+  if (launch_conv3_if<PRO, EPI>(a, s)) return check_launch("conv3");
   const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   if (big_tiles >= 512 && a.N % 256 != 0 && a.N % 384 == 0) launch_nt_cfg<128, 384, PRO, EPI>(a, s);
   else if (big_tiles >= 512) launch_nt_cfg<256, 256, PRO, EPI>(a, s);
@@ -772,7 +755,8 @@ extern "C" int pdae_conv_stats(int M, int N, int K, const float* X, const float*
   if (rc) return rc;
   // narrow outputs (the first set-abstraction level: 64 / 128 channels): the 128-wide tile
   const bool narrow = N <= 128;
-  if (scale) {
+  if (scale ? launch_conv3_if<PRO_BNRELU, EPI_STATS>(a, s) : launch_conv3_if<PRO_NONE, EPI_STATS>(a, s)) {
+  } else if (scale) {
     if (narrow) launch_nt_cfg<128, 128, PRO_BNRELU, EPI_STATS>(a, s);
     else launch_nt_cfg<256, 256, PRO_BNRELU, EPI_STATS>(a, s);
   } else {
@@ -855,6 +839,7 @@ extern "C" int pdae_group_gemm_scatter(int M, int N, int K, const float* X, cons
   NtArgs a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = ldy;
   a.gbias = gbias, a.a_groups = a_groups, a.c_groups = c_groups;
+  if (launch_conv3_if<PRO_NONE, EPI_GROUP_SCATTER>(a, as_stream(stream))) return check_launch("group_gemm_scatter");
   // (the 256-row tile from 32 k rows on: measured on the embedder's two calls)
   if (M >= 32768 && N % 256 == 0) {
     launch_nt_cfg<256, 256, PRO_NONE, EPI_GROUP_SCATTER>(a, as_stream(stream));

@@ -50,16 +50,15 @@ static void launch_rows3(Args& a, int cfg, int splits, int sb, hipStream_t s) {
 }
 
 void launch_gemm3(Args& a, int cfg, bool w_kn, int epi, int splits, int stream_blocks, hipStream_t s) {
-  using namespace rows;
   if (!w_kn) {
-    if (epi == EPI_STORE) launch_rows3<false, EPI_STORE>(a, cfg, splits, stream_blocks, s);
-    else if (epi == EPI_BIAS_RELU) launch_rows3<false, EPI_BIAS_RELU>(a, cfg, splits, 0, s);
-    else if (epi == EPI_MUL_POS) launch_rows3<false, EPI_MUL_POS>(a, cfg, splits, 0, s);
-    else launch_rows3<false, EPI_BIAS_GELU2>(a, cfg, splits, 0, s);
+    if (epi == rows::EPI_STORE) launch_rows3<false, rows::EPI_STORE>(a, cfg, splits, stream_blocks, s);
+    else if (epi == rows::EPI_BIAS_RELU) launch_rows3<false, rows::EPI_BIAS_RELU>(a, cfg, splits, 0, s);
+    else if (epi == rows::EPI_MUL_POS) launch_rows3<false, rows::EPI_MUL_POS>(a, cfg, splits, 0, s);
+    else launch_rows3<false, rows::EPI_BIAS_GELU2>(a, cfg, splits, 0, s);
   } else {
-    if (epi == EPI_STORE) launch_rows3<true, EPI_STORE>(a, cfg, splits, stream_blocks, s);
-    else if (epi == EPI_MUL_POS) launch_rows3<true, EPI_MUL_POS>(a, cfg, splits, 0, s);
-    else launch_rows3<true, EPI_MUL_GELUGRAD>(a, cfg, splits, 0, s);
+    if (epi == rows::EPI_STORE) launch_rows3<true, rows::EPI_STORE>(a, cfg, splits, stream_blocks, s);
+    else if (epi == rows::EPI_MUL_POS) launch_rows3<true, rows::EPI_MUL_POS>(a, cfg, splits, 0, s);
+    else launch_rows3<true, rows::EPI_MUL_GELUGRAD>(a, cfg, splits, 0, s);
   }
 }
 
@@ -86,6 +85,51 @@ void launch_wgrad3(const rows::WgradArgs& g, int tn, int pl, hipStream_t s) {
   (void)tn;                                             // (one tile width: 128)
   if (g.a_groups || g.b_groups || g.scale) wgrad3_launch<true>(g, pl, s);
   else wgrad3_launch<false>(g, pl, s);
+}
+
+template <int PRO, int EPI>
+static void conv3_launch(NtArgs& a, hipStream_t s) {
+  a.tile_rows = (a.M + 127) / 128;
+  a.tiles_n = (a.N + 127) / 128;
+  a.tiles = a.tile_rows * a.tiles_n;
+  const size_t lds = (size_t)2 * 3 * 256 * 80;
+  auto k = conv3_kernel<PRO, EPI>;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(k, dim3(8 * ((a.tiles + 7) / 8)), dim3(512), lds, s, a);
+}
+
+bool conv3_takes(const NtArgs& a, int pro, int epi) {
+  (void)pro;
+  if (a.K % 32 != 0 || a.K < 32 || a.M <= 0) return false;
+  const bool group_epi = epi == EPI_GROUPBIAS_STATS || epi == EPI_GROUPMAX || epi == EPI_STORE_GROUPMAX || epi == EPI_GROUP_SCATTER;
+  if ((group_epi || a.a_groups) && a.M % 32 != 0) return false;
+  return epi == EPI_BIAS || epi == EPI_STATS || group_epi;
+}
+
+void launch_conv3(NtArgs& a, int pro, int epi, hipStream_t s) {
+  if (pro == PRO_NONE) {
+    switch (epi) {
+      case EPI_BIAS: conv3_launch<PRO_NONE, EPI_BIAS>(a, s); break;
+      case EPI_GROUPBIAS_STATS: conv3_launch<PRO_NONE, EPI_GROUPBIAS_STATS>(a, s); break;
+      case EPI_STATS: conv3_launch<PRO_NONE, EPI_STATS>(a, s); break;
+      case EPI_STORE_GROUPMAX: conv3_launch<PRO_NONE, EPI_STORE_GROUPMAX>(a, s); break;
+      case EPI_GROUPMAX: conv3_launch<PRO_NONE, EPI_GROUPMAX>(a, s); break;
+      default: conv3_launch<PRO_NONE, EPI_GROUP_SCATTER>(a, s); break;
+    }
+  } else {
+    switch (epi) {
+      case EPI_BIAS: conv3_launch<PRO_BNRELU, EPI_BIAS>(a, s); break;
+      case EPI_STATS: conv3_launch<PRO_BNRELU, EPI_STATS>(a, s); break;
+      case EPI_STORE_GROUPMAX: conv3_launch<PRO_BNRELU, EPI_STORE_GROUPMAX>(a, s); break;
+      case EPI_GROUPMAX: conv3_launch<PRO_BNRELU, EPI_GROUPMAX>(a, s); break;
+      case EPI_GROUPBIAS_STATS: conv3_launch<PRO_BNRELU, EPI_GROUPBIAS_STATS>(a, s); break;
+      default: conv3_launch<PRO_BNRELU, EPI_GROUP_SCATTER>(a, s); break;
+    }
+  }
 }
 
 }  // namespace rows3

@@ -19,6 +19,7 @@
 #pragma once
 #include <type_traits>
 
+#include "nt_args.h"
 #include "rows_common.h"
 
 namespace pdae {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
       constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
       const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
-      if (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+      if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
       else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
     };
     constexpr int S = 6 * G * KS;                             // slots (MFMAs) of a tile
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
       constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
       constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
       const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
-      if (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+      if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
       else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
     };
     constexpr int S = 12 * G, NR = (NF + 2) / 3, SB = S - NR, NC = 16, SC = SB - 1;
@@ -565,6 +566,232 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
           const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           slot[row * TN + (wn * TJ + j) * 32 + r] = hi[i][j][e] + lo[i][j][e];
         }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The fused NT GEMMs of the patch embedder and of the set-abstraction MLPs (gemm.hip gemm_nt_kernel's contracts: NtArgs,
+// PRO_BNRELU producer with optional 32-row group gather, the group-wise epilogues) on the exact-split arithmetic and
+// on gemm3_kernel's pipeline: C[M,N] = epi(pro(A[M,K]) . B[N,K]^T), K % 32 == 0.  Block tile 128 x 128, eight waves
+// of 32 x 64: a wave's 32 rows are ONE group of a point cloud (one 32-row MFMA tile), so the group bias is the
+// accumulators' start value, the group max is a max over a lane's 16 registers and its partner lane (lane ^ 32), and
+// the BatchNorm column statistics meet across the four waves of a column in LDS.
+//   PRO_BNRELU            a := relu(a * scale[k] + shift[k]) on the staged A octet right before it is split
+//   EPI_BIAS              C = acc + bias
+//   EPI_GROUPBIAS_STATS   C = acc + gbias[m / 32]; per-column sum / sum of squares -> stats (atomics per XCD slot, or
+//                         plain per-tile-row partials in deterministic mode)
+//   EPI_STATS             C = acc (+ bias) with the same statistics
+//   EPI_STORE_GROUPMAX    C = acc + bias stored; gmax / garg = max over each group's rows and the first row attaining it
+//   EPI_GROUPMAX          the same without the store
+//   EPI_GROUP_SCATTER     C[c_groups[m / 32] * 32 + m % 32] = acc + gbias[m / 32] (gbias nullable)
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
+  constexpr int TI = 1, TJ = 2, WM = 4, WN = 2, BM = 128, BN = 128, ROWB = 80, BKT = 32;
+  constexpr int PLANE = (BM + BN) * ROWB, BUF = 3 * PLANE;
+  constexpr int G = TI * TJ;
+  constexpr bool DUAL = true;
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+  const int chunk = (p.tiles + 7) >> 3;
+  {
+    const int slot = blockIdx.x >> 3;
+    if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
+  }
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int KT = p.K / BKT;
+  // this thread's octet of A and of B (one each: 128 rows x 4 octets = 512): conflict-free LDS store map of gemm3_kernel
+  const int orow = ((tid >> 5) << 3) + (((tid >> 2) & 1) << 2) + ((tid >> 3) & 3), ocol = tid & 3;
+  int am = min(m0 + orow, M - 1);
+  if (p.a_groups) am = p.a_groups[am >> 5] * 32 + (am & 31);       // whole 32-row groups gathered
+  const unsigned aoff = ((unsigned)am * (unsigned)p.lda + ocol * 8) * 4u;
+  const unsigned boff = ((unsigned)min(n0 + orow, N - 1) * (unsigned)p.ldb + ocol * 8) * 4u;
+  const int alds = orow * ROWB + ocol * 16, blds = (BM + orow) * ROWB + ocol * 16;
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Bb = reinterpret_cast<const char*>(p.B);
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+
+  float ra[2][8], rb[2][8], rs[2][8], rh[2][8];         // staged A / B octets; the producer's scale / shift of the A octet's k
+  u32x4 pka[3], pkb[3];
+  auto gload = [&](auto set_c, int kt) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    const size_t kb = (size_t)min(kt, KT - 1) * BKT * 4;
+    const float4 a0 = *reinterpret_cast<const float4*>(Ab + kb + aoff);
+    const float4 a1 = *reinterpret_cast<const float4*>(Ab + kb + aoff + 16);
+    const float4 b0 = *reinterpret_cast<const float4*>(Bb + kb + boff);
+    const float4 b1 = *reinterpret_cast<const float4*>(Bb + kb + boff + 16);
+    ra[set][0] = a0.x, ra[set][1] = a0.y, ra[set][2] = a0.z, ra[set][3] = a0.w;
+    ra[set][4] = a1.x, ra[set][5] = a1.y, ra[set][6] = a1.z, ra[set][7] = a1.w;
+    rb[set][0] = b0.x, rb[set][1] = b0.y, rb[set][2] = b0.z, rb[set][3] = b0.w;
+    rb[set][4] = b1.x, rb[set][5] = b1.y, rb[set][6] = b1.z, rb[set][7] = b1.w;
+    if constexpr (PRO == PRO_BNRELU) {
+      const char* sc = reinterpret_cast<const char*>(p.pro_scale) + kb + ocol * 32;
+      const char* sh = reinterpret_cast<const char*>(p.pro_shift) + kb + ocol * 32;
+      const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 16);
+      const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 16);
+      rs[set][0] = s0.x, rs[set][1] = s0.y, rs[set][2] = s0.z, rs[set][3] = s0.w;
+      rs[set][4] = s1.x, rs[set][5] = s1.y, rs[set][6] = s1.z, rs[set][7] = s1.w;
+      rh[set][0] = h0.x, rh[set][1] = h0.y, rh[set][2] = h0.z, rh[set][3] = h0.w;
+      rh[set][4] = h1.x, rh[set][5] = h1.y, rh[set][6] = h1.z, rh[set][7] = h1.w;
+    }
+  };
+  auto side_chunk = [&](auto c_c, auto set_c, int buf) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8, set = decltype(set_c)::value;
+    auto run = [&](float (&v)[8], u32x4 (&pk)[3], char* d) __attribute__((always_inline)) {
+      split_chunk<ch>(v, pk);
+      if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[0];
+      if (ch == 7) {
+        *reinterpret_cast<u32x4*>(d + PLANE) = pk[1];
+        *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[2];
+      }
+    };
+    if constexpr (o == 0) {
+      if constexpr (PRO == PRO_BNRELU && ch == 0) {        // the previous layer's BatchNorm + ReLU, never stored
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[set][j] = fmaxf(ra[set][j] * rs[set][j] + rh[set][j], 0.f);
+      }
+      run(ra[set], pka, lds3 + buf * BUF + alds);
+    } else {
+      run(rb[set], pkb, lds3 + buf * BUF + blds);
+    }
+  };
+  f32x16 hi[TI][TJ], lo[TI][TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    float init = 0.f;
+    if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) {
+      const int gr = m0 + wm * 32, gc = n0 + (wn * TJ + j) * 32 + r;
+      if (gr < M && gc < N && (EPI == EPI_GROUPBIAS_STATS || p.gbias)) init = p.gbias[(size_t)(gr >> 5) * N + gc];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hi[0][j][e] = init, lo[0][j][e] = 0.f;
+  }
+  bf16x8 fa[2][TI][3], fb[2][TJ][3];
+  const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (BM + wn * TJ * 32 + r) * ROWB + 16 * h;
+  constexpr int NF = 3 * (TI + TJ);
+  auto frag_one = [&](auto f_c, auto st_c, int buf, int s16) __attribute__((always_inline)) {
+    constexpr int f = decltype(f_c)::value, st = decltype(st_c)::value;
+    constexpr int FPL[6] = {2, 0, 0, 2, 1, 1};
+    constexpr bool isa = f < 6 ? (f % 2 == 0) : (f - 6 < 3 * (TI - 1));
+    constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
+    constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
+    const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
+    if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+    else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
+  };
+  constexpr int S = 12 * G, NR = (NF + 2) / 3, SB = S - NR, NC = 16, SC = SB - 1;
+  auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
+    constexpr int P2 = decltype(par_c)::value;
+    using SetN = std::integral_constant<int, P2 ^ 1>;
+    static_for<S>([&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr int step = s / (6 * G), gi = (s % (6 * G)) / 6, q = s % 6;
+      mfma_one<DUAL, q>(fa[step][gi / TJ], fb[step][gi % TJ], hi[gi / TJ][gi % TJ], lo[gi / TJ][gi % TJ]);
+      static_for<NF>([&](auto f_c) {
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f * (6 * G) / NF == s) frag_one(f_c, C1{}, P2, 1);
+      });
+      static_for<NC>([&](auto c_c) {
+        constexpr int c = decltype(c_c)::value;
+        if constexpr (c * SC / NC == s) side_chunk(c_c, SetN{}, P2 ^ 1);
+      });
+      if constexpr (s == (NC - 1) * SC / NC) gload(SetN{}, kt + 3);
+      if constexpr (s == SB - 1) __syncthreads();
+      if constexpr (s >= SB) {
+        static_for<NF>([&](auto f_c) {
+          constexpr int f = decltype(f_c)::value;
+          if constexpr (f / 3 == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  gload(C0{}, 0);
+  gload(C1{}, 1);
+  static_for<NC>([&](auto c_c) { side_chunk(c_c, C0{}, 0); });
+  gload(C0{}, 2);
+  __syncthreads();
+  static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
+  for (int kt = 0; kt < KT; kt += 2) {
+    ktile(C0{}, kt);
+    if (kt + 1 < KT) ktile(C1{}, kt + 1);
+  }
+
+  // ---- epilogue: this wave's 32 rows are one group; a lane holds 16 rows of one column, its partner (lane ^ 32) the rest
+  float csum[TJ], csq[TJ];
+  const int rbase = m0 + wm * 32;
+  const bool rows_in = rbase < M;                       // (M % 32 == 0 for the group epilogues: a group is inside or outside)
+  const unsigned ldc = (unsigned)p.ldc;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    csum[j] = 0.f, csq[j] = 0.f;
+    const int col = n0 + (wn * TJ + j) * 32 + r;
+    const bool colok = col < N;
+    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+    const float add = (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) ? 0.f : bv;
+    float vmax = -__builtin_huge_valf();
+    int amax = 0;
+    float* cbase = nullptr;
+    if (EPI != EPI_GROUPMAX) {
+      int crow = rbase;
+      if (EPI == EPI_GROUP_SCATTER && rows_in) crow = p.c_groups[rbase >> 5] * 32;
+      cbase = p.C + (size_t)(crow + 4 * h) * ldc + col;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const bool in = colok && rbase + lr < M;
+      const float v = (hi[0][j][e] + lo[0][j][e]) + add;
+      if ((EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) && rbase + lr < M) {
+        csum[j] += v;
+        csq[j] += v * v;
+      }
+      if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+        if (v > vmax) vmax = v, amax = lr;              // e ascending => lr ascending within this half
+      }
+      if (EPI != EPI_GROUPMAX && in) cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+    }
+    if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+      const float ov = __shfl_xor(vmax, 32, kWave);
+      const int oa = __shfl_xor(amax, 32, kWave);
+      if ((ov > vmax) || (ov == vmax && oa < amax)) vmax = ov, amax = oa;
+      if (h == 0 && colok && rows_in) {
+        p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
+        p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
+      }
+    }
+  }
+  if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) {
+    // per-tile column sums: one LDS slot per row of waves, added in wave order, then one atomic per column into the
+    // partial buffer of this block's XCD slot -- or, in deterministic mode, a plain store into row (tile row)
+    float* red = reinterpret_cast<float*>(lds3);        // [WM][2][BN]; the tile buffers are free now
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const float sum = csum[j] + __shfl_xor(csum[j], 32, kWave);
+      const float sq = csq[j] + __shfl_xor(csq[j], 32, kWave);
+      if (h == 0) {
+        red[(wm * 2 + 0) * BN + (wn * TJ + j) * 32 + r] = sum;
+        red[(wm * 2 + 1) * BN + (wn * TJ + j) * 32 + r] = sq;
+      }
+    }
+    __syncthreads();
+    float* dst = p.stats_det ? p.stats_det + (size_t)(m0 / BM) * 2 * N : p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
+    if (tid < 2 * BN) {
+      const int half = tid / BN, cc = tid - half * BN;
+      if (n0 + cc < N) {
+        float t = red[half * BN + cc];
+#pragma unroll
+        for (int k = 1; k < WM; ++k) t += red[(k * 2 + half) * BN + cc];
+        if (p.stats_det) dst[half * N + n0 + cc] = t;
+        else atomicAdd(dst + half * N + n0 + cc, t);
+      }
+    }
   }
 }
 

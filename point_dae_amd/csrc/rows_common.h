@@ -193,4 +193,6 @@ size_t lds_bytes3(const Cfg3& c);
 void launch_gemm3(rows::Args& a, int cfg, bool w_kn, int epi, int splits, int stream_blocks, hipStream_t s);
 void launch_wgrad3(const rows::WgradArgs& g, int tn, int pl, hipStream_t s);
 }  // namespace rows3
+// the arithmetic in force for the forward / data-gradient half of the family (rows_gemm.hip)
+int gemm_arith_rows();
 }  // namespace pdae

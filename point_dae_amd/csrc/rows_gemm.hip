@@ -748,6 +748,10 @@ static int arith_of(bool wgrad) {
   return gemm_arith();
 }
 
+namespace pdae {
+int gemm_arith_rows() { return arith_of(false); }
+}  // namespace pdae
+
 // shapes the exact-split kernels take: the reduction in whole 32-deep tiles (every layer of the models but the K = 3
 // / K = 4 ones), 32-bit byte offsets as the fp32 kernels
 static bool gemm3_takes(int N, int K, bool bkn) { return K % 32 == 0 && K >= 32 && (!bkn || N % 4 == 0); }
