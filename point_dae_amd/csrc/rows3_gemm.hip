@@ -92,14 +92,17 @@ static void conv3_launch(NtArgs& a, hipStream_t s) {
   a.tile_rows = (a.M + 127) / 128;
   a.tiles_n = (a.N + 127) / 128;
   a.tiles = a.tile_rows * a.tiles_n;
-  const size_t lds = (size_t)2 * 3 * 256 * 80;
+  const size_t lds = (size_t)2 * 3 * 256 * 80 + 4 * 2 * 128 * sizeof(float);
   auto k = conv3_kernel<PRO, EPI>;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once = true;
   }
-  hipLaunchKernelGGL(k, dim3(8 * ((a.tiles + 7) / 8)), dim3(512), lds, s, a);
+  // persistent blocks (one residency: 32 CUs per XCD) when the stream of k-tiles keeps its parity across output tiles
+  const int chunk = (a.tiles + 7) / 8, kt = a.K / 32;
+  const int nslots = (kt % 2 == 0 && kt >= 4 && chunk > 32) ? 32 : chunk;
+  hipLaunchKernelGGL(k, dim3(8 * nslots), dim3(512), lds, s, a);
 }
 
 bool conv3_takes(const NtArgs& a, int pro, int epi) {

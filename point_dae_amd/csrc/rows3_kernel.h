@@ -591,26 +591,41 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
   constexpr int PLANE = (BM + BN) * ROWB, BUF = 3 * PLANE;
   constexpr int G = TI * TJ;
   constexpr bool DUAL = true;
-  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  extern __shared__ __attribute__((aligned(16))) char lds3[];   // [2][BUF] tile buffers, then [WM][2][BN] floats of statistics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
+  // Persistent blocks (as gemm_nt_kernel): block (xcd, slot) walks tiles slot, slot + nslots, ... of its XCD's chunk and
+  // the k-tiles of consecutive output tiles form ONE stream through the pipeline -- the loads run three positions
+  // ahead across the tile boundary, so a boundary costs the epilogue only (no exposed first loads: ~3 of the ~6 us a
+  // tile pays on top of its k-loop).  The host launches one residency of blocks when K / 32 is even and >= 4 (the
+  // stream keeps its buffer / register-set parity across tiles), else one block per tile.
   const int chunk = (p.tiles + 7) >> 3;
-  {
-    const int slot = blockIdx.x >> 3;
-    if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
-  }
-  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
+  int slot = blockIdx.x >> 3;
+  auto tile_of = [&](int sl) {
+    const int t = xcd * chunk + sl;
+    return (sl < chunk && t < p.tiles) ? t : -1;
+  };
+  int tile = tile_of(slot);
+  if (tile < 0) return;
   const int KT = p.K / BKT;
   // this thread's octet of A and of B (one each: 128 rows x 4 octets = 512): conflict-free LDS store map of gemm3_kernel
   const int orow = ((tid >> 5) << 3) + (((tid >> 2) & 1) << 2) + ((tid >> 3) & 3), ocol = tid & 3;
-  int am = min(m0 + orow, M - 1);
-  if (p.a_groups) am = p.a_groups[am >> 5] * 32 + (am & 31);       // whole 32-row groups gathered
-  const unsigned aoff = ((unsigned)am * (unsigned)p.lda + ocol * 8) * 4u;
-  const unsigned boff = ((unsigned)min(n0 + orow, N - 1) * (unsigned)p.ldb + ocol * 8) * 4u;
   const int alds = orow * ROWB + ocol * 16, blds = (BM + orow) * ROWB + ocol * 16;
+  unsigned aoff[2], boff[2];                           // [0] the tile being multiplied, [1] the next one of this block
+  auto offsets_of = [&](int t, unsigned& ao, unsigned& bo) __attribute__((always_inline)) {
+    const int tm0 = (t / p.tiles_n) * BM, tn0 = (t % p.tiles_n) * BN;
+    int am = min(tm0 + orow, M - 1);
+    if (p.a_groups) am = p.a_groups[am >> 5] * 32 + (am & 31);     // whole 32-row groups gathered
+    ao = ((unsigned)am * (unsigned)p.lda + ocol * 8) * 4u;
+    bo = ((unsigned)min(tn0 + orow, N - 1) * (unsigned)p.ldb + ocol * 8) * 4u;
+  };
+  offsets_of(tile, aoff[0], boff[0]);
+  int next = tile_of(slot + nslots);
+  aoff[1] = aoff[0], boff[1] = boff[0];
+  if (next >= 0) offsets_of(next, aoff[1], boff[1]);
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
   using C0 = std::integral_constant<int, 0>;
@@ -618,13 +633,17 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
 
   float ra[2][8], rb[2][8], rs[2][8], rh[2][8];         // staged A / B octets; the producer's scale / shift of the A octet's k
   u32x4 pka[3], pkb[3];
-  auto gload = [&](auto set_c, int kt) __attribute__((always_inline)) {
+  // position `pos` of the stream: k-tile pos of this tile, or k-tile pos - KT of the next one (past the last tile: the
+  // last k-tile again, split into the buffer nobody reads)
+  auto gload = [&](auto set_c, int pos) __attribute__((always_inline)) {
     constexpr int set = decltype(set_c)::value;
-    const size_t kb = (size_t)min(kt, KT - 1) * BKT * 4;
-    const float4 a0 = *reinterpret_cast<const float4*>(Ab + kb + aoff);
-    const float4 a1 = *reinterpret_cast<const float4*>(Ab + kb + aoff + 16);
-    const float4 b0 = *reinterpret_cast<const float4*>(Bb + kb + boff);
-    const float4 b1 = *reinterpret_cast<const float4*>(Bb + kb + boff + 16);
+    const bool nx = pos >= KT && next >= 0;
+    const size_t kb = (size_t)(nx ? pos - KT : min(pos, KT - 1)) * BKT * 4;
+    const unsigned ao = nx ? aoff[1] : aoff[0], bo = nx ? boff[1] : boff[0];
+    const float4 a0 = *reinterpret_cast<const float4*>(Ab + kb + ao);
+    const float4 a1 = *reinterpret_cast<const float4*>(Ab + kb + ao + 16);
+    const float4 b0 = *reinterpret_cast<const float4*>(Bb + kb + bo);
+    const float4 b1 = *reinterpret_cast<const float4*>(Bb + kb + bo + 16);
     ra[set][0] = a0.x, ra[set][1] = a0.y, ra[set][2] = a0.z, ra[set][3] = a0.w;
     ra[set][4] = a1.x, ra[set][5] = a1.y, ra[set][6] = a1.z, ra[set][7] = a1.w;
     rb[set][0] = b0.x, rb[set][1] = b0.y, rb[set][2] = b0.z, rb[set][3] = b0.w;
@@ -661,16 +680,6 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
     }
   };
   f32x16 hi[TI][TJ], lo[TI][TJ];
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    float init = 0.f;
-    if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) {
-      const int gr = m0 + wm * 32, gc = n0 + (wn * TJ + j) * 32 + r;
-      if (gr < M && gc < N && (EPI == EPI_GROUPBIAS_STATS || p.gbias)) init = p.gbias[(size_t)(gr >> 5) * N + gc];
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) hi[0][j][e] = init, lo[0][j][e] = 0.f;
-  }
   bf16x8 fa[2][TI][3], fb[2][TJ][3];
   const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (BM + wn * TJ * 32 + r) * ROWB + 16 * h;
   constexpr int NF = 3 * (TI + TJ);
@@ -717,81 +726,101 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
   gload(C0{}, 2);
   __syncthreads();
   static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
-  for (int kt = 0; kt < KT; kt += 2) {
-    ktile(C0{}, kt);
-    if (kt + 1 < KT) ktile(C1{}, kt + 1);
-  }
 
-  // ---- epilogue: this wave's 32 rows are one group; a lane holds 16 rows of one column, its partner (lane ^ 32) the rest
-  float csum[TJ], csq[TJ];
-  const int rbase = m0 + wm * 32;
-  const bool rows_in = rbase < M;                       // (M % 32 == 0 for the group epilogues: a group is inside or outside)
-  const unsigned ldc = (unsigned)p.ldc;
-#pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    csum[j] = 0.f, csq[j] = 0.f;
-    const int col = n0 + (wn * TJ + j) * 32 + r;
-    const bool colok = col < N;
-    const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
-    const float add = (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) ? 0.f : bv;
-    float vmax = -__builtin_huge_valf();
-    int amax = 0;
-    float* cbase = nullptr;
-    if (EPI != EPI_GROUPMAX) {
-      int crow = rbase;
-      if (EPI == EPI_GROUP_SCATTER && rows_in) crow = p.c_groups[rbase >> 5] * 32;
-      cbase = p.C + (size_t)(crow + 4 * h) * ldc + col;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const bool in = colok && rbase + lr < M;
-      const float v = (hi[0][j][e] + lo[0][j][e]) + add;
-      if ((EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) && rbase + lr < M) {
-        csum[j] += v;
-        csq[j] += v * v;
-      }
-      if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
-        if (v > vmax) vmax = v, amax = lr;              // e ascending => lr ascending within this half
-      }
-      if (EPI != EPI_GROUPMAX && in) cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
-    }
-    if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
-      const float ov = __shfl_xor(vmax, 32, kWave);
-      const int oa = __shfl_xor(amax, 32, kWave);
-      if ((ov > vmax) || (ov == vmax && oa < amax)) vmax = ov, amax = oa;
-      if (h == 0 && colok && rows_in) {
-        p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
-        p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
-      }
-    }
-  }
-  if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) {
-    // per-tile column sums: one LDS slot per row of waves, added in wave order, then one atomic per column into the
-    // partial buffer of this block's XCD slot -- or, in deterministic mode, a plain store into row (tile row)
-    float* red = reinterpret_cast<float*>(lds3);        // [WM][2][BN]; the tile buffers are free now
-    __syncthreads();
+  for (;;) {
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-      const float sum = csum[j] + __shfl_xor(csum[j], 32, kWave);
-      const float sq = csq[j] + __shfl_xor(csq[j], 32, kWave);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + (wn * TJ + j) * 32 + r] = sum;
-        red[(wm * 2 + 1) * BN + (wn * TJ + j) * 32 + r] = sq;
+      float init = 0.f;
+      if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) {
+        const int gr = m0 + wm * 32, gc = n0 + (wn * TJ + j) * 32 + r;
+        if (gr < M && gc < N && (EPI == EPI_GROUPBIAS_STATS || p.gbias)) init = p.gbias[(size_t)(gr >> 5) * N + gc];
       }
-    }
-    __syncthreads();
-    float* dst = p.stats_det ? p.stats_det + (size_t)(m0 / BM) * 2 * N : p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
-    if (tid < 2 * BN) {
-      const int half = tid / BN, cc = tid - half * BN;
-      if (n0 + cc < N) {
-        float t = red[half * BN + cc];
 #pragma unroll
-        for (int k = 1; k < WM; ++k) t += red[(k * 2 + half) * BN + cc];
-        if (p.stats_det) dst[half * N + n0 + cc] = t;
-        else atomicAdd(dst + half * N + n0 + cc, t);
+      for (int e = 0; e < 16; ++e) hi[0][j][e] = init, lo[0][j][e] = 0.f;
+    }
+    for (int kt = 0; kt < KT; kt += 2) {
+      ktile(C0{}, kt);
+      if (kt + 1 < KT) ktile(C1{}, kt + 1);
+    }
+    // ---- epilogue: this wave's 32 rows are one group; a lane holds 16 rows of one column, its partner (lane ^ 32) the
+    // rest.  (LDS already holds the next tile's first k-tile, its fragments are in registers, its loads are in flight.)
+    float csum[TJ], csq[TJ];
+    const int rbase = m0 + wm * 32;
+    const bool rows_in = rbase < M;                     // (M % 32 == 0 for the group epilogues: a group is inside or outside)
+    const unsigned ldc = (unsigned)p.ldc;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      csum[j] = 0.f, csq[j] = 0.f;
+      const int col = n0 + (wn * TJ + j) * 32 + r;
+      const bool colok = col < N;
+      const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+      const float add = (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_GROUP_SCATTER) ? 0.f : bv;
+      float vmax = -__builtin_huge_valf();
+      int amax = 0;
+      float* cbase = nullptr;
+      if (EPI != EPI_GROUPMAX) {
+        int crow = rbase;
+        if (EPI == EPI_GROUP_SCATTER && rows_in) crow = p.c_groups[rbase >> 5] * 32;
+        cbase = p.C + (size_t)(crow + 4 * h) * ldc + col;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int lr = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const bool in = colok && rbase + lr < M;
+        const float v = (hi[0][j][e] + lo[0][j][e]) + add;
+        if ((EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) && rbase + lr < M) {
+          csum[j] += v;
+          csq[j] += v * v;
+        }
+        if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+          if (v > vmax) vmax = v, amax = lr;            // e ascending => lr ascending within this half
+        }
+        if (EPI != EPI_GROUPMAX && in) cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+      }
+      if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
+        const float ov = __shfl_xor(vmax, 32, kWave);
+        const int oa = __shfl_xor(amax, 32, kWave);
+        if ((ov > vmax) || (ov == vmax && oa < amax)) vmax = ov, amax = oa;
+        if (h == 0 && colok && rows_in) {
+          p.gmax[(size_t)(rbase >> 5) * N + col] = vmax;
+          p.garg[(size_t)(rbase >> 5) * N + col] = (unsigned char)amax;
+        }
       }
     }
+    if (EPI == EPI_GROUPBIAS_STATS || EPI == EPI_STATS) {
+      // per-tile column sums: one LDS slot per row of waves, added in wave order, then one atomic per column into the
+      // partial buffer of this block's XCD slot -- or, in deterministic mode, a plain store into row (tile row)
+      float* red = reinterpret_cast<float*>(lds3 + 2 * BUF);          // [WM][2][BN], behind the tile buffers
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float sum = csum[j] + __shfl_xor(csum[j], 32, kWave);
+        const float sq = csq[j] + __shfl_xor(csq[j], 32, kWave);
+        if (h == 0) {
+          red[(wm * 2 + 0) * BN + (wn * TJ + j) * 32 + r] = sum;
+          red[(wm * 2 + 1) * BN + (wn * TJ + j) * 32 + r] = sq;
+        }
+      }
+      __syncthreads();
+      float* dst = p.stats_det ? p.stats_det + (size_t)(m0 / BM) * 2 * N : p.stats + (size_t)(blockIdx.x & 7) * 2 * N;
+      if (tid < 2 * BN) {
+        const int half = tid / BN, cc = tid - half * BN;
+        if (n0 + cc < N) {
+          float t = red[half * BN + cc];
+#pragma unroll
+          for (int k = 1; k < WM; ++k) t += red[(k * 2 + half) * BN + cc];
+          if (p.stats_det) dst[half * N + n0 + cc] = t;
+          else atomicAdd(dst + half * N + n0 + cc, t);
+        }
+      }
+      __syncthreads();                                  // red is written again by the next tile's epilogue
+    }
+    if (next < 0) break;
+    slot += nslots;
+    tile = next;
+    aoff[0] = aoff[1], boff[0] = boff[1];
+    next = tile_of(slot + nslots);
+    if (next >= 0) offsets_of(next, aoff[1], boff[1]);
   }
 }
 
