@@ -73,8 +73,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// C[M,N] = epi(A[M,K] . op(B)), the contract of rows::rows_gemm_kernel (same Args, same epilogues, same split-K /
-// stream-K slab forms) for K % 32 == 0.  Block tile (32 TI WM) x (32 TJ WN), WM WN waves of TI x TJ MFMA tiles; an LDS
+// C[M,N] = epi(A[M,K] . op(B)), the contract of rows::rows_gemm_kernel (same Args, same epilogues, same split-K slab
+// form; its stream-K form is not built) for K % 32 == 0.  Block tile (32 TI WM) x (32 TJ WN), WM WN waves of TI x TJ MFMA tiles; an LDS
 // tile holds KS 16-deep steps of the reduction (KS = 2: 80-B rows; KS = 1: 48-B rows, half the LDS, so that TWO blocks
 // fit a CU and one block's first loads and epilogue run under the other's MFMAs).
 // Pipeline per LDS tile t (double-buffered, ONE barrier per tile), written as S = 6 KS TI TJ SLOTS of one MFMA each
@@ -91,7 +91,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Fragments live in two register sets (the stage of a 16-deep step alternates), register sets and fragment stages are
 // indexed statically: the tile loop is unrolled by two.  The loop is branch-free: past the end the last tile is loaded
 // / split / stored again (into the buffer nobody reads).
-template <int TI, int TJ, int WM, int WN, int KS, bool BKN, int EPI, bool DUAL, int ABL = 0>
+template <int TI, int TJ, int WM, int WN, int KS, bool BKN, int EPI, bool DUAL, int ABL = 0, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
@@ -108,66 +108,72 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
-  const int KTA = p.K / BK3;                                  // (work units stay 32 deep: the plan's unit)
-  const long long units = (long long)p.tiles * KTA;
-  long long u = 0, uend = 1;
-  int sb = 0;
-  if (p.stream_blocks) {
-    const int P = p.stream_blocks;
-    sb = (int)(blockIdx.x & 7) * (P >> 3) + (int)(blockIdx.x >> 3);
-    u = sb * units / P, uend = (sb + 1) * units / P;
-    if (u >= uend) return;
-  } else {
-    const int chunk = (p.tiles + 7) >> 3;
-    const int slot = blockIdx.x >> 3;
-    if (slot >= chunk || (int)(blockIdx.x & 7) * chunk + slot >= p.tiles) return;
-  }
+  // Persistent blocks: block (xcd, slot) walks tiles slot, slot + nslots, ... of its XCD's chunk (n fastest inside a chunk:
+  // the re-reads of an A row band hit that XCD's L2) and the LDS tiles of consecutive output tiles form ONE stream
+  // through the pipeline -- loads run three positions ahead across the tile boundary, so a boundary costs the epilogue
+  // only.  The host launches one residency of blocks when the reduction of a block is an even number >= 4 of LDS tiles
+  // (the stream then keeps its buffer / register-set parity across tiles), else one block per tile.  blockIdx.y = the
+  // split of the reduction (slabs the consumer adds).  (The fp32-input kernel's stream-K form is not built here.)
+  const int chunk = (p.tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
+  int slot = blockIdx.x >> 3;
+  auto tile_of = [&](int sl) {
+    const int t = xcd * chunk + sl;
+    return (sl < chunk && t < p.tiles) ? t : -1;
+  };
+  int tile = tile_of(slot);
+  if (tile < 0) return;
   // octet o of an operand tile -> (row, octet of the row): eight consecutive lanes hit eight different 16-B slots of
   // the 128-B window a ds_write_b128 group covers (80-B rows: two rows four apart; 48-B rows: four rows two apart)
   auto octet_row = [](int o) { return KS == 2 ? ((o >> 5) << 3) + (((o >> 2) & 1) << 2) + ((o >> 3) & 3)
                                               : ((o >> 4) << 3) + (((o >> 1) & 3) << 1) + ((o >> 3) & 1); };
   auto octet_col = [](int o) { return KS == 2 ? (o & 3) : (o & 1); };
-  for (;;) {
-    int tile, kbeg, kend, piece = 0;
-    bool tile_ends = false;
-    if (p.stream_blocks) {
-      tile = (int)(u / KTA);
-      const int k0 = (int)(u % KTA), k1 = (int)min((long long)KTA, k0 + (uend - u));
-      u += k1 - k0;
-      kbeg = k0 * BK3, kend = k1 * BK3;
-      tile_ends = k1 == KTA;
-      const long long uf = (long long)tile * KTA;
-      piece = sb - (int)(((uf + 1) * p.stream_blocks - 1) / units);
-    } else {
-      tile = (int)(blockIdx.x & 7) * ((p.tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
-      kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-      piece = blockIdx.y;
-    }
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-    const int KT = (kend - kbeg) / BKT;
-    // 32-bit byte offsets of this thread's staged pieces from the (uniform) operand bases; rows / columns past the
-    // matrix edge are clamped (their products are never stored)
-    unsigned aoff[OA], boff[OB];
-    int alds[OA], blds[OB];
+  const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk), piece = blockIdx.y;
+  const int KT = (kend - kbeg) / BKT;
+  // 32-bit byte offsets of this thread's staged pieces from the (uniform) operand bases, [0] for the tile being
+  // multiplied, [1] for the next one of this block; rows / columns past the matrix edge are clamped (their products
+  // are never stored)
+  unsigned aoff[2][OA], boff[2][OB];
+  int alds[OA], blds[OB];
+  auto offsets_of = [&](int t, unsigned (&ao)[OA], unsigned (&bo)[OB]) __attribute__((always_inline)) {
+    const int tm0 = (t / p.tiles_n) * BM, tn0 = (t % p.tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < OA; ++i) {
       const int o = (tid + i * NT) % (BM * OPR), row = octet_row(o), oc = octet_col(o);   // (past the tile: an earlier octet again)
-      aoff[i] = ((unsigned)min(m0 + row, M - 1) * (unsigned)p.lda + oc * 8) * 4u;
-      alds[i] = row * ROWB + oc * 16;
+      ao[i] = ((unsigned)min(tm0 + row, M - 1) * (unsigned)p.lda + oc * 8) * 4u;
     }
 #pragma unroll
     for (int i = 0; i < OB; ++i) {
       const int o = (tid + i * NT) % (BN * OPR);
       if (BKN) {
         const int kg = o / BN, col = o % BN;                  // patch: k = 8 kg .. 8 kg + 7 of column col
-        boff[i] = ((unsigned)(8 * kg) * (unsigned)p.ldb + (unsigned)min(n0 + col, N - 1)) * 4u;
-        blds[i] = (BM + col) * ROWB + kg * 16;
+        bo[i] = ((unsigned)(8 * kg) * (unsigned)p.ldb + (unsigned)min(tn0 + col, N - 1)) * 4u;
       } else {
         const int row = octet_row(o), oc = octet_col(o);
-        boff[i] = ((unsigned)min(n0 + row, N - 1) * (unsigned)p.ldb + oc * 8) * 4u;
-        blds[i] = (BM + row) * ROWB + oc * 16;
+        bo[i] = ((unsigned)min(tn0 + row, N - 1) * (unsigned)p.ldb + oc * 8) * 4u;
       }
     }
+  };
+#pragma unroll
+  for (int i = 0; i < OA; ++i) {
+    const int o = (tid + i * NT) % (BM * OPR);
+    alds[i] = octet_row(o) * ROWB + octet_col(o) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < OB; ++i) {
+    const int o = (tid + i * NT) % (BN * OPR);
+    blds[i] = BKN ? (BM + o % BN) * ROWB + (o / BN) * 16 : (BM + octet_row(o)) * ROWB + octet_col(o) * 16;
+  }
+  offsets_of(tile, aoff[0], boff[0]);
+  // PERS false (a launch of one tile per block: most of the Transformer blocks' GEMMs): no next tile, and none of its
+  // registers or address selects in the loop
+  int next = PERS ? tile_of(slot + nslots) : -1;
+#pragma unroll
+  for (int i = 0; i < OA; ++i) aoff[1][i] = aoff[0][i];
+#pragma unroll
+  for (int i = 0; i < OB; ++i) boff[1][i] = boff[0][i];
+  if (PERS && next >= 0) offsets_of(next, aoff[1], boff[1]);
+  {
     const char* Ab = reinterpret_cast<const char*>(p.A + (size_t)blockIdx.z * p.strideA) + (size_t)kbeg * 4;
     const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)blockIdx.z * p.strideB) +
                      (BKN ? (size_t)kbeg * p.ldb * 4 : (size_t)kbeg * 4);
@@ -176,31 +182,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
 
     float ra[2][OA][8], rb[2][OB][8];                         // two register sets of staged fp32
     u32x4 pka[OA][3], pkb[OB][3];
-    auto gload_a = [&](auto set_c, int kt) __attribute__((always_inline)) {
+    // position `pos` of the stream: LDS tile pos of this output tile, or pos - KT of the block's next one (past the last
+    // tile: the last LDS tile again, split into the buffer nobody reads)
+    auto gload_a = [&](auto set_c, int pos) __attribute__((always_inline)) {
       constexpr int set = decltype(set_c)::value;
-      const char* Ak = Ab + (size_t)min(kt, KT - 1) * BKT * 4;
+      const bool nx = PERS && pos >= KT && next >= 0;
+      const char* Ak = Ab + (size_t)(nx ? pos - KT : min(pos, KT - 1)) * BKT * 4;
 #pragma unroll
       for (int i = 0; i < OA; ++i) {
         {
-          const float4 v0 = *reinterpret_cast<const float4*>(Ak + aoff[i]);
-          const float4 v1 = *reinterpret_cast<const float4*>(Ak + aoff[i] + 16);
+          const unsigned ao = nx ? aoff[1][i] : aoff[0][i];
+          const float4 v0 = *reinterpret_cast<const float4*>(Ak + ao);
+          const float4 v1 = *reinterpret_cast<const float4*>(Ak + ao + 16);
           ra[set][i][0] = v0.x, ra[set][i][1] = v0.y, ra[set][i][2] = v0.z, ra[set][i][3] = v0.w;
           ra[set][i][4] = v1.x, ra[set][i][5] = v1.y, ra[set][i][6] = v1.z, ra[set][i][7] = v1.w;
         }
       }
     };
-    auto gload_b = [&](auto set_c, int kt) __attribute__((always_inline)) {
+    auto gload_b = [&](auto set_c, int pos) __attribute__((always_inline)) {
       constexpr int set = decltype(set_c)::value;
-      const char* Bk = Bb + (size_t)min(kt, KT - 1) * BKT * bstep;
+      const bool nx = PERS && pos >= KT && next >= 0;
+      const char* Bk = Bb + (size_t)(nx ? pos - KT : min(pos, KT - 1)) * BKT * bstep;
 #pragma unroll
       for (int i = 0; i < OB; ++i) {
         {
+          const unsigned bo = nx ? boff[1][i] : boff[0][i];
           if (BKN) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rb[set][i][q] = *reinterpret_cast<const float*>(Bk + boff[i] + q * ldb4);
+            for (int q = 0; q < 8; ++q) rb[set][i][q] = *reinterpret_cast<const float*>(Bk + bo + q * ldb4);
           } else {
-            const float4 v0 = *reinterpret_cast<const float4*>(Bk + boff[i]);
-            const float4 v1 = *reinterpret_cast<const float4*>(Bk + boff[i] + 16);
+            const float4 v0 = *reinterpret_cast<const float4*>(Bk + bo);
+            const float4 v1 = *reinterpret_cast<const float4*>(Bk + bo + 16);
             rb[set][i][0] = v0.x, rb[set][i][1] = v0.y, rb[set][i][2] = v0.z, rb[set][i][3] = v0.w;
             rb[set][i][4] = v1.x, rb[set][i][5] = v1.y, rb[set][i][6] = v1.z, rb[set][i][7] = v1.w;
           }
@@ -237,13 +249,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     };
 
     f32x16 hi[TI][TJ], lo[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
-
     bf16x8 fa[2][TI][3], fb[2][TJ][3];                        // fragments: [stage][tile][plane]
     const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (BM + wn * TJ * 32 + r) * ROWB + 16 * h;
     constexpr int NF = 3 * (TI + TJ);                         // fragment reads of one 16-deep step
@@ -310,10 +315,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       gload_b(C0{}, 2);
       __syncthreads();
       static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
-      for (int kt = 0; kt < KT; kt += 2) {
-        ktile(C0{}, kt);
-        if (kt + 1 < KT) ktile(C1{}, kt + 1);
-      }
+    }
+    for (;;) {
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+    for (int kt = 0; kt < KT; kt += 2) {
+      ktile(C0{}, kt);
+      if (kt + 1 < KT) ktile(C1{}, kt + 1);
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -365,15 +378,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     const bool full = m0 + BM <= M && n0 + BN <= N;
     if (full) epilogue(std::true_type{}, std::false_type{});
     else epilogue(std::false_type{}, std::false_type{});
-    if (!p.stream_blocks) break;
-    if (tile_ends)
-      for (int q = piece + 1; q < p.slabs; ++q) {
-        Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)q * p.slab;
-        if (full) epilogue(std::true_type{}, std::true_type{});
-        else epilogue(std::false_type{}, std::true_type{});
-      }
-    if (u >= uend) break;
-    __syncthreads();
+    if (!PERS || next < 0) break;
+    slot += nslots;
+    tile = next;
+#pragma unroll
+    for (int i = 0; i < OA; ++i) aoff[0][i] = aoff[1][i];
+#pragma unroll
+    for (int i = 0; i < OB; ++i) boff[0][i] = boff[1][i];
+    next = tile_of(slot + nslots);
+    if (next >= 0) offsets_of(next, aoff[1], boff[1]);
+    }   // tiles of this block
   }
 }
 

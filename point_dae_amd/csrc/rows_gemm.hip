@@ -818,6 +818,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
     if (splits < 0) splits = 1, stream_blocks = 0;
   }
   if (stream_blocks < 0 || stream_blocks % 8 != 0) return bad_arg("rows_gemm: stream_blocks must be a multiple of 8");
+  if (stream_blocks && cfg >= rows3::CFG3_BASE) return unsupported("rows_gemm: the exact-split tile shapes have no stream-K form");
   if (stream_blocks) {
     const bool f3 = cfg >= rows3::CFG3_BASE;
     const int bm = f3 ? 32 * rows3::kCfg3[cfg - rows3::CFG3_BASE].ti * rows3::kCfg3[cfg - rows3::CFG3_BASE].wm : 32 * kCfg[cfg].ti * kCfg[cfg].wm;
