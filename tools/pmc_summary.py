@@ -1,8 +1,10 @@
-"""HBM bytes per launch of the hand-written GEMM / attention kernels from two rocprofv3 --pmc passes
-(FETCH_SIZE, WRITE_SIZE; separate runs: they do not fit one pass on gfx950).
-usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  -> JSON on stdout.
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide
-coalesced reads -> doubled.  Units: KiB."""
+"""HBM bytes per launch of every hand-written kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+runs: they do not fit one pass on gfx950).
+usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [kernel_summary.txt]  -> JSON on stdout.
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced reads ->
+doubled.  Units: KiB.  With the kernel summary of the same command (tools/trace_summary.py: calls per step) the bytes of
+the row-GEMM families (gemm3 / wgrad3b / wgrad_reduce, or their fp32-input twins) are also summed per STEP:
+`rows_families_hbm_bytes_per_step`, the `traffic` of bench.py's roofline."""
 import csv
 import glob
 import json
@@ -10,29 +12,10 @@ import os
 import re
 import sys
 
-NAMES = {
-    r'gemm_nt_kernel<256, 256, 0, 3>': 'gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>',
-    r'gemm_nt_kernel<128, 384, 1, 4>': 'gemm_nt_kernel<128,384,BNRELU,GROUPMAX>',
-    r'gemm_nt_kernel<256, 256, 1, 5>': 'gemm_nt_kernel<256,256,BNRELU,STORE_GROUPMAX>',
-    r'gemm_tn_kernel<128, 128, 1>': 'gemm_tn_kernel<BNRELU>',
-    r'gemm_tn_kernel<128, 128, 0>': 'gemm_tn_kernel<NONE>',
-    r'rows_gemm_kernel<1, 1, 2, 2, false, 0>': 'rows_gemm_kernel<64x64,NT,STORE>',
-    r'rows_gemm_kernel<1, 1, 2, 2, true, 0>': 'rows_gemm_kernel<64x64,KN,STORE>',
-    r'rows_gemm_kernel<1, 1, 2, 2, false, 2>': 'rows_gemm_kernel<64x64,NT,GELU>',
-    r'rows_gemm_kernel<1, 1, 2, 2, true, 3>': 'rows_gemm_kernel<64x64,KN,MUL>',
-    r'rows::wgrad_kernel': 'wgrad_kernel',
-    r'rows::wgrad_reduce_kernel': 'wgrad_reduce_kernel',
-    r'fps_kernel': 'fps_kernel',
-    r'knn_kernel': 'knn_kernel',
-    r'chamfer_fwd_packed': 'chamfer_fwd_packed',
-    r'chamfer_bwd_packed': 'chamfer_bwd_packed',
-    r'add_layernorm_fwd_kernel': 'add_layernorm_fwd_kernel',
-    r'attention_fwd_kernel': 'attention_fwd_kernel',
-    r'attention_bwd_kernel': 'attention_bwd_kernel',
-    r'layernorm_bwd_kernel': 'layernorm_bwd_kernel',
-    r'bnrelu_backward_apply_kernel': 'bnrelu_backward_apply_kernel',
-    r'bnrelu_backward_reduce_kernel': 'bnrelu_backward_reduce_kernel',
-}
+
+def short(n):
+    n = re.sub(r'\(.*', '', n).replace('void ', '')
+    return n.replace('pdae::', '')
 
 
 def collect(d, counter):
@@ -40,24 +23,37 @@ def collect(d, counter):
     for path in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if r.get('Counter_Name') != counter:
+                if r.get('Counter_Name') != counter or 'pdae::' not in r['Kernel_Name']:
                     continue
-                for pat, key in NAMES.items():
-                    if pat in r['Kernel_Name']:
-                        a = out.setdefault(key, [0, 0.0])
-                        a[0] += 1
-                        a[1] += float(r['Counter_Value'])
-                        break
-    return out
+                a = out.setdefault(short(r['Kernel_Name']), {})
+                a[r['Dispatch_Id']] = a.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+    return {k: (len(v), sum(v.values())) for k, v in out.items()}
 
 
 fetch, write = collect(sys.argv[1], 'FETCH_SIZE'), collect(sys.argv[2], 'WRITE_SIZE')
 res = {}
-for key in fetch:
+for key in sorted(fetch):
     n, s = fetch[key]
-    wn, ws = write.get(key, [0, 0.0])
+    wn, ws = write.get(key, (0, 0.0))
     fk, wk = s / n, (ws / wn if wn else 0.0)
-    res[key] = {'FETCH_SIZE_KB_avg': fk, 'WRITE_SIZE_KB_avg': wk, 'dispatches': n,
-                'hbm_bytes_per_launch': (2 * fk + wk) * 1024,
-                'note': 'FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); separate --pmc passes'}
+    res[key] = {'FETCH_SIZE_KB_avg': fk, 'WRITE_SIZE_KB_avg': wk, 'dispatches': n, 'hbm_bytes_per_launch': (2 * fk + wk) * 1024}
+res['_note'] = ('hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE doubled (gfx950 reports half of wide coalesced '
+                'reads, MI355X_MICROARCH.md HBM section); separate --pmc passes; fabric-side counters: Infinity-Cache hits included')
+if len(sys.argv) > 3:
+    calls = {}
+    for ln in open(sys.argv[3]):
+        m = re.match(r'\s*[\d.]+%\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)$', ln)
+        if m:
+            calls[short(m.group(4).strip())] = float(m.group(2))
+    fam = [k for k in res if re.search(r'rows3::gemm3_kernel|rows3::wgrad3b_kernel|rows::wgrad_reduce_kernel|rows::rows_gemm_kernel|rows::wgrad_kernel', k)]
+    total, detail = 0.0, {}
+    for k in fam:
+        c = calls.get(k)
+        if c is None:
+            continue
+        b = res[k]['hbm_bytes_per_launch'] * c
+        total += b
+        detail[k] = {'calls_per_step': c, 'bytes_per_step': b}
+    res['rows_families_hbm_bytes_per_step'] = total
+    res['rows_families_detail'] = detail
 print(json.dumps(res, indent=1))

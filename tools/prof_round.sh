@@ -15,7 +15,7 @@ rm -rf $OUT/stats
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python bench.py --no-cpu-baseline --no-also --no-tvis-table --steps 5 --warmup 2 --probe-steps 0 > $OUT/pmc_$c.log 2>&1
 done
-python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/pmc.json
+python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/kernel_summary.txt > $OUT/pmc.json
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT
 bash tools/prof_mfma.sh

@@ -22,7 +22,7 @@ def short(n):
     if n.startswith('Cijk_'):
         m = re.search(r'(Cijk_[A-Za-z]+_[A-Za-z]+)_.*?(MT\d+x\d+x\d+)', n)
         return 'library GEMM ' + (m.group(1) + ' ' + m.group(2) if m else '')
-    if 'pdae::gemm' in n or 'pdae::rows::' in n or 'pdae::layernorm_bwd' in n or 'pdae::colsum2' in n or 'pdae::fps' in n or 'pdae::knn' in n:
+    if 'pdae::gemm' in n or 'pdae::rows::' in n or 'pdae::rows3::' in n or 'pdae::layernorm_bwd' in n or 'pdae::colsum2' in n or 'pdae::fps' in n or 'pdae::knn' in n:
         return re.sub(r'\(.*', '', n).replace('void ', '')
     return re.sub(r'[<(].*', '', n).replace('void ', '')[:80]
 
