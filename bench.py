@@ -356,6 +356,40 @@ def published_leg(args, device, rank):
             'steps': args.also_steps, 'loss_last_step': float(loss)}
 
 
+def dgcnn_leg(args, device, rank):
+    """`--model_name Point_CAE_DGCNN_FCOnly` (the published non-Transformer runs' model, rerun.sh:37-40: total_bs 256
+    over 8 GPUs = 32 clouds of 1024 points per GPU) on the cfg2 YAML as a short timed leg -> {value, ms_per_step}."""
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedStaticStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG2))
+    config.model.NAME = 'Point_CAE_DGCNN_FCOnly'
+    model = FlatDataParallel(builder.model_builder(config.model).to(device), broadcast=False, process_group=None)
+    model.world_size = 1                         # a local leg on rank 0: no collective
+    optimizer, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+    B, N = 32, 1024
+    x = torch.from_numpy(shapenet_like_clouds(2 * B, N, seed=700 + rank)).to(device)
+    gstep = GraphedStaticStep(model, optimizer, lambda a, b: a + b, B, N)
+    for i in range(4):
+        gstep(x[:B], x[B:])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.also_steps):
+        out = gstep(x[:B], x[B:])
+    loss = out[0].detach().clone() if isinstance(out, (tuple, list)) else None
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del model, optimizer, gstep
+    return {'workload': 'cfg2 YAML with --model_name Point_CAE_DGCNN_FCOnly (rerun.sh:37-40; 256 clouds over 8 GPUs = '
+                        'B=32 per GPU), N=1024, k=20, full train step, hipGraph replay',
+            'value': B * args.also_steps / dt, 'unit': 'clouds/s', 'ms_per_step': dt / args.also_steps * 1e3,
+            'steps': args.also_steps, 'loss_last_step': float(loss) if loss is not None else None}
+
+
 def cpu_baseline(config, args):
     """The CPU oracle (plain-PyTorch model + C restatement of the native ops)
     on a bounded sample of the same workload: `cpu_steps` optimisation steps of
@@ -479,7 +513,7 @@ def main():
     from point_dae_amd.synthetic import shapenet_like_clouds
 
     config = cfg_from_yaml_file(os.path.join(ROOT, CFG3 if args.workload == 'cfg3' else CFG2))
-    if args.model_name and args.workload == 'cfg3':
+    if args.model_name:
         config.model.NAME = args.model_name
     config.npoints = args.npoints
     config.model.num_group = args.num_group
@@ -667,6 +701,7 @@ def main():
                 del step
                 line['also'] = {'cfg2': cfg2_leg(args, device, rank)}
                 line['also']['published_variant'] = published_leg(args, device, rank)
+                line['also']['dgcnn'] = dgcnn_leg(args, device, rank)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
         print(json.dumps(line), flush=True)

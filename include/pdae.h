@@ -304,6 +304,64 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
                             pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * DGCNN encoder (csrc/dgcnn.hip).  Replaces, for Point_CAE_DGCNN_FCOnly (models/PointCAE_DGCNN.py:146-231), the
+ * reference's feature-space kNN + edge features (models/dgcnn_util.py:7-34: matmul, topk, advanced-index gather,
+ * cat of (x_j - x_i, x_i) as a (B, 2C, N, 20) tensor) and the Conv2d -> BatchNorm2d -> LeakyReLU(0.2) -> max over the
+ * 20 neighbours of every EdgeConv (:99-131), and conv5's BatchNorm1d -> LeakyReLU -> max over the points (:132-136).
+ * Activations are rows (points) x channels; b clouds of n points; R = b n.
+ *   rows_sqnorm:  xx[r] = |x_r|^2 (C % 4 == 0).
+ *   gram_topk:    idx (b, n, k) int32, ids within the cloud: the k largest of pd[i][j] = (-xx_i + 2 g_ij) - xx_j
+ *                 (dgcnn_util.knn's expression, each operation rounded), best first, the lower id on equal values;
+ *                 gram (b, n, n) = X_b X_b^T from pdae_rows_gemm_batched.  k <= 64.
+ *   knn_reverse:  the reverse graph: rev_start (b, n+1), rev_src (b, n k): the points that list point s as a
+ *                 neighbour are rev_src[b][rev_start[b][s] .. rev_start[b][s+1]), ascending.  n <= 4096.
+ *   edge_gather_stats: pq (R, 2 co) = [p | q], p = W1 x, q = (W2 - W1) x, so that the conv output of edge (r, j) is
+ *                 e = p[idx[r][j]] + q[r].  ONE pass over the gathered rows: esel (R, co) the winning e of every
+ *                 (point, channel) -- max over j where gamma > 0, min where gamma < 0 (y = lrelu(bn(e)) is monotone
+ *                 in e with the sign of gamma), the first edge where gamma = 0 (torch.max's first occurrence) --
+ *                 sel (R, co) uint16 the winner's id within the cloud, psum (R, co) = sum_j p[idx[r][j]], and
+ *                 sums (2 co doubles) = sum e, sum e^2 over all R k edges (part: pdae_edge_parts() x 2 co doubles of
+ *                 scratch; added in block order).  co a power of two in 16..1024, n <= 65535.
+ *                 -> pdae_bn_finalize(co, R k, sums, ...) gives scale / shift / mean / invstd and the running estimates.
+ *   bn_lrelu_rows: out[r][c] = lrelu(e[r][c] scale[c] + shift[c]), slope 0.2; out2 (nullable, row stride ld2): a
+ *                 second copy into a wider row-major tensor (the concatenated features conv5 reads).
+ *   bn_lrelu_backward_reduce: g = (d1 + d2) * (y > 0 ? 1 : 0.2), y = e scale + shift (d1 contiguous, d2 with row
+ *                 stride ld2, either nullable); sums (2 C doubles) = sum g, sum g xhat, xhat = (e - mean) invstd;
+ *                 dbeta = sum g, dgamma = sum g xhat as floats (nullable).  part: pdae_edge_parts() x 2 C doubles.
+ *   edge_backward: dpq (R, 2 co) = [dp | dq], the gradient of pq under training-mode BatchNorm over the R k edges:
+ *                 d e[r][j] = scale (dy[r][j] - c1 - xhat[r][j] c2), dy = g at the winners and 0 elsewhere,
+ *                 c1 = sums[0] / (R k), c2 = sums[1] / (R k); dq[r] = sum_j d e[r][j] (closed form from psum),
+ *                 dp[s] = sum over the edges arriving at s (a gather over the reverse graph: no atomics).
+ *   cloud_pool_stats: y (R, C) -> ysel (b, C) the winning row value per cloud and channel (max / min / first by
+ *                 the sign of gamma), arow (b, C) int32 its row within the cloud, sums (2 C doubles) = sum y, sum y^2
+ *                 (part: b x 2 C doubles).
+ *   cloud_pool_backward: dy[r][c] = scale ((r == arow[b][c] ? g[b][c] : 0) - c1 - xhat[r][c] c2), sums from
+ *                 bn_lrelu_backward_reduce over the (b, C) winners, c1 / c2 = sums / R.
+ */
+int pdae_rows_sqnorm(int R, int C, const float* x, float* xx, pdae_stream_t stream);
+int pdae_gram_topk(int b, int n, int k, const float* gram, const float* xx, int32_t* idx, pdae_stream_t stream);
+int pdae_knn_reverse(int b, int n, int k, const int32_t* idx, int32_t* rev_start, int32_t* rev_src,
+                     pdae_stream_t stream);
+int pdae_edge_parts(void);
+int pdae_edge_gather_stats(int b, int n, int k, int co, const float* pq, const int32_t* idx, const float* gamma,
+                           float* esel, unsigned short* sel, float* psum, double* part, double* sums,
+                           pdae_stream_t stream);
+int pdae_bn_lrelu_rows(long long R, int C, const float* e, const float* scale, const float* shift, float* out,
+                       float* out2 /*nullable*/, int ld2, pdae_stream_t stream);
+int pdae_bn_lrelu_backward_reduce(long long R, int C, const float* d1 /*nullable*/, const float* d2 /*nullable*/,
+                                  int ld2, const float* e, const float* scale, const float* shift, const float* mean,
+                                  const float* invstd, float* g, double* part, double* sums,
+                                  float* dgamma /*nullable*/, float* dbeta /*nullable*/, pdae_stream_t stream);
+int pdae_edge_backward(int b, int n, int k, int co, const float* g, const float* pq, const unsigned short* sel,
+                       const float* psum, const int32_t* rev_start, const int32_t* rev_src, const float* scale,
+                       const float* mean, const float* invstd, const double* sums, float* dpq, pdae_stream_t stream);
+int pdae_cloud_pool_stats(int b, int n, int C, const float* y, const float* gamma, float* ysel, int32_t* arow,
+                          double* part, double* sums, pdae_stream_t stream);
+int pdae_cloud_pool_backward(int b, int n, int C, const float* y, const float* g, const int32_t* arow,
+                             const float* scale, const float* mean, const float* invstd, const double* sums,
+                             float* dy, pdae_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Dense layers.  The reference runs nn.Linear / 1x1 nn.Conv1d through
  * cuBLAS / cuDNN in fp32 (patch embedder models/PointCAE_transformer.py:24-51,
  * qkv / proj :113-137, fc1 / fc2 :94-110, pos_embed :329-333, increase_dim

@@ -95,6 +95,15 @@ _SIGNATURES = {
     "pdae_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_rows_sqnorm": [_i, _i, _vp, _vp, _vp],
+    "pdae_gram_topk": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_knn_reverse": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_edge_gather_stats": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bn_lrelu_rows": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pdae_bn_lrelu_backward_reduce": [ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_edge_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_cloud_pool_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_cloud_pool_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 # host-side queries (no stream argument)
 _HOST = {
@@ -111,6 +120,7 @@ _HOST = {
     "pdae_deterministic": [],
     "pdae_set_gemm_arith": [_i],
     "pdae_gemm_arith": [],
+    "pdae_edge_parts": [],
 }
 _STR = ("pdae_version", "pdae_last_error")
 

@@ -370,14 +370,15 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False, big_c
         for m0 in range(0, M, rows):
             m1 = min(M, m0 + rows)
             cfg, _, _ = _lib.rows_gemm_plan(m1 - m0, N, K, w_kn, False)
-            if big_cfg is not None and BIG_TILES and m1 - m0 >= BIG_ROWS:
+            if big_cfg is not None and cfg < 16 and BIG_TILES and m1 - m0 >= BIG_ROWS:
                 cfg = big_cfg
             _lib.call('pdae_rows_gemm', x, m1 - m0, N, K, _lib.ptr(x[m0:m1]), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
                       epi, _lib.ptr(z[m0:m1]) if z is not None else None, _lib.ptr(y[m0:m1]), cfg, 1, 0)
         return y
     cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
-    if big_cfg is not None and M >= BIG_ROWS and splits == 1 and BIG_TILES:
-        cfg = big_cfg         # a caller's measured tile shape for a multi-millisecond product (the plan is calibrated on M <= 8192)
+    if big_cfg is not None and cfg < 16 and M >= BIG_ROWS and splits == 1 and BIG_TILES:
+        cfg = big_cfg         # a caller's measured fp32-input tile shape for a multi-millisecond product (that plan is calibrated
+                              # on M <= 8192; the exact-split family's plan, cfg >= 16, prices rounds and stands)
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
     probed_family('rows_gemm', 2.0 * M * N * K,
                   lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),

@@ -7,15 +7,20 @@ registered directly AND inside conv1..conv5, so its state_dict carries both key 
 
     model(corrupted_pts, pts) -> (loss_coarse, zeros(1));  model(.., pts, return_feat=True) -> (B,1024)
 
-Data path on MI355X, activations as rows (points) x channels:
+Data path on MI355X (csrc/dgcnn.hip has the derivations), activations as rows (points) x channels:
   * the graph is rebuilt before every EdgeConv in the space of that layer's input features: the Gram
-    matrices X_b X_b^T of all clouds are ONE batched launch of the fp32-MFMA row GEMM
-    (pdae_rows_gemm_batched), the distances -|xi|^2 + 2 xi.xj - |xj|^2 and the top-20 follow;
-  * an EdgeConv is conv([x_j - x_i, x_i]) = W1 x_j + (W2 - W1) x_i: two products PER POINT
+    matrices X_b X_b^T of all clouds are ONE batched launch of the row GEMM (pdae_rows_gemm_batched),
+    pdae_gram_topk selects the 20 largest of the reference's -|xi|^2 + 2 xi.xj - |xj|^2 per row;
+  * an EdgeConv is conv([x_j - x_i, x_i]) = W1 x_j + (W2 - W1) x_i = p[j] + q[i]: two products PER POINT
     (one row GEMM on the stacked weight [W1; W2 - W1]) instead of one per edge -- 20x fewer FLOPs
-    and no (B,2C,N,20) tensor -- then a row gather + add per edge, BatchNorm, LeakyReLU, max over
-    the 20 neighbours;
-  * conv5 / recfc on the row GEMMs (bias + ReLU in their epilogues), Chamfer on the gfx950 kernel.
+    and no (B,2C,N,20) tensor; BatchNorm statistics, the winning edge (max or min of e by the sign of
+    gamma: lrelu(bn(.)) is monotone) and sum_j p[j] in ONE pass over the gathered rows
+    (pdae_edge_gather_stats), BatchNorm + LeakyReLU on the winners per point (pdae_bn_lrelu_rows);
+    backward as a gather over the reverse graph (pdae_knn_reverse, pdae_edge_backward): no atomics,
+    no per-edge tensor in either direction;
+  * conv5 on the row GEMM, its BatchNorm1d + LeakyReLU + max over the points as pdae_cloud_pool_stats /
+    pdae_cloud_pool_backward; recfc on the row GEMMs, Chamfer on the gfx950 kernel.
+The whole encoder is ONE autograd node (_Encoder): forward and backward are explicit kernel sequences.
 """
 import torch
 import torch.nn as nn
@@ -23,27 +28,129 @@ import torch.nn.functional as F
 
 from . import _lib, nn_ops
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from .patch_embed import _bn_finalize
 from .registry import MODELS
 
 K_GRAPH = 20
 
 
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
 def feature_knn(x_rows, B, N, k=K_GRAPH):
-    """x_rows (B*N, C) -> flat neighbour row ids (B*N*k,) int64 (dgcnn_util.knn :7-12 + the batch offsets of
-    get_graph_feature :24-28): Gram matrices on the batched row GEMM, then the reference's expression."""
-    with torch.no_grad():
-        x = x_rows.detach()
-        C = x.shape[1]
-        if C % 4:                                            # xyz: 3 columns -> 4 (the GEMM reduces in multiples of 4)
-            x = F.pad(x, (0, 4 - C % 4))
-            C = x.shape[1]
-        x = x.contiguous()
-        gram = torch.empty((B, N, N), device=x.device, dtype=torch.float32)
-        _lib.call('pdae_rows_gemm_batched', x, B, N, N, C, _lib.ptr(x), N * C, _lib.ptr(x), N * C, _lib.ptr(gram), N * N)
-        xx = x.view(B, N, C).square().sum(-1)
-        pd = -xx.unsqueeze(1) - (-2 * gram) - xx.unsqueeze(2)      # -xx - inner - xx^T with inner = -2 x^T x
-        idx = pd.topk(k=k, dim=-1)[1]
-        return (idx + torch.arange(B, device=x.device).view(-1, 1, 1) * N).reshape(-1)
+    """x_rows (B*N, C), C % 4 == 0 -> (B, N, k) int32 neighbour ids within the cloud (dgcnn_util.knn :7-12):
+    Gram matrices on the batched row GEMM, the reference's distance expression and its top-k on one wave per row."""
+    x = x_rows.detach()
+    C = x.shape[1]
+    gram = _empty((B, N, N), x)
+    _lib.call('pdae_rows_gemm_batched', x, B, N, N, C, _lib.ptr(x), N * C, _lib.ptr(x), N * C, _lib.ptr(gram), N * N)
+    xx = _empty((B * N,), x)
+    _lib.call('pdae_rows_sqnorm', x, B * N, C, _lib.ptr(x), _lib.ptr(xx))
+    idx = _empty((B, N, k), x, torch.int32)
+    _lib.call('pdae_gram_topk', x, B, N, k, _lib.ptr(gram), _lib.ptr(xx), _lib.ptr(idx))
+    return idx
+
+
+def _parts(like, width):
+    return _empty((_lib.lib().pdae_edge_parts(), 2 * width), like, torch.float64), _empty((2 * width,), like, torch.float64)
+
+
+def _eval_affine(bn):
+    """scale / shift / mean / invstd of an eval-mode BatchNorm (running estimates)."""
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * invstd
+    return scale, bn.bias - bn.running_mean * scale, bn.running_mean, invstd
+
+
+class _Encoder(torch.autograd.Function):
+    """dgcnn_encoder.forward (dgcnn_util.py:117-136) on rows.  Inputs: x4 (B*N, 4) the xyz rows zero-padded to 4
+    columns; per EdgeConv the stacked weight [W1; W2 - W1] (2 Co, C), gamma, beta; conv5's weight (1024, 512), gamma,
+    beta.  The BatchNorm modules ride along for their running estimates (updated in place in training mode)."""
+
+    @staticmethod
+    def forward(ctx, x4, B, N, training, bns, *params):
+        R = B * N
+        ws, gammas, betas = params[0:15:3], params[1:15:3], params[2:15:3]
+        k = min(K_GRAPH, N)
+        cat = _empty((R, sum(w.shape[0] // 2 for w in ws[:4])), x4)
+        saved, x, off = [], x4.contiguous(), 0
+        for li in range(4):
+            w, gamma, bn = ws[li].contiguous(), gammas[li], bns[li]
+            co = w.shape[0] // 2
+            idx = feature_knn(x, B, N, k)
+            pq = nn_ops.rows_gemm(x, w)
+            esel, psum = _empty((R, co), x), _empty((R, co), x)
+            sel = _empty((R, co), x, torch.int16)
+            part, sums = _parts(x, co)
+            _lib.call('pdae_edge_gather_stats', x, B, N, k, co, _lib.ptr(pq), _lib.ptr(idx), _lib.ptr(gamma), _lib.ptr(esel),
+                      _lib.ptr(sel), _lib.ptr(psum), _lib.ptr(part), _lib.ptr(sums))
+            if training:
+                scale, shift, mean, invstd = _bn_finalize(bn, R * k, x, stats64=sums)
+            else:
+                scale, shift, mean, invstd = (t.contiguous() for t in _eval_affine(bn))
+            out = _empty((R, co), x)
+            _lib.call('pdae_bn_lrelu_rows', x, R, co, _lib.ptr(esel), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(out),
+                      cat.data_ptr() + 4 * off, cat.shape[1])
+            saved.append((x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd))
+            x, off = out, off + co
+        w5, g5, bn5 = ws[4].contiguous(), gammas[4], bns[4]
+        C5 = w5.shape[0]
+        y5 = nn_ops.rows_gemm(cat, w5)
+        ysel, arow = _empty((B, C5), x), _empty((B, C5), x, torch.int32)
+        part, sums = _empty((B, 2 * C5), x, torch.float64), _empty((2 * C5,), x, torch.float64)
+        _lib.call('pdae_cloud_pool_stats', x, B, N, C5, _lib.ptr(y5), _lib.ptr(g5), _lib.ptr(ysel), _lib.ptr(arow),
+                  _lib.ptr(part), _lib.ptr(sums))
+        if training:
+            sc5, sh5, mean5, is5 = _bn_finalize(bn5, R, x, stats64=sums)
+        else:
+            sc5, sh5, mean5, is5 = (t.contiguous() for t in _eval_affine(bn5))
+        feat = _empty((B, C5), x)
+        _lib.call('pdae_bn_lrelu_rows', x, B, C5, _lib.ptr(ysel), _lib.ptr(sc5), _lib.ptr(sh5), _lib.ptr(feat), None, 0)
+        ctx.layers, ctx.top = saved, (cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5)
+        ctx.dims = (B, N, k)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        B, N, k = ctx.dims
+        R = B * N
+        cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5 = ctx.top
+        C5 = w5.shape[0]
+        dfeat = dfeat.contiguous()
+        grads = [None] * 15
+        g5 = _empty((B, C5), dfeat)
+        part, sums = _parts(dfeat, C5)
+        dgamma, dbeta = _empty((C5,), dfeat), _empty((C5,), dfeat)
+        _lib.call('pdae_bn_lrelu_backward_reduce', dfeat, B, C5, _lib.ptr(dfeat), None, 0, _lib.ptr(ysel), _lib.ptr(sc5),
+                  _lib.ptr(sh5), _lib.ptr(mean5), _lib.ptr(is5), _lib.ptr(g5), _lib.ptr(part), _lib.ptr(sums),
+                  _lib.ptr(dgamma), _lib.ptr(dbeta))
+        dy5 = _empty((R, C5), dfeat)
+        _lib.call('pdae_cloud_pool_backward', dfeat, B, N, C5, _lib.ptr(y5), _lib.ptr(g5), _lib.ptr(arow), _lib.ptr(sc5),
+                  _lib.ptr(mean5), _lib.ptr(is5), _lib.ptr(sums), _lib.ptr(dy5))
+        dcat = nn_ops.rows_gemm(dy5, w5, True)
+        grads[12], grads[13], grads[14] = nn_ops.rows_wgrad([dy5], [cat], [False])[0][0], dgamma, dbeta
+        del dy5
+        dx, off = None, cat.shape[1]
+        for li in (3, 2, 1, 0):
+            x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd = ctx.layers[li]
+            co = w.shape[0] // 2
+            off -= co
+            g = _empty((R, co), dfeat)
+            part, sums = _parts(dfeat, co)
+            dgamma, dbeta = _empty((co,), dfeat), _empty((co,), dfeat)
+            _lib.call('pdae_bn_lrelu_backward_reduce', dfeat, R, co, _lib.ptr(dx), dcat.data_ptr() + 4 * off, dcat.shape[1],
+                      _lib.ptr(esel), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(g),
+                      _lib.ptr(part), _lib.ptr(sums), _lib.ptr(dgamma), _lib.ptr(dbeta))
+            rev_start, rev_src = _empty((B, N + 1), dfeat, torch.int32), _empty((B, N * k), dfeat, torch.int32)
+            _lib.call('pdae_knn_reverse', dfeat, B, N, k, _lib.ptr(idx), _lib.ptr(rev_start), _lib.ptr(rev_src))
+            dpq = _empty((R, 2 * co), dfeat)
+            _lib.call('pdae_edge_backward', dfeat, B, N, k, co, _lib.ptr(g), _lib.ptr(pq), _lib.ptr(sel), _lib.ptr(psum),
+                      _lib.ptr(rev_start), _lib.ptr(rev_src), _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd),
+                      _lib.ptr(sums), _lib.ptr(dpq))
+            grads[3 * li], grads[3 * li + 1], grads[3 * li + 2] = nn_ops.rows_wgrad([dpq], [x], [False])[0][0], dgamma, dbeta
+            dx = nn_ops.rows_gemm(dpq, w, True) if li > 0 else None
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class dgcnn_encoder(nn.Module):
@@ -58,35 +165,20 @@ class dgcnn_encoder(nn.Module):
         self.conv4 = nn.Sequential(nn.Conv2d(128 * 2, 256, kernel_size=1, bias=False), self.bn4, act())
         self.conv5 = nn.Sequential(nn.Conv1d(256 * 2, 1024, kernel_size=1, bias=False), self.bn5, act())
 
-    def _bn_act(self, rows, bn):
-        if self.training:
-            bn.num_batches_tracked += 1
-        y = F.batch_norm(rows, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training, bn.momentum, bn.eps)
-        return F.leaky_relu(y, 0.2)
-
-    def edge_conv(self, x_rows, B, N, conv):
-        """(B*N, C) -> (B*N, C'): max over the 20 neighbours of lrelu(bn(W [x_j - x_i, x_i]))."""
-        C = x_rows.shape[1]
-        w = conv[0].weight.reshape(conv[0].weight.shape[0], 2 * C)
-        Co = w.shape[0]
-        idx = feature_knn(x_rows, B, N)
-        # W [x_j - x_i, x_i] = W1 x_j + (W2 - W1) x_i: both products per POINT, stacked into one GEMM
-        pq = nn_ops.linear_any(x_rows, torch.cat([w[:, :C], w[:, C:] - w[:, :C]], dim=0))        # (B*N, 2 Co)
-        e = pq[:, :Co].index_select(0, idx).view(B * N, K_GRAPH, Co) + pq[:, Co:].unsqueeze(1)
-        y = self._bn_act(e.reshape(B * N * K_GRAPH, Co), conv[1])
-        return y.view(B * N, K_GRAPH, Co).max(dim=1)[0]
-
     def forward(self, x):
         """x (B,3,N) as the reference -> (B,1024)."""
-        B, _, N = x.shape
-        rows = x.transpose(1, 2).reshape(B * N, -1)
-        feats = []
+        B, C, N = x.shape
+        rows = F.pad(x.transpose(1, 2).reshape(B * N, C), (0, (-C) % 4))
+        params, bns = [], []
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            rows = self.edge_conv(rows, B, N, conv)
-            feats.append(rows)
-        y = nn_ops.linear_any(torch.cat(feats, dim=1), self.conv5[0].weight.squeeze(-1))
-        y = self._bn_act(y, self.conv5[1])
-        return y.view(B, N, -1).max(dim=1)[0]
+            w = conv[0].weight.flatten(1)                          # (Co, 2 Cin) = [W1 | W2] over cat(x_j - x_i, x_i)
+            cin = w.shape[1] // 2
+            stacked = torch.cat([w[:, :cin], w[:, cin:] - w[:, :cin]], dim=0)
+            params += [F.pad(stacked, (0, (-cin) % 4)), conv[1].weight, conv[1].bias]
+            bns.append(conv[1])
+        params += [self.conv5[0].weight.squeeze(-1), self.conv5[1].weight, self.conv5[1].bias]
+        bns.append(self.conv5[1])
+        return _Encoder.apply(rows, B, N, self.training, bns, *params)
 
 
 @MODELS.register_module()
