@@ -309,7 +309,10 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
  * cat of (x_j - x_i, x_i) as a (B, 2C, N, 20) tensor) and the Conv2d -> BatchNorm2d -> LeakyReLU(0.2) -> max over the
  * 20 neighbours of every EdgeConv (:99-131), and conv5's BatchNorm1d -> LeakyReLU -> max over the points (:132-136).
  * Activations are rows (points) x channels; b clouds of n points; R = b n.
- *   rows_sqnorm:  xx[r] = |x_r|^2 (C % 4 == 0).
+ *   rows_sqnorm:  xx[r] = |x_r|^2 (C % 4 == 0).   rows_pad: out (R, cp) = x (R, c) with zero columns appended.
+ *   edge_weight_stack: ws (2 co, kp) = [W1; W2 - W1], zero-padded from cin to kp columns, from the Conv2d weight
+ *                 w (co, 2 cin) = [W1 | W2] over cat(x_j - x_i, x_i); edge_weight_unstack: its transpose,
+ *                 dw (co, 2 cin) = [dWs_top - dWs_bottom | dWs_bottom].
  *   gram_topk:    idx (b, n, k) int32, ids within the cloud: the k largest of pd[i][j] = (-xx_i + 2 g_ij) - xx_j
  *                 (dgcnn_util.knn's expression, each operation rounded), best first, the lower id on equal values;
  *                 gram (b, n, n) = X_b X_b^T from pdae_rows_gemm_batched.  k <= 64.
@@ -333,12 +336,16 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
  *                 c1 = sums[0] / (R k), c2 = sums[1] / (R k); dq[r] = sum_j d e[r][j] (closed form from psum),
  *                 dp[s] = sum over the edges arriving at s (a gather over the reverse graph: no atomics).
  *   cloud_pool_stats: y (R, C) -> ysel (b, C) the winning row value per cloud and channel (max / min / first by
- *                 the sign of gamma), arow (b, C) int32 its row within the cloud, sums (2 C doubles) = sum y, sum y^2
- *                 (part: b x 2 C doubles).
+ *                 the sign of gamma), arow (b, C) int32 its row within the cloud, sums (2 C doubles) = sum y, sum y^2.
+ *                 A cloud's rows are split over rs = pdae_cloud_pool_splits(b, n) blocks; scratch: pv, pr (b, rs, C)
+ *                 the ranges' winners, part b rs x 2 C doubles.
  *   cloud_pool_backward: dy[r][c] = scale ((r == arow[b][c] ? g[b][c] : 0) - c1 - xhat[r][c] c2), sums from
  *                 bn_lrelu_backward_reduce over the (b, C) winners, c1 / c2 = sums / R.
  */
 int pdae_rows_sqnorm(int R, int C, const float* x, float* xx, pdae_stream_t stream);
+int pdae_rows_pad(long long R, int c, int cp, const float* x, float* out, pdae_stream_t stream);
+int pdae_edge_weight_stack(int co, int cin, int kp, const float* w, float* ws, pdae_stream_t stream);
+int pdae_edge_weight_unstack(int co, int cin, int kp, const float* dws, float* dw, pdae_stream_t stream);
 int pdae_gram_topk(int b, int n, int k, const float* gram, const float* xx, int32_t* idx, pdae_stream_t stream);
 int pdae_knn_reverse(int b, int n, int k, const int32_t* idx, int32_t* rev_start, int32_t* rev_src,
                      pdae_stream_t stream);
@@ -355,8 +362,9 @@ int pdae_bn_lrelu_backward_reduce(long long R, int C, const float* d1 /*nullable
 int pdae_edge_backward(int b, int n, int k, int co, const float* g, const float* pq, const unsigned short* sel,
                        const float* psum, const int32_t* rev_start, const int32_t* rev_src, const float* scale,
                        const float* mean, const float* invstd, const double* sums, float* dpq, pdae_stream_t stream);
+int pdae_cloud_pool_splits(int b, int n);
 int pdae_cloud_pool_stats(int b, int n, int C, const float* y, const float* gamma, float* ysel, int32_t* arow,
-                          double* part, double* sums, pdae_stream_t stream);
+                          float* pv, int32_t* pr, double* part, double* sums, pdae_stream_t stream);
 int pdae_cloud_pool_backward(int b, int n, int C, const float* y, const float* g, const int32_t* arow,
                              const float* scale, const float* mean, const float* invstd, const double* sums,
                              float* dy, pdae_stream_t stream);

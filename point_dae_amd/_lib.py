@@ -102,7 +102,10 @@ _SIGNATURES = {
     "pdae_bn_lrelu_rows": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "pdae_bn_lrelu_backward_reduce": [ctypes.c_longlong, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_edge_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pdae_cloud_pool_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_cloud_pool_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_rows_pad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp],
+    "pdae_edge_weight_stack": [_i, _i, _i, _vp, _vp, _vp],
+    "pdae_edge_weight_unstack": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_cloud_pool_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 # host-side queries (no stream argument)
@@ -121,6 +124,7 @@ _HOST = {
     "pdae_set_gemm_arith": [_i],
     "pdae_gemm_arith": [],
     "pdae_edge_parts": [],
+    "pdae_cloud_pool_splits": [_i, _i],
 }
 _STR = ("pdae_version", "pdae_last_error")
 

@@ -52,6 +52,9 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {   // unsigned order 
 // -pairwise_distance[i][j] of dgcnn_util.knn: pd = (-xx_i - inner) - xx_j with inner = -2 g, each operation rounded
 __device__ __forceinline__ float neg_pd(float g, float xi, float xj) { return xj - (2.0f * g - xi); }
 
+// One wave per row: two passes over the (L2-resident) row.  Measured alternatives, both slower (76-81 against 66-69 us
+// at 32 x 1024^2): the row held in registers (one read, 16 more live registers), and four rows per wave (the
+// selection is a dependent chain per row; more resident waves hide it better).
 __global__ __launch_bounds__(256) void gram_topk_kernel(int n, int k, const float* __restrict__ gram_all,
                                                         const float* __restrict__ xx_all, int* __restrict__ idx_all) {
   __shared__ unsigned long long stage_all[4][128];
@@ -381,17 +384,18 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(int R, int n, int k,
 }
 
 // ---- conv5's BatchNorm1d + LeakyReLU + max over a cloud's points -------------------------------------------------
-// y [b n][C]; a block = one cloud x 256 channels, wave w takes rows w, w+4, ...
-// ysel / arow [b][C]: the winning value and its row within the cloud; part [b][2][C] doubles.
-__global__ __launch_bounds__(256) void cloud_pool_stats_kernel(int n, int C, const float* __restrict__ y,
+// y [b n][C]; a block = one cloud x 256 channels x one of `rs` row ranges, wave w takes rows w, w+4, ... of its range.
+// pv / pr [b][rs][C]: the range's winning value and its row within the cloud; part [b rs][2][C] doubles.
+__global__ __launch_bounds__(256) void cloud_pool_stats_kernel(int n, int C, int rs, const float* __restrict__ y,
                                                                const float* __restrict__ gamma,
-                                                               float* __restrict__ ysel, int* __restrict__ arow,
+                                                               float* __restrict__ pv, int* __restrict__ pr,
                                                                double* __restrict__ part) {
   __shared__ double red[4][kWave][2];
   __shared__ float bestv[4][kWave];
   __shared__ int bestr[4][kWave];
   const int lane = lane_id(), wave = threadIdx.x / kWave;
-  const int c4 = blockIdx.x * 256 + lane * 4, bi = blockIdx.y;
+  const int c4 = blockIdx.x * 256 + lane * 4, bi = blockIdx.y, ri = blockIdx.z;
+  const int per = (n + rs - 1) / rs, r0 = ri * per, r1 = min(n, r0 + per);
   const bool live = c4 < C;
   float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) gm = *reinterpret_cast<const float4*>(gamma + c4);
@@ -406,19 +410,19 @@ __global__ __launch_bounds__(256) void cloud_pool_stats_kernel(int n, int C, con
   for (int u = 0; u < 4; ++u) best[u] = mode[u] > 0 ? -__builtin_huge_valf() : __builtin_huge_valf();
   const float* yc = y + (size_t)bi * n * C;
   if (live)
-    for (int r = wave; r < n; r += 4) {
+    for (int r = r0 + wave; r < r1; r += 4) {
       const float4 v = *reinterpret_cast<const float4*>(yc + (size_t)r * C + c4);
       const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         s1[u] += (double)vv[u];
         s2[u] += (double)vv[u] * (double)vv[u];
-        const bool take = mode[u] > 0 ? vv[u] > best[u] : (mode[u] < 0 ? vv[u] < best[u] : r == wave);
+        const bool take = mode[u] > 0 ? vv[u] > best[u] : (mode[u] < 0 ? vv[u] < best[u] : r == r0 + wave);
         best[u] = take ? vv[u] : best[u];
         who[u] = take ? r : who[u];
       }
     }
-  double* o = part + (size_t)bi * 2 * C;
+  double* o = part + ((size_t)bi * rs + ri) * 2 * C;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     __syncthreads();
@@ -434,17 +438,39 @@ __global__ __launch_bounds__(256) void cloud_pool_stats_kernel(int n, int C, con
         if (w > 0 && bestr[w][lane] != 0x7fffffff) {
           const float cv = bestv[w][lane];
           const int cr = bestr[w][lane];
-          // the earliest row wins ties (torch.max's first occurrence); gamma = 0: row 0
+          // the earliest row wins ties (torch.max's first occurrence); gamma = 0: the first row
           const bool better = mode[u] > 0 ? (cv > bv || (cv == bv && cr < br))
                                           : (mode[u] < 0 ? (cv < bv || (cv == bv && cr < br)) : cr < br);
           if (better || br == 0x7fffffff) bv = cv, br = cr;
         }
       }
       o[c4 + u] = a, o[C + c4 + u] = b2;
-      ysel[(size_t)bi * C + c4 + u] = bv;
-      arow[(size_t)bi * C + c4 + u] = br;
+      pv[((size_t)bi * rs + ri) * C + c4 + u] = bv;
+      pr[((size_t)bi * rs + ri) * C + c4 + u] = br;
     }
   }
+}
+
+// the winner of a cloud among its row ranges' winners (ranges ascend in rows: the first best keeps torch.max's rule)
+__global__ void cloud_pool_merge_kernel(int total, int C, int rs, const float* __restrict__ pv, const int* __restrict__ pr,
+                                        const float* __restrict__ gamma, float* __restrict__ ysel,
+                                        int* __restrict__ arow) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int bi = t / C, c = t - bi * C;
+  const float gmv = gamma[c];
+  const int mode = gmv > 0.f ? 1 : (gmv < 0.f ? -1 : 0);
+  float bv = 0.f;
+  int br = 0x7fffffff;
+  for (int ri = 0; ri < rs; ++ri) {
+    const float cv = pv[((size_t)bi * rs + ri) * C + c];
+    const int cr = pr[((size_t)bi * rs + ri) * C + c];
+    if (cr == 0x7fffffff) continue;
+    const bool better = br == 0x7fffffff || (mode > 0 ? cv > bv : (mode < 0 ? cv < bv : false));
+    if (better) bv = cv, br = cr;
+  }
+  ysel[t] = bv;
+  arow[t] = br;
 }
 
 // dy[r][c] = scale_c ((r == arow[b][c] ? g[b][c] : 0) - c1_c - xhat[r][c] c2_c), xhat = (y - mean) invstd
@@ -479,12 +505,38 @@ __global__ __launch_bounds__(256) void cloud_pool_backward_kernel(long long R, i
   }
 }
 
+// ws [2 co][kp] = [W1; W2 - W1] zero-padded to kp columns, from the conv weight w [co][2 cin] = [W1 | W2]
+__global__ void edge_weight_stack_kernel(int co, int cin, int kp, const float* __restrict__ w, float* __restrict__ ws) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * co * kp) return;
+  const int o = t / kp, c = t - o * kp;
+  float v = 0.f;
+  if (c < cin) v = o < co ? w[o * 2 * cin + c] : w[(o - co) * 2 * cin + cin + c] - w[(o - co) * 2 * cin + c];
+  ws[t] = v;
+}
+// its transpose: dw [co][2 cin] = [dWs_top - dWs_bottom | dWs_bottom]
+__global__ void edge_weight_unstack_kernel(int co, int cin, int kp, const float* __restrict__ dws, float* __restrict__ dw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= co * 2 * cin) return;
+  const int o = t / (2 * cin), c = t - o * 2 * cin;
+  dw[t] = c < cin ? dws[o * kp + c] - dws[(co + o) * kp + c] : dws[(co + o) * kp + c - cin];
+}
+// out [R][cp] = x [R][c] with zero columns appended
+__global__ void rows_pad_kernel(long long total, int c, int cp, const float* __restrict__ x, float* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long long r = t / cp;
+  const int j = (int)(t - r * cp);
+  out[t] = j < c ? x[r * c + j] : 0.f;
+}
+
 static int part_reduce(hipStream_t s, int P, int width, const double* part, double* out, float* fa, float* fb) {
   hipLaunchKernelGGL(part_reduce_f64_kernel, dim3((width + kWave - 1) / kWave), dim3(1024), 0, s, P, width, part, out, fa, fb);
   return check_launch("part_reduce");
 }
 
-constexpr int kEdgeBlocks = 1024;
+constexpr int kEdgeBlocks = 512;      // partial rows of the streaming reductions
+constexpr int kGatherBlocks = 1024;   // the gather pass wants every wave slot (latency-bound on L2 gathers)
 
 }  // namespace pdae
 
@@ -533,7 +585,7 @@ extern "C" int pdae_knn_reverse(int b, int n, int k, const int* idx, int* rev_st
   return check_launch("knn_reverse");
 }
 
-extern "C" int pdae_edge_parts(void) { return kEdgeBlocks; }
+extern "C" int pdae_edge_parts(void) { return kGatherBlocks; }
 
 static bool edge_width_ok(int co) { return co == 64 || co == 128 || co == 256 || co == 32 || co == 16 || co == 512 || co == 1024; }
 
@@ -546,11 +598,11 @@ extern "C" int pdae_edge_gather_stats(int b, int n, int k, int co, const float* 
   if ((long long)b * n * 2 * co >= (1LL << 31)) return unsupported("edge_gather_stats: more than 2^31 elements");
   if (!pq || !idx || !gamma || !esel || !sel || !psum || !part || !sums) return bad_arg("edge_gather_stats: null pointer");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(edge_gather_stats_kernel, dim3(kEdgeBlocks), dim3(256), 256 * 8 * sizeof(double), s, b * n, n, k, co,
+  hipLaunchKernelGGL(edge_gather_stats_kernel, dim3(kGatherBlocks), dim3(256), 256 * 8 * sizeof(double), s, b * n, n, k, co,
                      pq, idx, gamma, esel, sel, psum, part);
   int rc = check_launch("edge_gather_stats");
   if (rc != PDAE_OK) return rc;
-  return part_reduce(s, kEdgeBlocks, 2 * co, part, sums, nullptr, nullptr);
+  return part_reduce(s, kGatherBlocks, 2 * co, part, sums, nullptr, nullptr);
 }
 
 extern "C" int pdae_bn_lrelu_rows(long long R, int C, const float* e, const float* scale, const float* shift, float* out,
@@ -601,16 +653,26 @@ extern "C" int pdae_edge_backward(int b, int n, int k, int co, const float* g, c
   return check_launch("edge_backward");
 }
 
+extern "C" int pdae_cloud_pool_splits(int b, int n) {
+  int rs = 1;
+  while (rs < 16 && (long long)b * rs < 128 && n / (rs * 2) >= 32) rs *= 2;
+  return rs;
+}
+
 extern "C" int pdae_cloud_pool_stats(int b, int n, int C, const float* y, const float* gamma, float* ysel, int* arow,
-                                     double* part, double* sums, pdae_stream_t stream) {
+                                     float* pv, int* pr, double* part, double* sums, pdae_stream_t stream) {
   if (b <= 0 || n <= 0 || C <= 0 || C % 4 != 0) return bad_arg("cloud_pool_stats: b, n > 0, C a positive multiple of 4");
   if (b > 65535) return unsupported("cloud_pool_stats: b > 65535");
-  if (!y || !gamma || !ysel || !arow || !part || !sums) return bad_arg("cloud_pool_stats: null pointer");
+  if (!y || !gamma || !ysel || !arow || !pv || !pr || !part || !sums) return bad_arg("cloud_pool_stats: null pointer");
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(cloud_pool_stats_kernel, dim3((C + 255) / 256, b), dim3(256), 0, s, n, C, y, gamma, ysel, arow, part);
+  const int rs = pdae_cloud_pool_splits(b, n);
+  hipLaunchKernelGGL(cloud_pool_stats_kernel, dim3((C + 255) / 256, b, rs), dim3(256), 0, s, n, C, rs, y, gamma, pv, pr, part);
   int rc = check_launch("cloud_pool_stats");
   if (rc != PDAE_OK) return rc;
-  return part_reduce(s, b, 2 * C, part, sums, nullptr, nullptr);
+  hipLaunchKernelGGL(cloud_pool_merge_kernel, dim3((b * C + 255) / 256), dim3(256), 0, s, b * C, C, rs, pv, pr, gamma, ysel, arow);
+  rc = check_launch("cloud_pool_merge");
+  if (rc != PDAE_OK) return rc;
+  return part_reduce(s, b * rs, 2 * C, part, sums, nullptr, nullptr);
 }
 
 extern "C" int pdae_cloud_pool_backward(int b, int n, int C, const float* y, const float* g, const int* arow,
@@ -624,4 +686,26 @@ extern "C" int pdae_cloud_pool_backward(int b, int n, int C, const float* y, con
   hipLaunchKernelGGL(cloud_pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), R, n, C, y, g, arow,
                      scale, mean, invstd, sums, dy);
   return check_launch("cloud_pool_backward");
+}
+
+extern "C" int pdae_edge_weight_stack(int co, int cin, int kp, const float* w, float* ws, pdae_stream_t stream) {
+  if (co <= 0 || cin <= 0 || kp < cin) return bad_arg("edge_weight_stack: co, cin > 0, kp >= cin required");
+  if (!w || !ws) return bad_arg("edge_weight_stack: null pointer");
+  hipLaunchKernelGGL(edge_weight_stack_kernel, dim3((2 * co * kp + 255) / 256), dim3(256), 0, as_stream(stream), co, cin, kp, w, ws);
+  return check_launch("edge_weight_stack");
+}
+
+extern "C" int pdae_edge_weight_unstack(int co, int cin, int kp, const float* dws, float* dw, pdae_stream_t stream) {
+  if (co <= 0 || cin <= 0 || kp < cin) return bad_arg("edge_weight_unstack: co, cin > 0, kp >= cin required");
+  if (!dws || !dw) return bad_arg("edge_weight_unstack: null pointer");
+  hipLaunchKernelGGL(edge_weight_unstack_kernel, dim3((2 * co * cin + 255) / 256), dim3(256), 0, as_stream(stream), co, cin, kp, dws, dw);
+  return check_launch("edge_weight_unstack");
+}
+
+extern "C" int pdae_rows_pad(long long R, int c, int cp, const float* x, float* out, pdae_stream_t stream) {
+  if (R < 0 || c <= 0 || cp < c) return bad_arg("rows_pad: R >= 0, 0 < c <= cp required");
+  if (R == 0) return PDAE_OK;
+  if (!x || !out) return bad_arg("rows_pad: null pointer");
+  hipLaunchKernelGGL(rows_pad_kernel, dim3((unsigned)((R * cp + 255) / 256)), dim3(256), 0, as_stream(stream), R * cp, c, cp, x, out);
+  return check_launch("rows_pad");
 }

@@ -64,20 +64,25 @@ def _eval_affine(bn):
 
 
 class _Encoder(torch.autograd.Function):
-    """dgcnn_encoder.forward (dgcnn_util.py:117-136) on rows.  Inputs: x4 (B*N, 4) the xyz rows zero-padded to 4
-    columns; per EdgeConv the stacked weight [W1; W2 - W1] (2 Co, C), gamma, beta; conv5's weight (1024, 512), gamma,
-    beta.  The BatchNorm modules ride along for their running estimates (updated in place in training mode)."""
+    """dgcnn_encoder.forward (dgcnn_util.py:117-136) on rows.  Inputs: pts (B*N, 3) xyz rows; per EdgeConv the Conv2d
+    weight (Co, 2 Cin, 1, 1) = [W1 | W2], gamma, beta; conv5's weight (1024, 512, 1), gamma, beta.  The BatchNorm
+    modules ride along for their running estimates (updated in place in training mode)."""
 
     @staticmethod
-    def forward(ctx, x4, B, N, training, bns, *params):
+    def forward(ctx, pts, B, N, training, bns, *params):
         R = B * N
-        ws, gammas, betas = params[0:15:3], params[1:15:3], params[2:15:3]
+        convs, gammas, betas = params[0:15:3], params[1:15:3], params[2:15:3]
         k = min(K_GRAPH, N)
-        cat = _empty((R, sum(w.shape[0] // 2 for w in ws[:4])), x4)
-        saved, x, off = [], x4.contiguous(), 0
+        cin = pts.shape[1]
+        x = _empty((R, cin + (-cin) % 4), pts)
+        _lib.call('pdae_rows_pad', pts, R, cin, x.shape[1], _lib.ptr(pts.contiguous()), _lib.ptr(x))
+        cat = _empty((R, sum(w.shape[0] for w in convs[:4])), pts)
+        saved, off = [], 0
         for li in range(4):
-            w, gamma, bn = ws[li].contiguous(), gammas[li], bns[li]
-            co = w.shape[0] // 2
+            gamma, bn = gammas[li], bns[li]
+            co, kp = convs[li].shape[0], x.shape[1]
+            w = _empty((2 * co, kp), x)                             # [W1; W2 - W1], K padded like x
+            _lib.call('pdae_edge_weight_stack', x, co, cin, kp, _lib.ptr(convs[li].contiguous()), _lib.ptr(w))
             idx = feature_knn(x, B, N, k)
             pq = nn_ops.rows_gemm(x, w)
             esel, psum = _empty((R, co), x), _empty((R, co), x)
@@ -92,15 +97,17 @@ class _Encoder(torch.autograd.Function):
             out = _empty((R, co), x)
             _lib.call('pdae_bn_lrelu_rows', x, R, co, _lib.ptr(esel), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(out),
                       cat.data_ptr() + 4 * off, cat.shape[1])
-            saved.append((x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd))
-            x, off = out, off + co
-        w5, g5, bn5 = ws[4].contiguous(), gammas[4], bns[4]
+            saved.append((x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd, cin))
+            x, off, cin = out, off + co, co
+        w5, g5, bn5 = convs[4].flatten(1).contiguous(), gammas[4], bns[4]
         C5 = w5.shape[0]
         y5 = nn_ops.rows_gemm(cat, w5)
         ysel, arow = _empty((B, C5), x), _empty((B, C5), x, torch.int32)
-        part, sums = _empty((B, 2 * C5), x, torch.float64), _empty((2 * C5,), x, torch.float64)
+        rs = _lib.lib().pdae_cloud_pool_splits(B, N)
+        pv, pr = _empty((B, rs, C5), x), _empty((B, rs, C5), x, torch.int32)
+        part, sums = _empty((B * rs, 2 * C5), x, torch.float64), _empty((2 * C5,), x, torch.float64)
         _lib.call('pdae_cloud_pool_stats', x, B, N, C5, _lib.ptr(y5), _lib.ptr(g5), _lib.ptr(ysel), _lib.ptr(arow),
-                  _lib.ptr(part), _lib.ptr(sums))
+                  _lib.ptr(pv), _lib.ptr(pr), _lib.ptr(part), _lib.ptr(sums))
         if training:
             sc5, sh5, mean5, is5 = _bn_finalize(bn5, R, x, stats64=sums)
         else:
@@ -109,6 +116,7 @@ class _Encoder(torch.autograd.Function):
         _lib.call('pdae_bn_lrelu_rows', x, B, C5, _lib.ptr(ysel), _lib.ptr(sc5), _lib.ptr(sh5), _lib.ptr(feat), None, 0)
         ctx.layers, ctx.top = saved, (cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5)
         ctx.dims = (B, N, k)
+        ctx.shapes = [c.shape for c in convs]
         return feat
 
     @staticmethod
@@ -129,11 +137,11 @@ class _Encoder(torch.autograd.Function):
         _lib.call('pdae_cloud_pool_backward', dfeat, B, N, C5, _lib.ptr(y5), _lib.ptr(g5), _lib.ptr(arow), _lib.ptr(sc5),
                   _lib.ptr(mean5), _lib.ptr(is5), _lib.ptr(sums), _lib.ptr(dy5))
         dcat = nn_ops.rows_gemm(dy5, w5, True)
-        grads[12], grads[13], grads[14] = nn_ops.rows_wgrad([dy5], [cat], [False])[0][0], dgamma, dbeta
+        grads[12], grads[13], grads[14] = nn_ops.rows_wgrad([dy5], [cat], [False])[0][0].view(ctx.shapes[4]), dgamma, dbeta
         del dy5
         dx, off = None, cat.shape[1]
         for li in (3, 2, 1, 0):
-            x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd = ctx.layers[li]
+            x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd, cin = ctx.layers[li]
             co = w.shape[0] // 2
             off -= co
             g = _empty((R, co), dfeat)
@@ -148,7 +156,10 @@ class _Encoder(torch.autograd.Function):
             _lib.call('pdae_edge_backward', dfeat, B, N, k, co, _lib.ptr(g), _lib.ptr(pq), _lib.ptr(sel), _lib.ptr(psum),
                       _lib.ptr(rev_start), _lib.ptr(rev_src), _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd),
                       _lib.ptr(sums), _lib.ptr(dpq))
-            grads[3 * li], grads[3 * li + 1], grads[3 * li + 2] = nn_ops.rows_wgrad([dpq], [x], [False])[0][0], dgamma, dbeta
+            dws = nn_ops.rows_wgrad([dpq], [x], [False])[0][0]
+            dconv = _empty(ctx.shapes[li], dfeat)
+            _lib.call('pdae_edge_weight_unstack', dfeat, co, cin, x.shape[1], _lib.ptr(dws), _lib.ptr(dconv))
+            grads[3 * li], grads[3 * li + 1], grads[3 * li + 2] = dconv, dgamma, dbeta
             dx = nn_ops.rows_gemm(dpq, w, True) if li > 0 else None
         return (None, None, None, None, None) + tuple(grads)
 
@@ -167,18 +178,16 @@ class dgcnn_encoder(nn.Module):
 
     def forward(self, x):
         """x (B,3,N) as the reference -> (B,1024)."""
-        B, C, N = x.shape
-        rows = F.pad(x.transpose(1, 2).reshape(B * N, C), (0, (-C) % 4))
+        return self.forward_rows(x.transpose(1, 2))
+
+    def forward_rows(self, pts):
+        """pts (B,N,3) point rows (what the auto-encoder holds before the reference transposes them) -> (B,1024)."""
+        B, N, C = pts.shape
         params, bns = [], []
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            w = conv[0].weight.flatten(1)                          # (Co, 2 Cin) = [W1 | W2] over cat(x_j - x_i, x_i)
-            cin = w.shape[1] // 2
-            stacked = torch.cat([w[:, :cin], w[:, cin:] - w[:, :cin]], dim=0)
-            params += [F.pad(stacked, (0, (-cin) % 4)), conv[1].weight, conv[1].bias]
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            params += [conv[0].weight, conv[1].weight, conv[1].bias]
             bns.append(conv[1])
-        params += [self.conv5[0].weight.squeeze(-1), self.conv5[1].weight, self.conv5[1].bias]
-        bns.append(self.conv5[1])
-        return _Encoder.apply(rows, B, N, self.training, bns, *params)
+        return _Encoder.apply(pts.reshape(B * N, C), B, N, self.training, bns, *params)
 
 
 @MODELS.register_module()
@@ -205,12 +214,12 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
     def forward(self, corrupted_pts, pts, vis=False, return_feat=False, capture=None, **kwargs):
         nn_ops.begin_step(pts.device)
         if return_feat:
-            return self.dgcnn_encoder(pts[:, :, :3].transpose(1, 2).contiguous())
+            return self.dgcnn_encoder.forward_rows(pts[:, :, :3])
         for item in self.corrupt_type:
             if item == 'dropout_patch_pointmae' or item.startswith('dropout_global') or item == 'random_dropout':
                 raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
         corrupted_pts, pts = corrupted_pts[:, :, :3].contiguous(), pts[:, :, :3].contiguous()
-        feature = self.dgcnn_encoder(corrupted_pts.transpose(1, 2).contiguous())
+        feature = self.dgcnn_encoder.forward_rows(corrupted_pts)
         r = self.recfc
         coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(feature, r[0], 'relu'), r[2], 'relu'), r[4])
         coarse = coarse.view(-1, self.num_coarse, 3)
