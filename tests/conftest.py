@@ -57,3 +57,18 @@ def _one_created_stream():
         from point_dae_amd.graph_step import use_created_stream
         use_created_stream()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _poison_free_memory(request):
+    """PDAE_POISON=1: before every GPU test the caching allocator's free blocks are filled with NaN, so a kernel that
+    reads a `torch.empty` buffer it (or its producer) never wrote shows up as NaN instead of passing on memory that
+    happened to be zero (a fresh process) or stale-but-plausible (a long suite)."""
+    if os.environ.get('PDAE_POISON', '0') in ('', '0') or 'gpu' not in request.keywords:
+        yield
+        return
+    import torch
+    big = torch.full((1 << 30,), float('nan'), device='cuda')                  # 4 GB: the large-block pool
+    small = [torch.full((1 << k,), float('nan'), device='cuda') for k in range(8, 19) for _ in range(48)]
+    del big, small
+    yield

@@ -675,8 +675,11 @@ def test_graphed_static_step_equals_eager_step():
     for i, ((a0, a1), (b0, b1)) in enumerate(zip(eager, graphed)):
         # step 0 sees identical parameters (forward only: 1e-5); from step 1 on the runs differ by what the
         # set-abstraction max-pool ties do to one step's gradients (tie sensitivity: an LDS-atomic
-        # order flips a tied arg-max and re-routes a gradient element; measured 2e-4..6e-4 on the next loss)
-        tol = 1e-5 if i == 0 else (2e-3 if i < 2 else 1e-2)
+        # order flips a tied arg-max and re-routes a gradient element) and by AdamW's first updates being
+        # lr * sign(g) for every element however small.  Worst of 10 repetitions (tools/lab/static_step_noise.py):
+        # 1e-6, 5e-5, 1.4e-3, 2.9e-3, 6.1e-3, 6.3e-3 per step (the old 1e-2 bound on steps 2.. was exceeded in two of
+        # five runs of the whole suite); with PDAE_DETERMINISTIC=1: 0, 1e-6, 3e-5, 4e-4, 1.4e-3, 1.4e-3
+        tol = 1e-5 if i == 0 else (2e-3 if i < 2 else 5e-2)
         assert abs(a0 - b0) <= tol * abs(a0) and abs(a1 - b1) <= tol * abs(a1), (i, eager, graphed)
     assert (model_a.flat_param - model_b.flat_param).abs().max().item() < 2e-2
 
