@@ -48,6 +48,19 @@ const char* pdae_version(void);
 /* Text for the last failing status on this thread (hipGetErrorString or arg). */
 const char* pdae_last_error(void);
 
+/* Contexts.  The library's mutable state -- the deterministic-mode workspace, the parked (deferred) reductions, the
+ * GEMM arithmetic -- lives in a context; every entry point works on the calling thread's CURRENT context, which is
+ * the process default context until the thread sets one (the model of the CUDA / HIP runtime's current device; the
+ * reference's extensions keep no state at all, so it has nothing to bind here).  A host that drives several streams
+ * from several threads gives each thread its own context (and its own workspaces): nothing is shared between them.
+ * One context must not be used by two threads at once.  Everything else the library holds (per-kernel launch
+ * attributes set at first use) is immutable after its first write. */
+typedef struct pdae_ctx* pdae_ctx_t;
+int pdae_ctx_create(pdae_ctx_t* out);
+int pdae_ctx_destroy(pdae_ctx_t ctx);          /* not while it is current on the calling thread */
+int pdae_ctx_set_current(pdae_ctx_t ctx);      /* NULL: back to the process default context */
+pdae_ctx_t pdae_ctx_current(void);             /* NULL when the thread is on the default context */
+
 /* Deterministic mode.  The reference's reductions (cuDNN batch-norm statistics, cuBLAS split-K
  * weight gradients, ATen layer_norm backward: models/PointCAE_transformer.py:37-51, 94-147) and,
  * by default, this library's end in float atomics whose order of arrival varies from launch to
@@ -55,7 +68,7 @@ const char* pdae_last_error(void);
  * at batch 128) the batch-norm statistics, the embedder's weight / bias gradients, the LayerNorm
  * parameter gradients and the column sums store per-block partials and add them in block order:
  * bit-identical results from run to run and from hipGraph replay to eager launch, for one small
- * extra launch per reduction.  The workspace is shared by all launches: one stream at a time.
+ * extra launch per reduction.  The workspace is shared by all launches of its CONTEXT: one stream at a time per context.
  * workspace == NULL switches the mode off.  A reduction that needs more than `bytes` fails with
  * PDAE_ERR_UNSUPPORTED.  Not covered (LDS float atomics, kept): group_points_grad,
  * three_interpolate_grad and the large-cloud Chamfer gradient of the PointNet++ configuration. */

@@ -124,6 +124,10 @@ _HOST = {
     "pdae_set_gemm_arith": [_i],
     "pdae_gemm_arith": [],
     "pdae_edge_parts": [],
+    "pdae_ctx_create": [_vp],
+    "pdae_ctx_destroy": [_vp],
+    "pdae_ctx_set_current": [_vp],
+    "pdae_ctx_current": [],
     "pdae_cloud_pool_splits": [_i, _i],
 }
 _STR = ("pdae_version", "pdae_last_error")
@@ -156,7 +160,8 @@ def lib():
         for name, argtypes in _HOST.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name.endswith('_workspace') and 'wgrad' not in name else ctypes.c_int
+            fn.restype = (ctypes.c_longlong if name.endswith('_workspace') and 'wgrad' not in name else
+                          ctypes.c_void_p if name == 'pdae_ctx_current' else ctypes.c_int)
         for name in _STR:
             getattr(handle, name).restype = ctypes.c_char_p
         _lib = handle
@@ -269,12 +274,42 @@ def _check(handle, name, rc):
         raise RuntimeError(f"{name} failed with status {rc}: {handle.pdae_last_error().decode()}")
 
 
+class Context:
+    """A library context (include/pdae.h pdae_ctx_*): the deterministic-mode workspace, the parked reductions and the
+    GEMM arithmetic of the host thread that makes it current.  `with Context():` works on a private context."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _check(lib(), 'pdae_ctx_create', lib().pdae_ctx_create(ctypes.byref(h)))
+        self.handle, self._prev, self._keep = h, None, []
+
+    def __enter__(self):
+        self._prev = lib().pdae_ctx_current()
+        lib().pdae_ctx_set_current(self.handle)
+        return self
+
+    def set_deterministic(self, megabytes=64):
+        """Deterministic mode for THIS context (it must be current): the workspace belongs to the context."""
+        ws = torch.empty(megabytes << 20, dtype=torch.uint8, device='cuda')
+        self._keep.append(ws)
+        _check(lib(), 'pdae_set_deterministic', lib().pdae_set_deterministic(ws.data_ptr(), ws.numel()))
+
+    def __exit__(self, *exc):
+        torch.cuda.current_stream().synchronize()
+        lib().pdae_ctx_set_current(self._prev)
+        return False
+
+    def close(self):
+        _check(lib(), 'pdae_ctx_destroy', lib().pdae_ctx_destroy(self.handle))
+        self._keep = []
+
+
 _plan_cache = {}
 
 
 def rows_gemm_plan(M, N, K, w_kn, may_split):
-    """(cfg, splits, stream_blocks) of pdae_rows_gemm for a shape (host-side query, cached)."""
-    key = (M, N, K, w_kn, may_split)
+    """(cfg, splits, stream_blocks) of pdae_rows_gemm for a shape (host-side query, cached per arithmetic)."""
+    key = (M, N, K, w_kn, may_split, lib().pdae_gemm_arith())
     hit = _plan_cache.get(key)
     if hit is None:
         handle = lib()
@@ -306,7 +341,7 @@ def set_gemm_arith(arith):
 
 def rows_wgrad_workspace(M, Ns, Ks):
     """workspace floats of pdae_rows_wgrad for a group of layers (cached)."""
-    key = (M, tuple(Ns), tuple(Ks))
+    key = (M, tuple(Ns), tuple(Ks), lib().pdae_gemm_arith())
     hit = _wg_cache.get(key)
     if hit is None:
         handle = lib()
@@ -340,7 +375,7 @@ def rows_wgrad_multi(jobs):
         parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
         Ms, Ns, Ks = (iarr(*v) for v in ([j[0].shape[0] for j in part], [j[0].shape[1] for j in part],
                                         [j[1].shape[1] for j in part]))
-        key = ('multi', tuple(Ms), tuple(Ns), tuple(Ks))
+        key = ('multi', tuple(Ms), tuple(Ns), tuple(Ks), lib().pdae_gemm_arith())
         floats = _wg_cache.get(key)
         if floats is None:
             f = ctypes.c_longlong(0)

@@ -47,6 +47,7 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 // Column reductions that normally end in device-scope float atomics (order of arrival) write
 // one partial row per block, [partition][width], into the registered workspace instead;
 // det_reduce then adds the rows in partition order.  Same arithmetic per block either way.
+int& ctx_gemm_arith();   // the current context's GEMM arithmetic (det.hip; -1 = not decided yet)
 bool det_on();
 // the workspace when the mode is on (nullptr when it is off); *rc = PDAE_ERR_UNSUPPORTED and
 // nullptr when the registered buffer is smaller than `bytes`

@@ -10,19 +10,48 @@
 
 namespace pdae {
 
-static void* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
+// ---- contexts (include/pdae.h: pdae_ctx_create / pdae_ctx_set_current) -----------------------------------------
+// Everything mutable the library keeps between calls lives in a Ctx: the deterministic-mode workspace, the parked
+// (deferred) reductions, the GEMM arithmetic.  A host thread works on its current context (thread local; the process
+// default context until it sets one), so two threads driving two streams -- each with its own context and workspaces --
+// share nothing.
+constexpr int DEF_MAX = 48;
+struct DefJob {
+  const float* part;
+  float* out[3];
+  int n[3];
+  int P, width;
+};
+struct DefJobs {
+  DefJob j[DEF_MAX];
+};
+struct Ctx {
+  void* ws = nullptr;                 // deterministic mode
+  size_t ws_bytes = 0;
+  float* def_ws = nullptr;            // deferred reductions
+  size_t def_floats = 0, def_used = 0;
+  bool def_on = false, def_hold = false;
+  DefJobs def_jobs;
+  int def_n = 0;
+  int arith = -1;                     // GEMM arithmetic (-1: PDAE_GEMM in the environment decides at first use)
+};
+static Ctx g_default_ctx;
+static thread_local Ctx* t_ctx = nullptr;
+static Ctx& ctx() { return t_ctx ? *t_ctx : g_default_ctx; }
 
-bool det_on() { return g_ws != nullptr; }
+int& ctx_gemm_arith() { return ctx().arith; }
+
+bool det_on() { return ctx().ws != nullptr; }
 
 void* det_workspace(size_t bytes, int* rc) {
   *rc = PDAE_OK;
-  if (!g_ws) return nullptr;
-  if (bytes > g_ws_bytes) {
+  Ctx& c = ctx();
+  if (!c.ws) return nullptr;
+  if (bytes > c.ws_bytes) {
     *rc = unsupported("deterministic mode: the registered workspace is too small for this reduction");
     return nullptr;
   }
-  return g_ws;
+  return c.ws;
 }
 
 template <typename T>
@@ -64,31 +93,16 @@ int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* 
 }
 
 // ---- deferred reductions ---------------------------------------------------------------------
-constexpr int DEF_MAX = 48;
-struct DefJob {
-  const float* part;
-  float* out[3];
-  int n[3];
-  int P, width;
-};
-struct DefJobs {
-  DefJob j[DEF_MAX];
-};
-static float* g_def_ws = nullptr;
-static size_t g_def_floats = 0, g_def_used = 0;
-static bool g_def_on = false, g_def_hold = false;
-static DefJobs g_def_jobs;
-static int g_def_n = 0;
-
-bool deferred_on() { return g_def_on && !g_def_hold; }
+bool deferred_on() { return ctx().def_on && !ctx().def_hold; }
 
 float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2) {
-  if (!deferred_on() || g_def_n >= DEF_MAX) return nullptr;
+  Ctx& c = ctx();
+  if (!deferred_on() || c.def_n >= DEF_MAX) return nullptr;
   const size_t need = ((size_t)P * width + 63) & ~(size_t)63;
-  if (g_def_used + need > g_def_floats) return nullptr;
-  float* part = g_def_ws + g_def_used;
-  g_def_used += need;
-  DefJob& d = g_def_jobs.j[g_def_n++];
+  if (c.def_used + need > c.def_floats) return nullptr;
+  float* part = c.def_ws + c.def_used;
+  c.def_used += need;
+  DefJob& d = c.def_jobs.j[c.def_n++];
   d.part = part, d.P = P, d.width = width;
   d.out[0] = o0, d.out[1] = o1, d.out[2] = o2;
   d.n[0] = n0, d.n[1] = n1, d.n[2] = n2;
@@ -127,8 +141,8 @@ __global__ __launch_bounds__(256) void deferred_reduce_kernel(const DefJobs jobs
 
 extern "C" int pdae_set_deterministic(void* workspace, size_t bytes) {
   if (workspace && bytes < (1u << 20)) return pdae::bad_arg("set_deterministic: workspace of at least 1 MiB");
-  pdae::g_ws = workspace;
-  pdae::g_ws_bytes = workspace ? bytes : 0;
+  pdae::ctx().ws = workspace;
+  pdae::ctx().ws_bytes = workspace ? bytes : 0;
   return PDAE_OK;
 }
 
@@ -136,27 +150,50 @@ extern "C" int pdae_deterministic(void) { return pdae::det_on() ? 1 : 0; }
 
 extern "C" int pdae_deferred_begin(void* workspace, size_t bytes) {
   if (!workspace || bytes < (1u << 20)) return pdae::bad_arg("deferred_begin: workspace of at least 1 MiB");
-  pdae::g_def_ws = static_cast<float*>(workspace);
-  pdae::g_def_floats = bytes / sizeof(float);
-  pdae::g_def_used = 0, pdae::g_def_n = 0, pdae::g_def_on = true, pdae::g_def_hold = false;
+  pdae::Ctx& c = pdae::ctx();
+  c.def_ws = static_cast<float*>(workspace);
+  c.def_floats = bytes / sizeof(float);
+  c.def_used = 0, c.def_n = 0, c.def_on = true, c.def_hold = false;
   return PDAE_OK;
 }
 
 extern "C" int pdae_deferred_flush(pdae_stream_t stream) {
   using namespace pdae;
-  g_def_on = false;
+  Ctx& c = ctx();
+  c.def_on = false;
   const int rc = rows_wgrad_flush(as_stream(stream));
   if (rc) return rc;
-  if (g_def_n == 0) return PDAE_OK;
+  if (c.def_n == 0) return PDAE_OK;
   int widest = 0;
-  for (int i = 0; i < g_def_n; ++i) widest = g_def_jobs.j[i].width > widest ? g_def_jobs.j[i].width : widest;
-  hipLaunchKernelGGL(deferred_reduce_kernel, dim3((widest + 31) / 32, g_def_n), dim3(256), 0, as_stream(stream),
-                     g_def_jobs);
-  g_def_n = 0;
+  for (int i = 0; i < c.def_n; ++i) widest = c.def_jobs.j[i].width > widest ? c.def_jobs.j[i].width : widest;
+  hipLaunchKernelGGL(deferred_reduce_kernel, dim3((widest + 31) / 32, c.def_n), dim3(256), 0, as_stream(stream),
+                     c.def_jobs);
+  c.def_n = 0;
   return check_launch("deferred_flush");
 }
 
 extern "C" int pdae_deferred_hold(int hold) {
-  pdae::g_def_hold = hold != 0;
+  pdae::ctx().def_hold = hold != 0;
   return PDAE_OK;
 }
+
+extern "C" int pdae_ctx_create(pdae_ctx_t* out) {
+  if (!out) return pdae::bad_arg("ctx_create: null pointer");
+  *out = reinterpret_cast<pdae_ctx_t>(new pdae::Ctx());
+  return PDAE_OK;
+}
+
+extern "C" int pdae_ctx_destroy(pdae_ctx_t c) {
+  pdae::Ctx* p = reinterpret_cast<pdae::Ctx*>(c);
+  if (!p) return pdae::bad_arg("ctx_destroy: null context");
+  if (p == pdae::t_ctx) return pdae::bad_arg("ctx_destroy: the context is current on this thread");
+  delete p;
+  return PDAE_OK;
+}
+
+extern "C" int pdae_ctx_set_current(pdae_ctx_t c) {
+  pdae::t_ctx = reinterpret_cast<pdae::Ctx*>(c);
+  return PDAE_OK;
+}
+
+extern "C" pdae_ctx_t pdae_ctx_current(void) { return reinterpret_cast<pdae_ctx_t>(pdae::t_ctx); }

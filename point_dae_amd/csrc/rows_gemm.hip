@@ -727,17 +727,18 @@ using namespace pdae::rows;
 
 // ---- GEMM arithmetic of the row-GEMM family: exact-split bf16 (rows3_gemm.hip) unless PDAE_GEMM=f32mfma or
 // pdae_set_gemm_arith(PDAE_GEMM_F32MFMA) asks for the fp32-input MFMA kernels above
-static int g_arith = -1;
+// (the setting lives in the calling thread's context: det.hip)
 static int gemm_arith() {
-  if (g_arith < 0) {
+  int& a = ctx_gemm_arith();
+  if (a < 0) {
     const char* e = getenv("PDAE_GEMM");
-    g_arith = (e && (!strcmp(e, "f32mfma") || !strcmp(e, "f32") || !strcmp(e, "fp32"))) ? PDAE_GEMM_F32MFMA : PDAE_GEMM_BF16X3;
+    a = (e && (!strcmp(e, "f32mfma") || !strcmp(e, "f32") || !strcmp(e, "fp32"))) ? PDAE_GEMM_F32MFMA : PDAE_GEMM_BF16X3;
   }
-  return g_arith;
+  return a;
 }
 extern "C" int pdae_set_gemm_arith(int arith) {
   if (arith != PDAE_GEMM_F32MFMA && arith != PDAE_GEMM_BF16X3) return bad_arg("set_gemm_arith: PDAE_GEMM_F32MFMA or PDAE_GEMM_BF16X3");
-  g_arith = arith;
+  ctx_gemm_arith() = arith;
   return PDAE_OK;
 }
 extern "C" int pdae_gemm_arith(void) { return gemm_arith(); }

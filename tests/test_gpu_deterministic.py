@@ -350,3 +350,64 @@ def test_graphed_step_gradients_equal_eager_gradients(mode):
     finally:
         if mode == 'deterministic':
             _lib.set_deterministic(False)
+
+
+def test_two_threads_two_streams_two_contexts():
+    """include/pdae.h contexts: the library's mutable state (deterministic workspace, GEMM arithmetic, parked
+    reductions) belongs to the calling thread's current context.  Two host threads, each on its own stream and its
+    own context -- one deterministic on the fp32-input kernels, one atomic on the exact-split kernels -- run the
+    embedder's statistics reductions, a grouped weight gradient and a row GEMM at the same time: each sees its own
+    settings throughout, the deterministic thread's results are bit-identical to a single-threaded deterministic run,
+    and the default context is untouched.  (Forward and direct calls only: autograd runs backward nodes on ITS thread,
+    which is on the default context unless told otherwise -- INTEGRATION.md.)"""
+    import threading
+    from point_dae_amd import _lib, nn_ops
+    from point_dae_amd.patch_embed import patch_embed
+    first0, second0 = _embedder(1)
+    torch.manual_seed(3)
+    pts = torch.randn(64 * 32, 32, 3, device='cuda') * 0.2
+    w = torch.randn(1152, 384, device='cuda') / 20
+    a = torch.randn(3584, 384, device='cuda')
+    dy = torch.randn(3584, 1152, device='cuda')
+    torch.cuda.synchronize()
+
+    def work(ctx_det, arith, out, rounds):
+        stream = torch.cuda.Stream()
+        ctx = _lib.Context()
+        first, second = copy.deepcopy(first0), copy.deepcopy(second0)
+        try:
+            with torch.cuda.stream(stream), ctx, torch.no_grad():
+                if ctx_det:
+                    ctx.set_deterministic(64)
+                _lib.lib().pdae_set_gemm_arith(arith)
+                seen = []
+                for _ in range(rounds):
+                    seen.append((_lib.deterministic(), _lib.gemm_arith(), _lib.rows_gemm_plan(3584, 1152, 384, False, False)[0] >= 16))
+                    y = patch_embed(pts, first, second, True)
+                    z = nn_ops.rows_gemm(a, w)
+                    dws, dbs = nn_ops.rows_wgrad([dy], [a], [True])
+                out.update(seen=seen, y=y.clone(), z=z.clone(), dw=dws[0].clone(), db=dbs[0].clone(),
+                           rm=second[1].running_mean.clone())
+                stream.synchronize()
+        except Exception as e:          # surfaced by the main thread
+            out['error'] = e
+        finally:
+            ctx.close()
+
+    single = {}
+    work(True, _lib.GEMM_F32MFMA, single, 6)
+    assert 'error' not in single, single.get('error')
+    before = (_lib.deterministic(), _lib.gemm_arith())
+    r1, r2 = {}, {}
+    t1 = threading.Thread(target=work, args=(True, _lib.GEMM_F32MFMA, r1, 6))
+    t2 = threading.Thread(target=work, args=(False, _lib.GEMM_BF16X3, r2, 6))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    for r in (r1, r2):
+        assert 'error' not in r, r.get('error')
+    assert all(s_ == (True, _lib.GEMM_F32MFMA, False) for s_ in r1['seen']), r1['seen']
+    assert all(s_ == (False, _lib.GEMM_BF16X3, True) for s_ in r2['seen']), r2['seen']
+    for k in ('y', 'z', 'dw', 'db', 'rm'):
+        assert torch.equal(r1[k], single[k]), k
+    assert (r2['z'] - r1['z']).abs().max().item() <= 2e-6 * r1['z'].abs().max().item()
+    assert (_lib.deterministic(), _lib.gemm_arith()) == before
+    assert _lib.lib().pdae_ctx_current() is None
