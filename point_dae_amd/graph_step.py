@@ -26,12 +26,10 @@ from .point_cae_transformer import draw_mask, mask_row_ids
 def use_created_stream(device=None):
     """Make a created (non-NULL) stream the current stream of this thread and return it.
 
-    Call once before building a graphed step.  On this platform work issued into the legacy NULL
-    stream while captured step graphs exist -- a checkpoint's device-to-host copies, a clone -- makes
-    every later replay at B = 128 return garbage (tools/soak.py, tools/dbg_graph_poke.py: losses of
-    ~700 instead of 0.1 from the next replay on), whether the replays themselves run on the NULL
-    stream or not; with ONE created stream for everything the same sequences are fine.  Eager
-    launches are not affected."""
+    Call once before building a graphed step.  Up to round 3 a device-to-host copy on the legacy NULL
+    stream (a checkpoint) made later replays sporadically return garbage; the round-4 bisection
+    shows a replay-ordering race that the step's current graph no longer triggers, not a corrupted pool --
+    one created stream for everything remains the rule because it costs nothing."""
     s = torch.cuda.Stream(device)
     s.wait_stream(torch.cuda.current_stream(device))
     torch.cuda.set_stream(s)

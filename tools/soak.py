@@ -41,6 +41,13 @@ for i in range(steps):
         if POKE == 'pinned': z = torch.empty(model.flat_param.shape, pin_memory=True); z.copy_(model.flat_param); torch.cuda.synchronize()
         if POKE == 'other': z = torch.zeros(29000000, device=dev).cpu()
         if POKE == 'sync': torch.cuda.synchronize()
+        if POKE == 'nullcpu':
+            with torch.cuda.stream(torch.cuda.default_stream()): z = model.flat_param.cpu()
+        if POKE == 'nullkernel':
+            with torch.cuda.stream(torch.cuda.default_stream()): z = torch.zeros(1 << 20, device=dev) + 1
+        if POKE == 'nullkernel_sync':
+            with torch.cuda.stream(torch.cuda.default_stream()): z = torch.zeros(1 << 20, device=dev) + 1
+            torch.cuda.synchronize()
         if POKE == 'sleep': import time; time.sleep(2)
         if POKE == 'alloc': z = torch.empty(1 << 28, device=dev); del z
         if POKE == 'empty': torch.cuda.empty_cache()
