@@ -923,7 +923,7 @@ int rows_wgrad_flush(hipStream_t) { return PDAE_OK; }
 
 extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats) {
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !Ns || !Ks || !floats) return bad_arg("rows_wgrad_multi_workspace: bad argument");
-  static WgradArgs g;                      // (3 KB: off the stack; host-side query, one thread at a time like the plan cache)
+  static thread_local WgradArgs g;         // (3 KB: off the stack)
   const int tn = wgrad_tile_width(nprob, Ks);
   int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn);
   if (rc) return rc;
