@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
   for (; u < uend; slot += WSLOT) {
     const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
     const long long rel = u - P.unit0;
-    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int lt = P.lt0 + (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
     const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
     u += c1 - c0;
     const int bx = lt % P.tk, by = lt / P.tk;

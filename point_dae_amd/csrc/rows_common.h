@@ -48,6 +48,7 @@ struct WgradProb {
   int tk;             // tiles along K
   int tile0;          // first tile of this problem in the group
   int M, chunks;      // rows of this problem, 32-row chunks per tile
+  int lt0;            // this launch covers the problem's tiles lt0 .. (a group split over two launches; else 0)
   long long unit0;    // first unit of this problem
 };
 struct WgradArgs {
@@ -108,8 +109,8 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradArgs& g, int block)
   __shared__ float4 redb[PL > 1 ? PL : 1][WTM / 4];
   const int tile = block / PARTS, part = block % PARTS;
   const WgradProb& P = g.p[wg_prob_of_tile(g, tile)];
-  const int lt = tile - P.tile0;
-  const int bx = lt % P.tk, by = lt / P.tk;
+  const int lt = tile - P.tile0;                     // within this launch's share of the problem
+  const int bx = (lt + P.lt0) % P.tk, by = (lt + P.lt0) / P.tk;
   const int n0 = by * WTM, k0 = bx * TN;
   // blocks whose ranges meet this tile's units
   const long long u0 = P.unit0 + (long long)lt * P.chunks, u1 = u0 + P.chunks - 1;

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(const WgradArgs g) {
   for (; u < uend; slot += WSLOT) {
     const WgradProb& P = g.p[wg_prob_of_unit(g, u)];
     const long long rel = u - P.unit0;
-    const int lt = (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int lt = P.lt0 + (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
     const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
     u += c1 - c0;
     const int bx = lt % P.tk, by = lt / P.tk;
@@ -873,8 +873,12 @@ static int wgrad_tile_width(int nprob, const int* Ks) {
   return w384 ? 384 : (w256 ? 256 : 128);
 }
 
-static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g, int WTN) {
-  int tiles = 0;
+// Work layout of a grouped launch.  first / count: the window of the group's tiles (in the order of the problems, tiles
+// of a problem in (by, bx) order) this launch covers (count < 0: all); whole: one block per tile instead of equal unit
+// ranges over one residency of the chip (every problem must then have the same row count).
+static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, WgradArgs* g, int WTN, int first = 0,
+                        int count = -1, bool whole = false) {
+  int tiles = 0, seen = 0;
   long long units = 0;
   for (int q = 0; q < nprob; ++q) {
     if (Ns[q] <= 0 || Ks[q] <= 0 || Ns[q] % 4 != 0 || Ks[q] % 4 != 0)
@@ -886,17 +890,30 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
     P.tile0 = tiles;
     P.chunks = (Ms[q] + WCH - 1) / WCH;
     P.unit0 = units;
-    const int t = ((Ns[q] + WTM - 1) / WTM) * P.tk;
-    tiles += t;
-    units += (long long)t * P.chunks;
+    const int all = ((Ns[q] + WTM - 1) / WTM) * P.tk;
+    int lo = first - seen, hi = count < 0 ? all : first + count - seen;
+    lo = lo < 0 ? 0 : (lo > all ? all : lo);
+    hi = hi < lo ? lo : (hi > all ? all : hi);
+    P.lt0 = lo;
+    seen += all;
+    tiles += hi - lo;
+    units += (long long)(hi - lo) * P.chunks;
   }
   g->nprob = nprob, g->tiles = tiles, g->units = units;
+  if (whole) {                                    // a block per tile: ranges b units / blocks are whole tiles (equal chunks)
+    g->blocks = tiles, g->slots = 1;
+    return PDAE_OK;
+  }
   // one residency of the chip: 256 CUs x 2 blocks of 4 waves (128-wide tiles), x 1 block of 8 waves (384-wide)
   int wg_blocks = (WTN >= 256 || arith_of(true) == PDAE_GEMM_BF16X3) ? 256 : 512;   // (the exact-split kernel: 8 waves, 122 KB of LDS)
   // (lab) PDAE_WGRAD_BPT=k: k blocks per output tile instead of one residency of the chip
   static const int bpt = getenv("PDAE_WGRAD_BPT") ? atoi(getenv("PDAE_WGRAD_BPT")) : 0;
   if (bpt > 0) wg_blocks = (bpt * tiles + 7) / 8 * 8;
   g->blocks = (int)(units < wg_blocks ? units : wg_blocks);
+  if (g->blocks == 0) {
+    g->slots = 1;
+    return PDAE_OK;
+  }
   // slots per block: the most tiles one block's unit range touches (ranges are [b units / B, (b + 1) units / B))
   auto tile_of = [&](long long u) {
     int pi = 0;
@@ -916,6 +933,24 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
   return PDAE_OK;
 }
 
+// A stack's grouped launch as TWO launches when its tiles fill the chip several times over (exact-split kernel, every
+// layer with the same rows): the first `head` tiles -- whole rounds of one tile per block, in tile order -- and the rest
+// as equal unit ranges.  With a block per tile the 32 blocks an XCD runs at a time work on CONSECUTIVE tiles of one
+// layer, which share their dY band (same by) or their X band (same bx) and stream them in step: the bands come out of
+// that XCD's L2 instead of crossing the fabric once per tile (contiguous ranges put the concurrent blocks ~5 tiles
+// apart: 3.7 GB per encoder-stack launch against 1.06 GB of operands, profiles/pmc_r04.json).
+static int wgrad_head_tiles(int nprob, const int* Ms, const int* Ns, const int* Ks, int WTN) {
+  static const char* off = getenv("PDAE_WGRAD_SPLIT");        // lab: 0 switches the two-launch schedule off
+  if ((off && atoi(off) == 0) || arith_of(true) != PDAE_GEMM_BF16X3) return 0;
+  long long tiles = 0;
+  for (int q = 0; q < nprob; ++q) {
+    if (Ms[q] != Ms[0] || Ns[q] <= 0 || Ks[q] <= 0) return 0;
+    tiles += (long long)((Ns[q] + WTM - 1) / WTM) * ((Ks[q] + WTN - 1) / WTN);
+  }
+  const int rounds = (int)(tiles / 256);
+  return rounds >= 1 && tiles >= 384 ? rounds * 256 : 0;
+}
+
 namespace pdae {
 // (the weight-gradient reductions are no longer parked: a step's grouped launches are few and large)
 int rows_wgrad_flush(hipStream_t) { return PDAE_OK; }
@@ -925,9 +960,10 @@ extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const i
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !Ns || !Ks || !floats) return bad_arg("rows_wgrad_multi_workspace: bad argument");
   static thread_local WgradArgs g;         // (3 KB: off the stack)
   const int tn = wgrad_tile_width(nprob, Ks);
-  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn);
+  const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn, head);
   if (rc) return rc;
-  *floats = (long long)g.blocks * g.slots * wslot(tn);
+  *floats = ((long long)head + (long long)g.blocks * g.slots) * wslot(tn);
   return PDAE_OK;
 }
 
@@ -955,14 +991,28 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !dY || !X || !dW || !Ns || !Ks) return bad_arg("rows_wgrad_multi: bad argument");
   WgradArgs g = {};
   const int tn = wgrad_tile_width(nprob, Ks);
-  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn);
-  if (rc) return rc;
-  for (int q = 0; q < nprob; ++q) {
+  const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
+  for (int q = 0; q < nprob; ++q)
     if (!dW[q] || !dY[q] || !X[q]) return bad_arg("rows_wgrad_multi: null pointer");
-    g.p[q].dY = dY[q], g.p[q].X = X[q], g.p[q].dW = dW[q], g.p[q].db = db ? db[q] : nullptr;
-  }
   if (!workspace) return bad_arg("rows_wgrad_multi: null workspace");
   hipStream_t s = as_stream(stream);
+  auto bind = [&](WgradArgs& a) {
+    for (int q = 0; q < nprob; ++q)
+      a.p[q].dY = dY[q], a.p[q].X = X[q], a.p[q].dW = dW[q], a.p[q].db = db ? db[q] : nullptr;
+  };
+  if (head > 0) {                          // whole rounds of one tile per block first (wgrad_head_tiles)
+    WgradArgs a = {};
+    int rc = wgrad_layout(nprob, Ms, Ns, Ks, &a, tn, 0, head, true);
+    if (rc) return rc;
+    bind(a);
+    a.partials = workspace;
+    rows3::launch_wgrad3(a, tn, 1, s);
+    workspace += (size_t)head * wslot(tn);
+  }
+  int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn, head);
+  if (rc) return rc;
+  if (g.tiles == 0) return check_launch("rows_wgrad_multi");
+  bind(g);
   g.partials = workspace;
   // partial lanes of the reduction by the most partials a tile can have: the longest reduction spans the most
   // blocks, the block ranges are units / blocks long
