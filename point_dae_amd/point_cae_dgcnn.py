@@ -24,7 +24,6 @@ The whole encoder is ONE autograd node (_Encoder): forward and backward are expl
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, nn_ops
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
