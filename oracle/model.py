@@ -524,6 +524,49 @@ def dropout_global_random(pointcloud, drop_rate=0.5):
     return pointcloud[:, :int(num_points * (1 - drop_rate)), :].contiguous()
 
 
+def dropout_patch_random(pc_tensor, level=None):
+    """datasets/corrupt_util.py:900-924: 64 FPS centres, their 32 nearest points, a random subset of the patches kept
+    (python random.random for the level, one CPU torch.rand(64) for the mask; at least one patch)."""
+    import random
+    if level is None:
+        level = random.random() * 4
+    prob = level / 10.0 + 0.5
+    batch_size, num_points, _ = pc_tensor.shape
+    x = _np(pc_tensor[:, :, :3].contiguous())
+    _, center = O.furthest_point_sample(x, 64, return_centres=True)
+    _, idx = O.knn(x, center, 32)
+    idx = torch.from_numpy(idx) + torch.arange(0, batch_size).view(-1, 1, 1) * num_points
+    neighborhood = pc_tensor[:, :, :3].reshape(batch_size * num_points, -1)[idx.view(-1), :].view(batch_size, 64, 32, 3)
+    group_mask = torch.rand(64) > prob
+    if group_mask.sum().item() == 0:
+        group_mask[0] = True
+    return neighborhood[:, group_mask].reshape(batch_size, -1, 3).contiguous()
+
+
+def corrupt_in_forward(corrupted_pts, corrupt_type, items):
+    """The forward-side dispatch of models/PointCAE_pointnetv2.py:143-149 and models/PointCAE_DGCNN.py:198-221."""
+    import random
+    for item in corrupt_type:
+        if item not in items:
+            continue
+        if item == 'dropout_patch_pointmae':
+            corrupted_pts = dropout_patch_random(corrupted_pts)
+        elif item == 'dropout_global':
+            corrupted_pts = dropout_global_random(corrupted_pts)
+        elif item.startswith('dropout_global_p'):
+            corrupted_pts = dropout_global_random(corrupted_pts, drop_rate=int(item[-1]) / 10.0)
+        elif item == 'random_dropout':
+            if random.random() > 0.5:
+                corrupted_pts = dropout_patch_random(corrupted_pts)
+            else:
+                corrupted_pts = dropout_global_random(corrupted_pts)
+    return corrupted_pts
+
+
+IN_FORWARD = ('dropout_patch_pointmae', 'dropout_global', 'dropout_global_p1', 'dropout_global_p3', 'dropout_global_p5',
+              'dropout_global_p7', 'dropout_global_p9', 'random_dropout')
+
+
 class Point_CAE_PointNetv2(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -546,11 +589,8 @@ class Point_CAE_PointNetv2(nn.Module):
     def forward(self, corrupted_pts, pts, capture=None, **kwargs):
         corrupted_pts = corrupted_pts[:, :, :3].contiguous()
         pts = pts[:, :, :3].contiguous()
-        for item in self.corrupt_type:                 # only the CUDA-side dropouts act here (:144-149)
-            if item == 'dropout_global':
-                corrupted_pts = dropout_global_random(corrupted_pts)
-            elif item == 'dropout_patch_pointmae':
-                raise NotImplementedError(item)
+        # only the CUDA-side dropouts act here (:144-149)
+        corrupted_pts = corrupt_in_forward(corrupted_pts, self.corrupt_type, ('dropout_patch_pointmae', 'dropout_global'))
         feature = self.pointnetv2_encoder(corrupted_pts)
         B = pts.shape[0]
         coarse = self.folding1(feature).view(-1, self.num_coarse, 3)
@@ -624,6 +664,7 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
         if return_feat:
             return self.dgcnn_encoder(pts[:, :, :3].transpose(1, 2).contiguous())
         corrupted_pts, pts = corrupted_pts[:, :, :3].contiguous(), pts[:, :, :3].contiguous()
+        corrupted_pts = corrupt_in_forward(corrupted_pts, self.corrupt_type, IN_FORWARD)        # (:198-221)
         feature = self.dgcnn_encoder(corrupted_pts.transpose(1, 2).contiguous())
         coarse = self.recfc(feature).view(-1, self.num_coarse, 3)
         loss = self.loss_func(coarse, pts)

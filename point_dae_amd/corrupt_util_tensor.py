@@ -111,3 +111,63 @@ def corrupt_data(neighborhood, center, type=['clean']):
     rel = (neighborhood - center.unsqueeze(2)).contiguous()
     _, t_nb, t_c = corrupt_patches(rel, center.contiguous(), steps)
     return t_nb + t_c.unsqueeze(2), t_c
+
+
+# ---- whole-cloud dropouts that the non-Transformer models apply inside forward() -------------------------------
+# (datasets/corrupt_util.py:572-588, :900-924; dispatched by models/PointCAE_pointnetv2.py:143-149 and
+# models/PointCAE_DGCNN.py:198-221).  The random draws are the reference's host calls in its order (python `random`,
+# the CPU torch generator), so a run seeded like the reference keeps the same points; FPS / kNN run on the gfx950
+# kernels.  A model that applies one of these must be stepped eagerly (`draws_in_forward`): a captured graph would
+# replay one frozen draw -- and the surviving point count changes from step to step.
+IN_FORWARD = ('dropout_patch_pointmae', 'dropout_global', 'dropout_global_p1', 'dropout_global_p3', 'dropout_global_p5',
+              'dropout_global_p7', 'dropout_global_p9', 'random_dropout')
+
+
+def dropout_global_random(pointcloud, drop_rate=0.5):
+    """A random (1 - drop_rate) share of every cloud: one CPU torch.rand per batch, argsort, take (:572-588)."""
+    num_samples, num_points = pointcloud.size(0), pointcloud.size(1)
+    inx = torch.rand(num_samples, num_points, 1).argsort(1).to(pointcloud.device)
+    pointcloud = torch.take_along_dim(pointcloud, inx, dim=1)
+    return pointcloud[:, :int(num_points * (1 - drop_rate)), :].contiguous()
+
+
+def dropout_patch_random(pc_tensor, level=None):
+    """Point-MAE style patch dropout (:900-924): 64 FPS centres, their 32 nearest points each, a random subset of the
+    64 patches kept (each with probability 1 - prob, prob = level / 10 + 0.5, level ~ U[0, 4); at least one) ->
+    (B, kept * 32, 3) absolute coordinates (points shared by kept patches appear more than once, as in the reference)."""
+    from .knn_cuda import knn
+    from .pointnet2_utils import furthest_point_sample_with_centres
+    if level is None:
+        level = random.random() * 4
+    prob = level / 10.0 + 0.5
+    batch_size, num_points, _ = pc_tensor.shape
+    xyz = pc_tensor[:, :, :3].contiguous()
+    _, center = furthest_point_sample_with_centres(xyz, 64)
+    _, idx = knn(xyz, center, 32)                                            # (B, 64, 32)
+    idx = (idx + torch.arange(0, batch_size, device=pc_tensor.device).view(-1, 1, 1) * num_points).view(-1)
+    neighborhood = xyz.view(batch_size * num_points, -1)[idx, :].view(batch_size, 64, 32, 3)
+    group_mask = torch.rand(64) > prob
+    if group_mask.sum().item() == 0:
+        group_mask[0] = True
+    neighborhood = neighborhood[:, group_mask.to(pc_tensor.device)]
+    return neighborhood.reshape(batch_size, -1, 3).contiguous()
+
+
+def corrupt_in_forward(corrupted_pts, corrupt_type, items=IN_FORWARD):
+    """The forward-side dispatch of the two models: every item of `corrupt_type` that is one of `items` acts on the
+    (B, N, 3) cloud in list order; everything else was applied by the data loader."""
+    for item in corrupt_type:
+        if item not in items:
+            continue
+        if item == 'dropout_patch_pointmae':
+            corrupted_pts = dropout_patch_random(corrupted_pts)
+        elif item == 'dropout_global':
+            corrupted_pts = dropout_global_random(corrupted_pts)
+        elif item.startswith('dropout_global_p'):
+            corrupted_pts = dropout_global_random(corrupted_pts, drop_rate=int(item[-1]) / 10.0)
+        elif item == 'random_dropout':
+            if random.random() > 0.5:
+                corrupted_pts = dropout_patch_random(corrupted_pts)
+            else:
+                corrupted_pts = dropout_global_random(corrupted_pts)
+    return corrupted_pts

@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import _lib, nn_ops
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from .corrupt_util_tensor import IN_FORWARD, corrupt_in_forward
 from .patch_embed import _bn_finalize
 from .registry import MODELS
 
@@ -202,6 +203,12 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
         self.loss = config.loss
         self.build_loss_func(self.loss)
 
+    @property
+    def draws_in_forward(self):
+        """True when forward() draws random numbers on the host (the in-forward dropouts): such a step must not be
+        captured into a hipGraph (graph_step.GraphedStaticStep refuses it)."""
+        return any(item in IN_FORWARD for item in self.corrupt_type)
+
     def build_loss_func(self, loss_type):
         if loss_type == 'cdl1':
             self.loss_func = ChamferDistanceL1()
@@ -214,10 +221,8 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
         nn_ops.begin_step(pts.device)
         if return_feat:
             return self.dgcnn_encoder.forward_rows(pts[:, :, :3])
-        for item in self.corrupt_type:
-            if item == 'dropout_patch_pointmae' or item.startswith('dropout_global') or item == 'random_dropout':
-                raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
         corrupted_pts, pts = corrupted_pts[:, :, :3].contiguous(), pts[:, :, :3].contiguous()
+        corrupted_pts = corrupt_in_forward(corrupted_pts, self.corrupt_type)      # (:198-221: the CUDA-side dropouts)
         feature = self.dgcnn_encoder.forward_rows(corrupted_pts)
         r = self.recfc
         coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(feature, r[0], 'relu'), r[2], 'relu'), r[4])

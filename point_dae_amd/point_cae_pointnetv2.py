@@ -28,6 +28,7 @@ import torch.nn.functional as F
 
 from . import _lib, nn_ops, sa_mlp
 from .chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from .corrupt_util_tensor import corrupt_in_forward
 from .pointnet2_utils import ball_query, furthest_point_sample_with_centres
 from .registry import MODELS
 
@@ -194,16 +195,8 @@ class Point_CAE_PointNetv2(nn.Module):
         nn_ops.begin_step(pts.device)
         corrupted_pts = corrupted_pts[:, :, :3].contiguous()
         pts = pts[:, :, :3].contiguous()
-        B0 = pts.shape[0]
-        for item in self.corrupt_type:
-            if item == 'dropout_global':
-                # dropout_global_random (datasets/corrupt_util.py:572-588): a random half of every cloud; the
-                # reference draws torch.rand on the CPU and sorts there -- the same call keeps the same subset
-                n = corrupted_pts.shape[1]
-                inx = torch.rand(B0, n, 1).argsort(1).to(corrupted_pts.device)
-                corrupted_pts = torch.take_along_dim(corrupted_pts, inx, dim=1)[:, :int(n * 0.5), :].contiguous()
-            elif item == 'dropout_patch_pointmae':
-                raise NotImplementedError("in-forward corruption %r is outside the benchmarked path" % item)
+        # the CUDA-side dropouts of the reference's forward (:143-149); everything else came from the loader
+        corrupted_pts = corrupt_in_forward(corrupted_pts, self.corrupt_type, ('dropout_patch_pointmae', 'dropout_global'))
         B = pts.shape[0]
         feature = self.pointnetv2_encoder(corrupted_pts)                       # (B, 1024)
         f1 = self.folding1

@@ -92,6 +92,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
     # the step is replayed as hipGraphs (graph_step.py); eager launches only as a fallback
     # for configurations the graphed steps do not cover
     from .graph_step import GraphedStaticStep, GraphedTrainStep
+    from .point_cae_dgcnn import Point_CAE_DGCNN_FCOnly
     from .point_cae_pointnetv2 import Point_CAE_PointNetv2
     from .point_cae_transformer import PointCAE_transformer
     bs = ds_cfg['bs']
@@ -104,7 +105,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         # scalar, the un-masked model, gradient accumulation
         graphed = GraphedTrainStep(model, optimizer, config, bs, config.npoints, step_per_update=spu)
         step_fn = lambda corrupted, clean: graphed(clean)   # noqa: E731  (corrupted input unused on this path)
-    elif isinstance(base_model, Point_CAE_PointNetv2) and not base_model.draws_in_forward:
+    elif isinstance(base_model, (Point_CAE_PointNetv2, Point_CAE_DGCNN_FCOnly)) and not base_model.draws_in_forward:
         w = float(config.normal_weight)
         mixes = {'xyz': lambda a, b: a, 'normal': lambda a, b: w * b, 'xyznormal': lambda a, b: a + w * b,
                  'xyznormal_gradual': lambda a, b: a + w * b * gw_dev, 'xyznormal_warm': lambda a, b: a + w * b * gw_dev}
@@ -112,7 +113,7 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         step_fn = graphed
     else:
         # a model that draws a corruption on the host inside forward (`dropout_global`) cannot be captured -- the
-        # draw would be frozen into the graph -- and models without a graphed step (DGCNN) step eagerly
+        # draw would be frozen into the graph, and the surviving point count changes from step to step
         step_fn = None
     if rank == 0:
         log('step: %s' % ('eager' if step_fn is None else 'hipGraph replay (%s, step_per_update %d, loss_type %s)' % (

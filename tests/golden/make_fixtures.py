@@ -132,11 +132,12 @@ def pointnetv2_fixture(name, B, seed, corrupt_type=None):
     for lvl, sa in enumerate((enc.sa1, enc.sa2, enc.sa3)):
         sa.mlps[0].register_forward_hook(
             lambda m, i, o, lvl=lvl: cap.update({'arg%d' % lvl: o.detach().argmax(dim=3)}))      # (B, C, npoint)
-    torch.manual_seed(seed + 7)
+    import random
+    random.seed(seed + 7), torch.manual_seed(seed + 7)
     l_coarse, l_fine = ref(corrupted, clean)
     (l_coarse + 0.5 * l_fine).backward()
     orc = fill_state(OM.Point_CAE_PointNetv2(cfg), seed).train()
-    torch.manual_seed(seed + 7)
+    random.seed(seed + 7), torch.manual_seed(seed + 7)
     o1, o2 = orc(corrupted, clean)
     assert o1.item() == l_coarse.item() and o2.item() == l_fine.item(), (o1.item(), l_coarse.item())
     out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
@@ -161,8 +162,10 @@ def pointnetv2_fixture(name, B, seed, corrupt_type=None):
     print(name, 'loss', l_coarse.item(), l_fine.item(), 'size %.0f KB' % (os.path.getsize(path) / 1024))
 
 
-def dgcnn_fixture(name, B, seed):
-    """Point_CAE_DGCNN_FCOnly (the published non-Transformer model), B=2, N=1024."""
+def dgcnn_fixture(name, B, seed, corrupt_type=None):
+    """Point_CAE_DGCNN_FCOnly (the published non-Transformer model), B=2, N=1024.  corrupt_type: an in-forward
+    corruption list (models/PointCAE_DGCNN.py:198-221); python's and torch's host generators are re-seeded with
+    seed + 7 right before each forward so that the draws (patch-drop level and mask, global-drop order) reproduce."""
     from easydict import EasyDict
     import yaml
     import models.PointCAE_DGCNN as M
@@ -170,6 +173,8 @@ def dgcnn_fixture(name, B, seed):
     from point_dae_amd.synthetic import shapenet_like_clouds
     cfg = EasyDict(yaml.safe_load(open(os.path.join(R.REF, 'cfgs/pretrain_PointCAE_clean.yaml')))['model'])
     cfg.NAME = 'Point_CAE_DGCNN_FCOnly'
+    if corrupt_type is not None:
+        cfg.corrupt_type = list(corrupt_type)
     R.seed_all(seed)
     ref = M.Point_CAE_DGCNN_FCOnly(cfg)
     ref.device = torch.device('cpu')
@@ -180,9 +185,12 @@ def dgcnn_fixture(name, B, seed):
     cap = {}
     ref.dgcnn_encoder.register_forward_hook(lambda m, i, o: cap.update(feature=o))
     ref.recfc.register_forward_hook(lambda m, i, o: cap.update(coarse=o))
+    import random
+    random.seed(seed + 7), torch.manual_seed(seed + 7)
     loss, loss2 = ref(corrupted, clean)
     (loss + 0.5 * loss2.sum()).backward()
     orc = fill_state(OM.Point_CAE_DGCNN_FCOnly(cfg), seed).train()
+    random.seed(seed + 7), torch.manual_seed(seed + 7)
     o1, o2 = orc(corrupted, clean)
     assert o1.item() == loss.item(), (o1.item(), loss.item())
     out = dict(seed=np.int64(seed), B=np.int64(B), clean=clean.numpy(), corrupted=corrupted.numpy(),
@@ -209,6 +217,14 @@ if __name__ == '__main__':
     R.cpu_cuda_noop()
     if len(sys.argv) > 1 and sys.argv[1] == 'dgcnn':
         dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dgcnn_dropout':
+        dgcnn_fixture('dgcnn_dropout_patch_b2.npz', 2, 33, ['dropout_patch_pointmae'])
+        dgcnn_fixture('dgcnn_dropout_global_p3_b2.npz', 2, 35, ['dropout_global_p3'])
+        dgcnn_fixture('dgcnn_random_dropout_b2.npz', 2, 37, ['random_dropout'])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'pointnetv2_dropout_patch':
+        pointnetv2_fixture('pointnetv2_dropout_patch_b2.npz', 2, 25, ['dropout_patch_pointmae'])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'dropout_global':
         pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])

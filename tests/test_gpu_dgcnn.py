@@ -85,7 +85,7 @@ def _edge_reference(x, idx, w, bn, training=True):
     return F.leaky_relu(y, 0.2).view(B * N, k, -1).max(dim=1)[0]
 
 
-@pytest.mark.parametrize('B,N', [(4, 256), (2, 1024), (3, 100), (32, 64)])
+@pytest.mark.parametrize('B,N', [(4, 256), (2, 1024), (3, 100), (32, 64), (2, 716), (5, 333)])
 def test_encoder_equals_the_dense_edge_formulation(B, N, monkeypatch):
     """The four EdgeConvs + conv5 pool through _Encoder's kernels vs the dense formulation on the same graphs: features,
     running estimates, and every gradient; gamma with positive, negative and zero entries (max / min / first edge)."""

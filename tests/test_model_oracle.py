@@ -154,3 +154,43 @@ def test_oracle_dgcnn_reproduces_reference_fixture():
     check_grads(model, fx, 2e-4, 'dgcnn')
     feat = model.eval()(None, torch.from_numpy(fx['clean']), return_feat=True)
     assert feat.shape == (int(fx['B']), 1024)
+
+
+@pytest.mark.parametrize('name,items', [('dgcnn_dropout_patch_b2.npz', ['dropout_patch_pointmae']),
+                                        ('dgcnn_dropout_global_p3_b2.npz', ['dropout_global_p3']),
+                                        ('dgcnn_random_dropout_b2.npz', ['random_dropout'])])
+def test_oracle_dgcnn_in_forward_dropouts(name, items):
+    """models/PointCAE_DGCNN.py:198-221: the dropouts applied inside forward (datasets/corrupt_util.py:572-588 random
+    share of every cloud, :900-924 Point-MAE style patch drop over 64 FPS centres x 32 neighbours) -- fixtures from the
+    live reference with python's and torch's host generators seeded seed + 7 right before the forward."""
+    import random
+    from oracle import model as OM
+    from point_dae_amd.config import cfg_from_yaml_file
+    fx = load_fixture(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_clean.yaml')).model
+    cfg.corrupt_type = list(items)
+    model = fill_state(OM.Point_CAE_DGCNN_FCOnly(cfg), int(fx['seed'])).train()
+    random.seed(int(fx['seed']) + 7), torch.manual_seed(int(fx['seed']) + 7)
+    loss, zero = model(torch.from_numpy(fx['corrupted']), torch.from_numpy(fx['clean']))
+    loss.backward()
+    assert abs(loss.item() - float(fx['loss'])) <= 1e-6 * abs(float(fx['loss']))
+    check_grads(model, fx, 2e-4, name)
+
+
+def test_oracle_pointnetv2_dropout_patch_fixture():
+    """models/PointCAE_pointnetv2.py:143-145: the patch drop inside Point_CAE_PointNetv2.forward (live fixture)."""
+    import random
+    from oracle import model as OM
+    from point_dae_amd.config import cfg_from_yaml_file
+    fx = load_fixture('pointnetv2_dropout_patch_b2.npz')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_clean.yaml')).model
+    cfg.corrupt_type = ['dropout_patch_pointmae']
+    model = fill_state(OM.Point_CAE_PointNetv2(cfg), int(fx['seed'])).train()
+    random.seed(int(fx['seed']) + 7), torch.manual_seed(int(fx['seed']) + 7)
+    lc, lf = model(torch.from_numpy(fx['corrupted']), torch.from_numpy(fx['clean']))
+    (lc + 0.5 * lf).backward()
+    assert abs(lc.item() - float(fx['loss_coarse'])) <= 1e-6 * abs(float(fx['loss_coarse']))
+    assert abs(lf.item() - float(fx['loss_fine'])) <= 1e-6 * abs(float(fx['loss_fine']))
+    check_grads(model, fx, 2e-4, 'pointnetv2 dropout_patch')
