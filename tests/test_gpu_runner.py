@@ -128,6 +128,20 @@ def test_main_cli_dropout_global_config_trains(tmp_path):
     assert 'step: eager' in r.stdout
 
 
+@pytest.mark.parametrize('items,how', [([], 'step: hipGraph'), (['random_dropout'], 'step: eager')])
+def test_main_cli_dgcnn_model(tmp_path, items, how):
+    """rerun.sh:37-40: the published non-Transformer runs are `--model_name Point_CAE_DGCNN_FCOnly` on a
+    PointNet++-style YAML.  Through main -> run_net the step replays as a hipGraph (static shapes, no host draws); with
+    an in-forward dropout in model.corrupt_type it is stepped eagerly (the surviving point count changes per step)."""
+    cfg = yaml.safe_load(open(CFG2))
+    cfg['model']['corrupt_type'] = list(items)
+    cfg['max_epoch'] = 1
+    r = _run_main(tmp_path, cfg, extra=('--model_name', 'Point_CAE_DGCNN_FCOnly'), steps=6)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert how in r.stdout, r.stdout[-1500:]
+    assert 'clouds/s' in r.stdout
+
+
 @pytest.mark.parametrize('variant', ['xyznormal_gradual', 'normal', 'nomask', 'accumulate'])
 def test_main_cli_graphs_every_branch(tmp_path, variant):
     """runner_pretrain.py:161-197: every loss_type, the un-masked model and step_per_update > 1 replay as hipGraphs
