@@ -2,7 +2,7 @@
 formulation written with framework ops in fp32 (models/dgcnn_util.py:7-34 knn / get_graph_feature, :99-136 the
 Conv2d -> BatchNorm2d -> LeakyReLU(0.2) -> max over the 20 neighbours of every EdgeConv, conv5's BatchNorm1d ->
 LeakyReLU -> max over the points).  Indices bit-exact (the selection is exact on the reference's expression); floating
-point 1e-5 relative on activations, 2e-4 relative L2 on gradients (fp32 sums in another order; tolerances in the tests).
+point 2e-5 relative on activations, 1e-3 relative L2 on gradients (typically 1e-5; tolerances and their reasons in the tests).
 The model-level fixture of the live reference is tests/test_gpu_model.py::test_dgcnn_product_model_reproduces_reference_fixture."""
 import numpy as np
 import pytest
@@ -123,7 +123,10 @@ def test_encoder_equals_the_dense_edge_formulation(B, N, monkeypatch):
     assert _rel(feat, want) <= 2e-5, _rel(feat, want)
     for (name, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
         assert p.grad is not None, name
-        assert _rel(p.grad, q.grad) <= 2e-4, (name, _rel(p.grad, q.grad))
+        # (typically 1e-5; the bound leaves room for LeakyReLU's kink: a winner whose pre-activation is within fp32
+        # rounding of 0 takes slope 1 in one computation and 0.2 in the other -- one such entry moves a BatchNorm bias
+        # gradient by 2-4e-4 of its norm; seen with PDAE_GEMM=f32mfma, whose products sit further from the fp64 ones)
+        assert _rel(p.grad, q.grad) <= 1e-3, (name, _rel(p.grad, q.grad))
     for (name, a), (_, b) in zip(enc.named_buffers(), ref.named_buffers()):
         if a.dtype.is_floating_point:
             assert torch.allclose(a, b.float(), rtol=1e-4, atol=1e-6), name
