@@ -241,6 +241,11 @@ if __name__ == '__main__':
         sys.exit(0)
     pointnetv2_fixture('pointnetv2_cfg1_b2.npz', 2, 21)
     pointnetv2_fixture('pointnetv2_dropout_global_b2.npz', 2, 23, ['dropout_global'])
+    pointnetv2_fixture('pointnetv2_dropout_patch_b2.npz', 2, 25, ['dropout_patch_pointmae'])
+    dgcnn_fixture('dgcnn_fconly_b2.npz', 2, 31)
+    dgcnn_fixture('dgcnn_dropout_patch_b2.npz', 2, 33, ['dropout_patch_pointmae'])
+    dgcnn_fixture('dgcnn_dropout_global_p3_b2.npz', 2, 35, ['dropout_global_p3'])
+    dgcnn_fixture('dgcnn_random_dropout_b2.npz', 2, 37, ['random_dropout'])
     transformer_fixture('transformer_folding_b2.npz', 2, 13, {'transformer_config.drop_path_rate': 0.0,
                         'transformer_config.depth': 4, 'transformer_config.decoder_depth': 2},
                         cls='PointCAE_transformer_fc_global_folding_local')
