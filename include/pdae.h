@@ -572,8 +572,10 @@ int pdae_rows_wgrad(int M, int nprob, const float* const* dY,
  * block order by the reduction launch that follows.  A step's backward thereby issues its blocks' weight gradients as
  * two large launches (decoder stack, encoder stack) instead of one small launch per block.  Output tiles: 128 x 128 on the
  * default exact-split arithmetic (pdae_set_gemm_arith below; two accumulator sets per tile); on the fp32-input kernels
- * 128 x 384 when every K of the group is a multiple of 384 (8 waves per block), 128 x 128 otherwise.  The workspace
- * queries answer for the arithmetic in force. */
+ * 128 x 384 when every K of the group is a multiple of 384 (8 waves per block), 128 x 128 otherwise.  On the exact-split
+ * arithmetic a group whose layers share their row count and whose tiles fill the chip more than once runs as whole
+ * rounds of ONE TILE PER BLOCK first (consecutive tiles together on an XCD, stored by their blocks: no partials) and the
+ * remaining tiles as above.  The workspace queries answer for the arithmetic in force. */
 int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const int* Ns, const int* Ks, long long* floats);
 /* One weight gradient dW[N,K] = sum_m dY[rowA(m)]^T x(X[rowB(m)]) with the patch embedder's operand forms (Encoder,
  * models/PointCAE_transformer.py:37-51; its conv layers' weight gradients, which autograd computes with cuDNN/cuBLAS in

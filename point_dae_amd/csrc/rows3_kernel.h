@@ -568,8 +568,25 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
       float* red = reinterpret_cast<float*>(lds3);     // [4 m-octets][TM]; the tile buffers are free now
       red[kg * TM + col] = asum;
       __syncthreads();
-      if (tid < TM) slot[TM * TN + tid] = (red[tid] + red[TM + tid]) + (red[2 * TM + tid] + red[3 * TM + tid]);
+      if (tid < TM) {
+        const float t = (red[tid] + red[TM + tid]) + (red[2 * TM + tid] + red[3 * TM + tid]);
+        if (!g.direct) slot[TM * TN + tid] = t;
+        else if (n0 + tid < P.N) P.db[n0 + tid] = t;
+      }
       __syncthreads();
+    }
+    if (g.direct) {                                    // this block summed the tile over ALL rows: the result, not a partial
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = n0 + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int cc = k0 + (wn * TJ + j) * 32 + r;
+            if (row < P.N && cc < P.K) P.dW[(size_t)row * P.K + cc] = hi[i][j][e] + lo[i][j][e];
+          }
+      continue;
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j)

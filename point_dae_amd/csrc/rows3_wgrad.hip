@@ -18,6 +18,7 @@ static void wgrad3_launch(const rows::WgradArgs& g, int pl, hipStream_t s) {
     once = true;
   }
   hipLaunchKernelGGL(k, dim3(g.blocks), dim3(512), lds, s, g);
+  if (g.direct) return;                              // whole tiles stored by their blocks: nothing to reduce
   if (pl == 1) hipLaunchKernelGGL((wgrad_reduce_kernel<1, TN>), dim3(g.tiles * PARTS1), dim3(256), 0, s, g);
   else if (pl == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, TN>), dim3(g.tiles * PARTSL * 4), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((wgrad_reduce_kernel<8, TN>), dim3(g.tiles * PARTSL * 8), dim3(256), 0, s, g);

@@ -53,6 +53,7 @@ struct WgradProb {
 };
 struct WgradArgs {
   int nprob, tiles, blocks, slots;              // grid; slots per block
+  int direct;                                   // 1: a block owns whole tiles and stores them (and the bias sums) itself: no partials
   long long units;
   float* partials;                              // [blocks][slots][wslot(TN)]
   // the embedder's forms (patch_embed.py; one problem per launch): whole 32-row groups gathered on either operand (row m

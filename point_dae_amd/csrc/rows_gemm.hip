@@ -963,7 +963,7 @@ extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const i
   const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
   int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn, head);
   if (rc) return rc;
-  *floats = ((long long)head + (long long)g.blocks * g.slots) * wslot(tn);
+  *floats = (long long)g.blocks * g.slots * wslot(tn);        // (the head tiles are stored by their blocks: no partials)
   return PDAE_OK;
 }
 
@@ -1005,9 +1005,8 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
     int rc = wgrad_layout(nprob, Ms, Ns, Ks, &a, tn, 0, head, true);
     if (rc) return rc;
     bind(a);
-    a.partials = workspace;
+    a.partials = workspace, a.direct = 1;  // (a block per tile: it stores the tile and the bias sums itself, no reduction pass)
     rows3::launch_wgrad3(a, tn, 1, s);
-    workspace += (size_t)head * wslot(tn);
   }
   int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn, head);
   if (rc) return rc;
