@@ -939,15 +939,36 @@ static int wgrad_layout(int nprob, const int* Ms, const int* Ns, const int* Ks, 
 // layer, which share their dY band (same by) or their X band (same bx) and stream them in step: the bands come out of
 // that XCD's L2 instead of crossing the fabric once per tile (contiguous ranges put the concurrent blocks ~5 tiles
 // apart: 3.7 GB per encoder-stack launch against 1.06 GB of operands, profiles/pmc_r04.json).
+// The layers of a group in launch order: those with the group's most frequent row count first (stable), the others
+// behind them -- the leading run is what wgrad_head_tiles can give whole rounds to (the decoder stack's last block runs
+// on the returned rows only and arrives FIRST in the backward's order).  Outputs are per layer: order changes nothing else.
+static void wgrad_order(int nprob, const int* Ms, int* perm) {
+  int mode = Ms[0], best = 0;
+  for (int q = 0; q < nprob; ++q) {
+    int c = 0;
+    for (int r = 0; r < nprob; ++r) c += Ms[r] == Ms[q];
+    if (c > best) best = c, mode = Ms[q];
+  }
+  int n = 0;
+  for (int q = 0; q < nprob; ++q)
+    if (Ms[q] == mode) perm[n++] = q;
+  for (int q = 0; q < nprob; ++q)
+    if (Ms[q] != mode) perm[n++] = q;
+}
+
 static int wgrad_head_tiles(int nprob, const int* Ms, const int* Ns, const int* Ks, int WTN) {
   static const char* off = getenv("PDAE_WGRAD_SPLIT");        // lab: 0 switches the two-launch schedule off
   if ((off && atoi(off) == 0) || arith_of(true) != PDAE_GEMM_BF16X3) return 0;
-  long long tiles = 0;
+  long long lead = 0, tiles = 0;
+  bool run = true;
   for (int q = 0; q < nprob; ++q) {
-    if (Ms[q] != Ms[0] || Ns[q] <= 0 || Ks[q] <= 0) return 0;
-    tiles += (long long)((Ns[q] + WTM - 1) / WTM) * ((Ks[q] + WTN - 1) / WTN);
+    if (Ns[q] <= 0 || Ks[q] <= 0) return 0;
+    const long long t = (long long)((Ns[q] + WTM - 1) / WTM) * ((Ks[q] + WTN - 1) / WTN);
+    run = run && Ms[q] == Ms[0];
+    if (run) lead += t;                                        // the leading layers that share their row count
+    tiles += t;
   }
-  const int rounds = (int)(tiles / 256);
+  const int rounds = (int)(lead / 256);
   return rounds >= 1 && tiles >= 384 ? rounds * 256 : 0;
 }
 
@@ -960,6 +981,10 @@ extern "C" int pdae_rows_wgrad_multi_workspace(int nprob, const int* Ms, const i
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !Ns || !Ks || !floats) return bad_arg("rows_wgrad_multi_workspace: bad argument");
   static thread_local WgradArgs g;         // (3 KB: off the stack)
   const int tn = wgrad_tile_width(nprob, Ks);
+  int perm[WG_MAX], Mp[WG_MAX], Np[WG_MAX], Kp[WG_MAX];
+  wgrad_order(nprob, Ms, perm);
+  for (int q = 0; q < nprob; ++q) Mp[q] = Ms[perm[q]], Np[q] = Ns[perm[q]], Kp[q] = Ks[perm[q]];
+  Ms = Mp, Ns = Np, Ks = Kp;
   const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
   int rc = wgrad_layout(nprob, Ms, Ns, Ks, &g, tn, head);
   if (rc) return rc;
@@ -991,14 +1016,18 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
   if (nprob <= 0 || nprob > WG_MAX || !Ms || !dY || !X || !dW || !Ns || !Ks) return bad_arg("rows_wgrad_multi: bad argument");
   WgradArgs g = {};
   const int tn = wgrad_tile_width(nprob, Ks);
-  const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
   for (int q = 0; q < nprob; ++q)
     if (!dW[q] || !dY[q] || !X[q]) return bad_arg("rows_wgrad_multi: null pointer");
   if (!workspace) return bad_arg("rows_wgrad_multi: null workspace");
+  int perm[WG_MAX], Mp[WG_MAX], Np[WG_MAX], Kp[WG_MAX];
+  wgrad_order(nprob, Ms, perm);
+  for (int q = 0; q < nprob; ++q) Mp[q] = Ms[perm[q]], Np[q] = Ns[perm[q]], Kp[q] = Ks[perm[q]];
+  Ms = Mp, Ns = Np, Ks = Kp;
+  const int head = wgrad_head_tiles(nprob, Ms, Ns, Ks, tn);
   hipStream_t s = as_stream(stream);
   auto bind = [&](WgradArgs& a) {
     for (int q = 0; q < nprob; ++q)
-      a.p[q].dY = dY[q], a.p[q].X = X[q], a.p[q].dW = dW[q], a.p[q].db = db ? db[q] : nullptr;
+      a.p[q].dY = dY[perm[q]], a.p[q].X = X[perm[q]], a.p[q].dW = dW[perm[q]], a.p[q].db = db ? db[perm[q]] : nullptr;
   };
   if (head > 0) {                          // whole rounds of one tile per block first (wgrad_head_tiles)
     WgradArgs a = {};
