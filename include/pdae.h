@@ -326,8 +326,9 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
  *   edge_weight_stack: ws (2 co, kp) = [W1; W2 - W1], zero-padded from cin to kp columns, from the Conv2d weight
  *                 w (co, 2 cin) = [W1 | W2] over cat(x_j - x_i, x_i); edge_weight_unstack: its transpose,
  *                 dw (co, 2 cin) = [dWs_top - dWs_bottom | dWs_bottom].
- *   gram_topk:    idx (b, n, k) int32, ids within the cloud: the k largest of pd[i][j] = (-xx_i + 2 g_ij) - xx_j
- *                 (dgcnn_util.knn's expression, each operation rounded), best first, the lower id on equal values;
+ *   gram_topk:    idx (b, n, k) int32, ids within the cloud: the k largest of pd[i][j] = (-xx_j + 2 g_ij) - xx_i
+ *                 (dgcnn_util.knn's expression -- xx (B, 1, N) broadcasts over the columns first -- each operation
+ *                 rounded), best first, the lower id on equal values;
  *                 gram (b, n, n) = X_b X_b^T from pdae_rows_gemm_batched.  k <= 64.
  *   knn_reverse:  the reverse graph: rev_start (b, n+1), rev_src (b, n k): the points that list point s as a
  *                 neighbour are rev_src[b][rev_start[b][s] .. rev_start[b][s+1]), ascending.  n <= 4096.

@@ -49,8 +49,9 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {   // unsigned order 
   const unsigned u = __float_as_uint(f);
   return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
 }
-// -pairwise_distance[i][j] of dgcnn_util.knn: pd = (-xx_i - inner) - xx_j with inner = -2 g, each operation rounded
-__device__ __forceinline__ float neg_pd(float g, float xi, float xj) { return xj - (2.0f * g - xi); }
+// -pairwise_distance[i][j] of dgcnn_util.knn (:8-10): xx is (B, 1, N), so `-xx - inner` broadcasts xx over the COLUMNS:
+// pd[i][j] = ((-xx_j) - inner_ij) - xx_i with inner = -2 g (an exact scaling), each subtraction rounded once
+__device__ __forceinline__ float neg_pd(float g, float xi, float xj) { return xi - (2.0f * g - xj); }
 
 // One wave per row: two passes over the (L2-resident) row.  Measured alternatives, both slower (76-81 against 66-69 us
 // at 32 x 1024^2): the row held in registers (one read, 16 more live registers), and four rows per wave (the

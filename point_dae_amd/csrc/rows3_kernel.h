@@ -33,6 +33,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK3 = 32;          // reduction depth of one staged tile (two 16-deep MFMA steps)
+#ifndef R3_FPS
+#define R3_FPS 3                 // fragment reads per slot behind a tile's barrier (lab: tools/lab/fps_sweep.sh)
+#endif
 
 // The split of eight fp32 (an octet: 8 k of one row) into three planes of eight bf16, x = h + m + l exactly, cut in
 // eight CHUNKS of 5-6 VALU instructions so that the main loop can place one chunk behind each MFMA: chunks 0-3 take
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
     };
     constexpr int S = 6 * G * KS;                             // slots (MFMAs) of a tile
-    constexpr int NR = (NF + 2) / 3;                          // slots behind the barrier: three fragment reads each
+    constexpr int NR = (NF + R3_FPS - 1) / R3_FPS;            // slots behind the barrier: R3_FPS fragment reads each
     constexpr int SB = S - NR;                                // the barrier sits behind slot SB - 1
     constexpr int NC = 8 * (OA + OB);                         // split chunks of a tile
     constexpr int SC = SB - 1 > 0 ? SB - 1 : 1;               // ... spread over slots [0, SC)
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
         if constexpr (s >= SB) {
           static_for<NF>([&](auto f_c) {
             constexpr int f = decltype(f_c)::value;
-            if constexpr (f / 3 == s - SB && !(ABL & 16))
+            if constexpr (f / R3_FPS == s - SB && !(ABL & 16))
               frag_one(f_c, std::integral_constant<int, (KS == 2 ? 0 : P ^ 1)>{}, P ^ 1, 0);
           });
         }
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
       if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
       else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
     };
-    constexpr int S = 12 * G, NR = (NF + 2) / 3, SB = S - NR, NC = 16, SC = SB - 1;
+    constexpr int S = 12 * G, NR = (NF + R3_FPS - 1) / R3_FPS, SB = S - NR, NC = 16, SC = SB - 1;
     auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
       constexpr int P2 = decltype(par_c)::value;
       using SetN = std::integral_constant<int, P2 ^ 1>;
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
         if constexpr (s >= SB) {
           static_for<NF>([&](auto f_c) {
             constexpr int f = decltype(f_c)::value;
-            if constexpr (f / 3 == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
+            if constexpr (f / R3_FPS == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
           });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
     if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
     else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
   };
-  constexpr int S = 12 * G, NR = (NF + 2) / 3, SB = S - NR, NC = 16, SC = SB - 1;
+  constexpr int S = 12 * G, NR = (NF + R3_FPS - 1) / R3_FPS, SB = S - NR, NC = 16, SC = SB - 1;
   auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
     constexpr int P2 = decltype(par_c)::value;
     using SetN = std::integral_constant<int, P2 ^ 1>;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
       if constexpr (s >= SB) {
         static_for<NF>([&](auto f_c) {
           constexpr int f = decltype(f_c)::value;
-          if constexpr (f / 3 == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
+          if constexpr (f / R3_FPS == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
         });
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -788,7 +788,10 @@ static void plan_rows3(int M, int N, int K, bool may_split, int* cfg, int* split
       if (t < best * 0.995) best = t, *cfg = rows3::CFG3_BASE + c, *splits = s;
     }
   if (fc >= 0) *cfg = rows3::CFG3_BASE + fc;
-  if (fs >= 1 && may_split) *splits = fs;
+  if (fs >= 1 && may_split) {                                  // (a forced split count still leaves every slab a tile)
+    while (fs > 1 && (long long)(fs - 1) * (((K + fs - 1) / fs + 31) / 32 * 32) >= K) --fs;
+    *splits = fs;
+  }
 }
 
 extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg, int* splits,
@@ -811,6 +814,12 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   const bool fam3 = cfg >= rows3::CFG3_BASE;
   if ((fam3 ? cfg - rows3::CFG3_BASE >= rows3::NCFG3 : cfg >= NCFG) || splits > 8 || splits == 0) return bad_arg("rows_gemm: bad plan");
   if (fam3 && !gemm3_takes(N, K, w_kn != 0)) return unsupported("rows_gemm: the exact-split bf16 tile shapes need K % 32 == 0");
+  if (fam3 && splits > 1) {
+    // every slab of the reduction needs at least one 32-deep tile: a block whose slab starts at or past K would index
+    // its loads from a negative tile count (the kernel clamps positions to KT - 1)
+    const int kchunk = ((K + splits - 1) / splits + 31) / 32 * 32;
+    if ((long long)(splits - 1) * kchunk >= K) return bad_arg("rows_gemm: more split-K slabs than 32-deep tiles of the reduction");
+  }
   if (cfg < 0 || splits < 0) {
     int c, s, b;
     if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, false, &c, &s, &b);

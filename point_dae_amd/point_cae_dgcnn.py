@@ -116,6 +116,7 @@ class _Encoder(torch.autograd.Function):
         _lib.call('pdae_bn_lrelu_rows', x, B, C5, _lib.ptr(ysel), _lib.ptr(sc5), _lib.ptr(sh5), _lib.ptr(feat), None, 0)
         ctx.layers, ctx.top = saved, (cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5)
         ctx.dims = (B, N, k)
+        ctx.training = bool(training)
         ctx.shapes = [c.shape for c in convs]
         return feat
 
@@ -133,6 +134,10 @@ class _Encoder(torch.autograd.Function):
         _lib.call('pdae_bn_lrelu_backward_reduce', dfeat, B, C5, _lib.ptr(dfeat), None, 0, _lib.ptr(ysel), _lib.ptr(sc5),
                   _lib.ptr(sh5), _lib.ptr(mean5), _lib.ptr(is5), _lib.ptr(g5), _lib.ptr(part), _lib.ptr(sums),
                   _lib.ptr(dgamma), _lib.ptr(dbeta))
+        if not ctx.training:
+            # eval-mode BatchNorm (running estimates): y = scale x + shift has no batch-statistic terms, so the c1 / c2
+            # corrections of the backward kernels (fed by `sums`) vanish: d x = scale dy at the winners
+            sums.zero_()
         dy5 = _empty((R, C5), dfeat)
         _lib.call('pdae_cloud_pool_backward', dfeat, B, N, C5, _lib.ptr(y5), _lib.ptr(g5), _lib.ptr(arow), _lib.ptr(sc5),
                   _lib.ptr(mean5), _lib.ptr(is5), _lib.ptr(sums), _lib.ptr(dy5))
@@ -150,6 +155,8 @@ class _Encoder(torch.autograd.Function):
             _lib.call('pdae_bn_lrelu_backward_reduce', dfeat, R, co, _lib.ptr(dx), dcat.data_ptr() + 4 * off, dcat.shape[1],
                       _lib.ptr(esel), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(g),
                       _lib.ptr(part), _lib.ptr(sums), _lib.ptr(dgamma), _lib.ptr(dbeta))
+            if not ctx.training:
+                sums.zero_()
             rev_start, rev_src = _empty((B, N + 1), dfeat, torch.int32), _empty((B, N * k), dfeat, torch.int32)
             _lib.call('pdae_knn_reverse', dfeat, B, N, k, _lib.ptr(idx), _lib.ptr(rev_start), _lib.ptr(rev_src))
             dpq = _empty((R, 2 * co), dfeat)

@@ -4,7 +4,7 @@ With the workspace registered every float-atomic reduction of the Transformer pr
 (batch-norm statistics, the embedder's weight / bias gradients, LayerNorm parameter gradients,
 column sums) becomes per-block partials + an ordered pass, so
   * the same launch twice gives the same bits,
-  * the hipGraph-replayed step equals the eager step to <= 1e-6 (in fact bit for bit),
+  * the hipGraph-replayed step equals the eager launch of the same step body bit for bit,
   * the visible-groups embedder path equals all-groups-then-select: forward bit for bit,
     gradients to <= 1e-5 in the max norm.
 The default (atomic) mode is held to the looser bounds in test_gpu_gemm.py / test_gpu_model.py.
@@ -164,15 +164,9 @@ def test_workspace_too_small_is_refused():
         _lib.set_deterministic(False)
 
 
-def test_graphed_step_equals_eager_step_exactly(det):
-    """hipGraph replays vs eager launches of the cfg3 optimisation step (FPS ... AdamW), six updates:
-    losses and every parameter agree to 1e-6 (bit for bit in practice) -- the atomic mode's 2e-3 /
-    2e-2 bounds in test_gpu_model.py are summation-order noise amplified by AdamW, nothing else."""
+def _six_updates_setup():
     from point_dae_amd import builder
     from point_dae_amd.config import cfg_from_yaml_file
-    from point_dae_amd.data_parallel import FlatDataParallel
-    from point_dae_amd.graph_step import GraphedTrainStep
-    from point_dae_amd.runner_pretrain import train_step
     from point_dae_amd.synthetic import shapenet_like_clouds
     config = cfg_from_yaml_file(os.path.join(
         ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
@@ -180,44 +174,70 @@ def test_graphed_step_equals_eager_step_exactly(det):
     config.model.transformer_config.depth = 3
     config.model.transformer_config.decoder_depth = 2
     torch.manual_seed(0)
-    net_a = builder.model_builder(config.model).cuda().train()
-    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    net = builder.model_builder(config.model).cuda().train()
     B = 16
     x = torch.from_numpy(shapenet_like_clouds(B * 2, 1024, seed=4)).cuda().split(B)
+    return config, net, B, x
 
-    def seed(s):
-        random.seed(s), np.random.seed(s), torch.manual_seed(s)
 
+def _seed(s):
+    random.seed(s), np.random.seed(s), torch.manual_seed(s)
+
+
+def test_graphed_step_equals_eager_step_exactly(det):
+    """hipGraph replays vs eager launches of THE SAME step body (the cfg3 optimisation step, FPS ... AdamW), six
+    updates: the same kernels in the same order on the same inputs, so every loss and every parameter agree BIT FOR
+    BIT -- the header's promise for the deterministic mode (the atomic mode's 2e-3 / 2e-2 bounds in test_gpu_model.py
+    are summation-order noise amplified by AdamW, nothing else)."""
+    from point_dae_amd import builder
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    config, net_a, B, x = _six_updates_setup()
+    net_b = copy.deepcopy(net_a)
     model_a = FlatDataParallel(net_a)
     opt_a, _ = builder.build_opti_sche(model_a, config)
     model_a.zero_grad()
-    # the SAME step body launched kernel by kernel (never captured) ...
+    # the step body launched kernel by kernel (never captured) ...
     eager_step = GraphedTrainStep(model_a, opt_a, config, B, 1024, warmup_eager=1000)
-    seed(123)
+    _seed(123)
     eager = [eager_step(x[i % 2])[0].item() for i in range(6)]
     assert not eager_step.graphs
     # ... against its hipGraph replays
     model_b = FlatDataParallel(net_b)
     opt_b, _ = builder.build_opti_sche(model_b, config)
     step = GraphedTrainStep(model_b, opt_b, config, B, 1024, warmup_eager=1)
-    seed(123)
+    _seed(123)
     graphed = [step(x[i % 2])[0].item() for i in range(6)]
     assert len(step.graphs) >= 1
-    for a, b in zip(eager, graphed):
-        assert abs(a - b) <= 1e-6 * abs(a), (eager, graphed)
-    # and the plain autograd path of runner_pretrain.train_step (its weight gradients are reduced per block, the
-    # graphed step's per stack: another fixed summation order, so equal to rounding -- amplified by six AdamW updates)
+    assert eager == graphed, (eager, graphed)
+    assert torch.equal(model_a.flat_param, model_b.flat_param)
+
+
+def test_plain_autograd_step_tracks_the_graphed_step_within_amplified_rounding(det):
+    """A TOLERANCE test, not an identity: runner_pretrain.train_step (plain autograd: weight gradients reduced per
+    block) against the graphed step (per stack) -- two fixed but DIFFERENT summation orders, so the first update agrees
+    to fp32 rounding and six AdamW updates amplify that.  Bound derived from the arithmetic: one update moves a weight
+    by lr = 1e-3 times a sign-like ratio m / sqrt(v), so a relative gradient difference of ~1e-6 (exact-split products,
+    fp64 BatchNorm sums) becomes ~1e-5 of the loss per update; measured 5.4e-5 at the sixth update, bound 1e-4."""
+    from point_dae_amd import builder
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.runner_pretrain import train_step
+    config, net_b, B, x = _six_updates_setup()
+    net_c = copy.deepcopy(net_b)
+    model_b = FlatDataParallel(net_b)
+    opt_b, _ = builder.build_opti_sche(model_b, config)
+    step = GraphedTrainStep(model_b, opt_b, config, B, 1024, warmup_eager=1)
+    _seed(123)
+    graphed = [step(x[i % 2])[0].item() for i in range(6)]
     model_c = FlatDataParallel(net_c)
     opt_c, _ = builder.build_opti_sche(model_c, config)
     model_c.zero_grad()
-    seed(123)
+    _seed(123)
     plain = [train_step(model_c, opt_c, config, x[i % 2], x[i % 2])[0].item() for i in range(6)]
-    # (round 4: 5.4e-5 at the sixth update with the BatchNorm-backward sums accumulated in fp64 and the weight gradients
-    # on exact-split bf16 -- both paths moved by their own rounding; the bound is on six updates of AdamW amplification)
+    assert abs(plain[0] - graphed[0]) <= 2e-6 * abs(plain[0]), (plain, graphed)       # before any update: rounding only
     for a, b in zip(plain, graphed):
         assert abs(a - b) <= 1e-4 * abs(a), (plain, graphed)
-    diff = (model_a.flat_param - model_b.flat_param).abs().max().item()
-    assert diff <= 1e-6 * model_a.flat_param.abs().max().item(), diff
 
 
 @pytest.mark.parametrize('name', ['PointCAE_transformer', 'PointCAE_transformer_fc_global_folding_local'])

@@ -39,7 +39,8 @@ def test_gram_topk_selects_the_reference_s_neighbours(B, N, C, k):
     L.call('pdae_rows_sqnorm', x, B * N, C, x.data_ptr(), xx.data_ptr())
     assert torch.allclose(xx, x.square().sum(-1), rtol=1e-6, atol=0)
     xx = xx.view(B, N)
-    pd = -xx.unsqueeze(2) - (-2 * gram) - xx.unsqueeze(1)          # the reference's expression on these operands
+    xx_ref = xx.unsqueeze(1)                                       # (B, 1, N) as dgcnn_util.knn's keepdim sum over channels
+    pd = -xx_ref - (-2 * gram) - xx_ref.transpose(2, 1)            # the reference's expression, operand for operand (:10)
     want_v, want_i = pd.topk(k=k, dim=-1)
     got_v = pd.gather(-1, idx)
     assert torch.equal(got_v, want_v)
@@ -162,6 +163,47 @@ def test_eval_mode_uses_the_running_estimates(monkeypatch):
         want = y.view(B, N, -1).max(dim=1)[0]
     assert _rel(feat, want) <= 2e-5
     assert enc.bn1.num_batches_tracked.item() == 0
+
+
+def test_eval_mode_gradients_have_no_batch_statistic_terms(monkeypatch):
+    """Fine-tuning with frozen (eval) BatchNorm: the backward of an eval-mode forward is d x = scale dy through the
+    winners only -- the c1 / c2 corrections of the training-mode formula must not be applied (dgcnn_util.py:117-136 with
+    the modules in .eval()).  Every parameter gradient against the dense fp64 formulation with training=False."""
+    torch.manual_seed(9)
+    from point_dae_amd import point_cae_dgcnn as D
+    from point_dae_amd.point_cae_dgcnn import dgcnn_encoder, feature_knn
+    B, N = 3, 160
+    enc = dgcnn_encoder(channel=3).cuda()
+    with torch.no_grad():
+        for bn in (enc.bn1, enc.bn2, enc.bn3, enc.bn4, enc.bn5):
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.copy_(torch.linspace(-1.0, 1.5, bn.weight.numel()))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, bn.bias.numel()))
+    ref = dgcnn_encoder(channel=3).cuda()
+    ref.load_state_dict(enc.state_dict())
+    ref = ref.double().eval()
+    enc.eval()
+    x = torch.randn(B, 3, N, device='cuda')
+    graphs = []
+    monkeypatch.setattr(D, 'feature_knn', lambda *a: graphs.append(feature_knn(*a)) or graphs[-1])
+    feat = enc(x)
+    tgt = torch.randn_like(feat)
+    (feat * tgt).sum().backward()
+    rows = x.double().transpose(1, 2).reshape(B * N, 3)
+    feats = []
+    for conv, idx in zip((ref.conv1, ref.conv2, ref.conv3, ref.conv4), graphs):
+        rows = _edge_reference(rows, idx, conv[0].weight.flatten(1), conv[1], training=False)
+        feats.append(rows)
+    y = torch.cat(feats, 1) @ ref.conv5[0].weight.squeeze(-1).t()
+    y = F.leaky_relu(F.batch_norm(y, ref.bn5.running_mean, ref.bn5.running_var, ref.bn5.weight, ref.bn5.bias, False,
+                                  0.1, ref.bn5.eps), 0.2)
+    want = y.view(B, N, -1).max(dim=1)[0]
+    (want * tgt.double()).sum().backward()
+    assert _rel(feat, want) <= 2e-5
+    for (name, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, name
+        assert _rel(p.grad, q.grad) <= 1e-3, (name, _rel(p.grad, q.grad))
 
 
 def test_entries_refuse_what_they_do_not_implement():

@@ -165,3 +165,21 @@ def test_fp32_mfma_kernels_stay_selectable():
     env = dict(os.environ, PDAE_GEMM='f32mfma')
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out[0] == '0' and int(out[1]) < 16
+
+
+def test_split_k_slabs_without_a_tile_of_the_reduction_are_refused():
+    """pdae_rows_gemm with more split-K slabs than 32-deep tiles of K (K = 128, 8 slabs: slabs 4..7 would start past
+    the end of the rows) returns a bad-argument status instead of launching; the largest legal count still works and
+    its slabs add up to the unsplit product."""
+    L = _lib()
+    L.set_gemm_arith(BF16X3)
+    M, N, K = 256, 384, 128
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g)
+    y = torch.empty(8, M, N, device='cuda')
+    with pytest.raises(RuntimeError, match='split-K slabs'):
+        L.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), 0, None, 0, None, y.data_ptr(), 16, 8, 0)
+    L.call('pdae_rows_gemm', x, M, N, K, x.data_ptr(), w.data_ptr(), 0, None, 0, None, y.data_ptr(), 16, 4, 0)
+    one = _gemm(L, BF16X3, x, w, False, 16)
+    assert (y[:4].sum(0) - one).abs().max().item() <= 1e-5 * one.abs().max().item()

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from point_dae_amd import _lib, nn_ops  # noqa: E402
 
-lab = ctypes.CDLL(os.path.join(ROOT, 'tools', 'lab', 'librows3_lab.so'))
+lab = ctypes.CDLL(os.path.join(ROOT, 'tools', 'lab', os.environ.get('LABSO', 'librows3_lab.so')))
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 lab.lab_gemm3.argtypes = [i32, i32, i32, i32, vp, vp, i32, vp, vp]
 NAMES = {0: '128x128 8w k32', 1: '128x128 8w k32 1acc', 2: '128x192 8w k32', 3: '128x64 8w k32', 4: '64x128 4w k16',
