@@ -41,7 +41,7 @@ extern "C" int lab_gemm3(int variant, int M, int N, int K, const float* A, const
   V(9, 1, 2, 2, 2, 2, true)     // 64 x 128, 4 waves, 32-deep
 #define VA(id, ABL) if (variant == id) return launch<1, 2, 4, 2, 2, false, true, ABL>(a, s);
   VA(10, 1) VA(11, 2) VA(12, 4) VA(13, 8) VA(14, 16) VA(17, 31)
+  VA(30, 30) VA(29, 29) VA(27, 27) VA(23, 23) VA(15, 15)     // ONE piece of side work left: loads | split | LDS stores | barrier | fragment reads
 #define VB(id, ABL) if (variant == id) return launch<1, 2, 2, 2, 1, false, true, ABL>(a, s);
-  VB(20, 1) VB(21, 2) VB(22, 4) VB(23, 8) VB(24, 16) VB(27, 31)
   return -1;
 }
