@@ -41,6 +41,7 @@ import torch.distributed as dist  # noqa: E402
 
 CFG3 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'
 CFG2 = 'cfgs/pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'
+CFG5 = 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_double.yaml'
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (AMD's 5 PF headline includes 2:1 sparsity)
 # the row-GEMM family's default arithmetic: fp32 operands split exactly into three bf16 terms, SIX bf16 products per
@@ -50,7 +51,7 @@ HBM_PEAK_GBS = 8000.0
 VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
                                   # kernels are sub / mul / add / min chains
 EXP_PEAK_TOPS = 9.8               # v_exp_f32 per second (T/s): the transcendental rate VERDICT r3 prices EMD against
-ROUND = 4                         # profiles/*_rNN.json this bench refers to
+ROUND = 5                         # profiles/*_rNN.json this bench refers to
 
 
 def parse():
@@ -91,7 +92,7 @@ def _event_time_us(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters * 1e3
 
 
-def geometry_rooflines(args, clouds):
+def geometry_rooflines(args, clouds, shape=None):
     """FPS / kNN+group / Chamfer forward+backward at the workload's shapes: average launch time (HIP
     events on the launch stream, back-to-back launches) against BOTH rooflines north_star names --
     algorithmic bytes over the 8 TB/s HBM peak, and pair operations (9 per point pair:
@@ -100,6 +101,8 @@ def geometry_rooflines(args, clouds):
     iterations), which is what the two fractions show."""
     from point_dae_amd import _lib
     B, N, G, k = args.batch, args.npoints, args.num_group, 32
+    if shape is not None:
+        B, N, G = shape
     x = clouds[:B].contiguous()
     dev = x.device
     idx = torch.empty(B, G, dtype=torch.int32, device=dev)
@@ -119,6 +122,8 @@ def geometry_rooflines(args, clouds):
                                           _lib.ptr(dist_), _lib.ptr(nbr)))
     row('knn_kernel (B=%d, %dx%d -> %d, idx + dist + centred patches)' % (B, G, N, k), us,
         B * (12 * N + 12 * G + 8 * G * k + 4 * G * k + 12 * G * k), B * G * N)
+    if shape is not None:                                    # (a second shape: the two kernels whose cost depends on N, G)
+        return out
     P = B * int(0.65 * G)                                    # masked patches at the mean ratio
     a = nbr.reshape(-1, k, 3)[:P].contiguous()
     b = torch.roll(a, 1, 0).contiguous()
@@ -177,6 +182,38 @@ def tvis_table(step, batch, replays=6):
     return out
 
 
+def per_tvis_families(step, batch, nn_ops, want_replay=True):
+    """Deterministic per-T_vis tables of the row-GEMM families: for every captured visible-token count ONE eager run of
+    the graphed step's own body with exactly that many visible tokens (graph_step._draw(tvis)) under the launch-site
+    probe -> algorithmic FLOPs and bytes per family (functions of the shapes only: the same for every run), and the
+    families' device time from their launches captured into one hipGraph per family and replayed back to back.
+    -> {tvis: {family: {'gflop', 'gbytes', 'launches', 'ms'}}}"""
+    out = {}
+    step.pts.copy_(batch)
+    for tvis in sorted(step.graphs):
+        probe = nn_ops.Probe()
+        probe.keep_calls = want_replay
+        nn_ops.set_probe(probe)
+        try:
+            step._fwd_bwd(step._draw(tvis))
+            step.model.zero_grad()
+            torch.cuda.synchronize()
+        finally:
+            nn_ops.set_probe(None)
+        fam = probe.family_summary()
+        rep = {}
+        if want_replay:
+            probe.keep_calls = False
+            try:
+                rep = probe.family_replay_ms(replays=6)
+            except Exception as err:                     # a measurement aid: never fails the bench line
+                rep = {'error': repr(err)[:200]}
+        probe.calls = {}
+        out[tvis] = {k: {'gflop': r['flops'] / 1e9, 'gbytes': r['bytes'] / 1e9, 'launches': r['launches'],
+                         'ms': rep.get(k) if isinstance(rep.get(k), float) else None} for k, r in fam.items()}
+    return out
+
+
 def tvis_distribution(G):
     """P(T_vis) under MaskTransformer._mask_center_rand (:395-422): ratio ~ U(0.5, 0.8), num_mask = int(ratio G)."""
     lo, hi = 0.5, 0.8
@@ -219,53 +256,59 @@ def ddp_model(table, G, ms_per_step, ranks=(2, 4, 8), allreduce_mb=116.0):
     return out
 
 
-def dominant_roofline(probe, steps, bf16x3):
+def dominant_roofline(per_tvis, G, bf16x3):
     """The bench line's `roofline`: the row GEMM family (every Linear / 1x1 conv forward and data gradient) and the
-    grouped weight gradients (+ their reductions) -- the kernels that own ~60 % of the step -- as ONE time-weighted
-    figure: all their algorithmic fp32 FLOPs over all their time.  Time = one step's launches of the two families
-    captured into a hipGraph per family and replayed back to back (`timing`), next to HIP events around every eager
-    launch of the probe steps.  Peak: the arithmetic these kernels run -- exact-split bf16 (six bf16 MFMA products per
-    fp32 product: bf16 dense / 6) by default, the fp32-input MFMA peak under PDAE_GEMM=f32mfma; the fraction of the
-    fp32-input MFMA peak is reported alongside either way."""
-    fam = {k: v for k, v in probe.family_summary().items() if k in ('rows_gemm', 'rows_wgrad')}
-    if not fam:
+    grouped weight gradients (+ their reductions) -- the kernels that own ~65 % of the step -- as ONE time-weighted
+    figure.  Work and time are EXPECTATIONS over the mask-ratio distribution (tvis_distribution): per visible-token
+    count the families' algorithmic FLOPs / bytes at the launch sites (deterministic) and their device time (one step's
+    launches of a family captured into a hipGraph and replayed back to back), weighted with P(T_vis).  Peak: the
+    arithmetic these kernels run -- exact-split bf16 (six bf16 MFMA products per fp32 product: bf16 dense / 6) by
+    default, the fp32-input MFMA peak under PDAE_GEMM=f32mfma; the fraction of the fp32-input MFMA peak alongside."""
+    if not per_tvis:
         return None
+    p = tvis_distribution(G)
+    ts = [t for t in sorted(per_tvis) if t in p]
+    fams = ('rows_gemm', 'rows_wgrad')
+    if not ts or any(per_tvis[t].get(f, {}).get('ms') is None for t in ts for f in fams):
+        return None
+    z = sum(p[t] for t in ts)
+    ex = lambda f, key: sum(p[t] * per_tvis[t][f][key] for t in ts) / z
+    rows, gflop, ms, gbytes = {}, 0.0, 0.0, 0.0
+    for f in fams:
+        rows[f] = {'launches_per_step': ex(f, 'launches'), 'gflop_per_step': ex(f, 'gflop'), 'ms_per_step': ex(f, 'ms'),
+                   'algorithmic_gbytes_per_step': ex(f, 'gbytes'), 'achieved': ex(f, 'gflop') / ex(f, 'ms')}
+        gflop += rows[f]['gflop_per_step']
+        ms += rows[f]['ms_per_step']
+        gbytes += rows[f]['algorithmic_gbytes_per_step']
     peak = BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
-    rows = {}
-    tot_f = tot_ms = 0.0
-    for name, r in fam.items():
-        tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-        rows[name] = {'launches_per_step': r['launches'] / max(steps, 1), 'eager_ms_per_step': r['ms'] / max(steps, 1),
-                      'gflop_per_step': r['flops'] / max(steps, 1) / 1e9, 'eager_achieved': tf}
-        tot_f += r['flops']
-        tot_ms += r['ms']
-    gflop = tot_f / max(steps, 1) / 1e9
-    eager_ms = tot_ms / max(steps, 1)
-    ms, timing = eager_ms, 'HIP events around every eager launch of the two families over %d probe steps (host launch gaps included)' % steps
-    rep = getattr(probe, 'replay_ms', None)
-    if rep and 'error' not in rep and all(k in rep for k in fam):
-        ms = sum(rep[k] for k in fam)
-        timing = ('one step\'s launches of the two families (the graphed step\'s own body, run right after the timed region) '
-                  'captured into one hipGraph per family and replayed back to back, HIP events around 10 replays; '
-                  'profiles/kernel_summary_r%02d.txt has the same kernels\' durations inside the step\'s replays' % ROUND)
-        for k in fam:
-            rows[k]['ms_per_step'] = rep[k]
-            rows[k]['achieved'] = rows[k]['gflop_per_step'] / rep[k] if rep[k] > 0 else 0.0      # GFLOP / ms = TFLOP/s
     ach = gflop / ms                                  # GFLOP / ms = TFLOP/s
     traffic = traffic_src = None
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % ROUND)
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc)).get('rows_families_hbm_bytes_per_step')
-        if rec:
-            traffic, traffic_src = rec, 'profiles/pmc_r%02d.json (rocprofv3 --pmc passes of this command, bytes of the two families per STEP)' % ROUND
+    for rnd in range(ROUND, 0, -1):
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % rnd)
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get('rows_families_hbm_bytes_per_step')
+            if rec:
+                traffic, traffic_src = rec, ('profiles/pmc_r%02d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 '
+                                             'FETCH correction, bytes of the two families per STEP averaged over that run\'s mask draws; '
+                                             'fabric-side counters: Infinity-Cache hits included)' % rnd)
+                break
     return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
             'traffic': traffic, 'traffic_source': traffic_src,
+            'algorithmic_bytes': gbytes * 1e9,
+            'algorithmic_bytes_note': 'per step: every operand and every result of every launch of the two families once, 4 B per '
+                                      'element (M K + N K + slabs M N per product, M (N + K) + N K per weight gradient: DESIGN.md 4b)',
             'kernel': 'pdae::rows3::gemm3_kernel + pdae::rows3::wgrad3b_kernel (+ wgrad_reduce_kernel): the row-GEMM family' if bf16x3
                       else 'pdae::rows::rows_gemm_kernel + pdae::rows::wgrad_kernel (+ wgrad_reduce_kernel): the row-GEMM family',
-            'ms_per_step': ms, 'gflop_per_step': gflop, 'eager_ms_per_step': eager_ms,
-            'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS, 'families': rows, 'timing': timing,
+            'ms_per_step': ms, 'gflop_per_step': gflop,
+            'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS, 'families': rows,
+            'timing': 'per visible-token count: one step\'s launches of each family (the graphed step\'s own body) captured into a '
+                      'hipGraph per family and replayed back to back, HIP events around 6 replays; expectation over P(T_vis); '
+                      'profiles/kernel_summary_r%02d.txt has the same kernels\' durations inside the step\'s replays' % ROUND,
+            'expectation_over': {str(t): round(p[t] / z, 5) for t in ts},
             'peak_note': ('fp32-equivalent ceiling of the exact-split arithmetic: bf16 MFMA dense peak %.0f TFLOP/s / 6 products '
-                          '(MI355X_MICROARCH.md); the fp32-input MFMA peak is %.1f' % (MFMA_BF16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+                          '(MI355X_MICROARCH.md) at the 2.4 GHz peak clock; dense bf16 loops hold 1.6-1.9 GHz on this part (in-kernel '
+                          's_memtime / s_memrealtime, tools/lab/p3_clock.py), i.e. a sustained ceiling of ~280-330; the fp32-input '
+                          'MFMA peak is %.1f' % (MFMA_BF16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
                          if bf16x3 else 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
 
 
@@ -312,6 +355,57 @@ def cfg2_leg(args, device, rank):
                          'achieved': pairs * 9 / (us * 1e-6) / 1e12, 'peak': VALU_F32_PEAK_TOPS, 'unit': 'T op/s',
                          'frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),
                          'hbm_frac': B * (12 * (16384 + N) + 8 * (16384 + N)) / (us * 1e-6) / (HBM_PEAK_GBS * 1e9)}}
+
+
+def cfg5_leg(args, device, rank):
+    """BASELINE config 5's per-GPU workload (`..._p0005_double.yaml` at N=2048, G=128, local B=32 of the global 256 over
+    8 GPUs: the large-cloud stress of the LDS tiling) as a short timed leg: the same graphed train step, G = 128 patch
+    tokens per cloud (T_vis 26..64).  The host RNG is re-seeded before the warm-up and before the timed steps, so the timed
+    steps draw the mask ratios the warm-up already captured graphs for: replays only inside the timed region."""
+    import random
+    import numpy as np
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    config = cfg_from_yaml_file(os.path.join(ROOT, CFG5))
+    B, N, G = 32, 2048, 128
+    config.npoints, config.model.num_group = N, G
+    model = FlatDataParallel(builder.model_builder(config.model).to(device), broadcast=False, process_group=None)
+    model.world_size = 1                         # a local leg on rank 0: no collective
+    optimizer, _ = builder.build_opti_sche(model, config)
+    model.train()
+    model.zero_grad()
+    x = torch.from_numpy(shapenet_like_clouds(2 * B, N, seed=900 + rank)).to(device).split(B)
+    step = GraphedTrainStep(model, optimizer, config, B, N, split=False, warmup_eager=1)
+
+    def seed(v):
+        random.seed(v), np.random.seed(v), torch.manual_seed(v)
+    n = args.also_steps
+    seed(77)
+    for i in range(n + 1):                       # one eager step, then a capture + replay per new mask ratio
+        step(x[i % 2])
+    seed(77)
+    step(x[0])                                   # (the draw the eager step consumed: captured now)
+    for i in range(1, n + 1):
+        step(x[i % 2])
+    torch.cuda.synchronize()
+    seed(77)
+    tv = []
+    t0 = time.perf_counter()
+    for i in range(n + 1):
+        out = step(x[i % 2])
+        tv.append(step.last_tvis)
+    loss = out[0].detach().clone()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    geo = geometry_rooflines(args, torch.cat(x), shape=(B, N, G))
+    del model, optimizer, step
+    return {'workload': 'cfg5 per-GPU shape: ..._maskpatch_p0005_double.yaml at N=2048, G=128, k=32, local B=32 (global 256 over '
+                        '8 GPUs), full train step, hipGraph replay',
+            'value': B * (n + 1) / dt, 'unit': 'clouds/s', 'ms_per_step': dt / (n + 1) * 1e3, 'steps': n + 1,
+            'tvis_of_the_timed_steps': tv, 'loss_last_step': float(loss), 'roofline_geometry': geo}
 
 
 def published_leg(args, device, rank):
@@ -576,35 +670,27 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe_mode = 'HIP events around every launch of the kernel inside the timed region (eager launches)'
+    per_tvis = None
     if not args.eager and rank == 0 and args.workload == 'cfg3':
-        # hipGraph replay hides individual launches from host-recorded events, so
-        # the dominant kernel is timed with HIP events on its launch stream over
-        # `probe_steps` eager optimisation steps of the same workload, run right
-        # after the timed region (same process, same buffers, same shapes).
-        # profiles/ holds the rocprofv3 --kernel-trace average of the same
-        # kernel inside the graph replays for comparison.
+        # hipGraph replay hides individual launches from host-recorded events, so the single largest kernel (the
+        # embedder's conv3: `roofline_best`) is timed with HIP events on its launch stream over `probe_steps` eager
+        # forward + backward passes of the same workload, run right after the timed region (same process, same buffers,
+        # same shapes); profiles/ holds the rocprofv3 --kernel-trace average of the same kernel inside the graph replays.
         nn_ops.set_probe(probe)
         model.require_sync = False            # rank-0-only steps: no collective (the other ranks are not in them)
         for i in range(args.probe_steps):       # forward + backward only: the replicas' parameters stay in step
-            probe.keep_calls = i == args.probe_steps - 1          # the last probe step's launches are kept for a replay
             if isinstance(step, GraphedTrainStep):
-                # the graphed step's own body (gradient sink armed, the stacks' grouped weight gradients), launched
-                # kernel by kernel: what the replays run
                 step.pts.copy_(batches[i % pool])
                 step._fwd_bwd(step._draw())
             else:
                 lx, ln = model(batches[i % pool], batches[i % pool])
                 (lx + float(config.normal_weight) * ln.sum()).backward()
             model.zero_grad()
-        model.require_sync = True
         torch.cuda.synchronize()
-        probe.keep_calls = False
         nn_ops.set_probe(None)
-        try:
-            probe.replay_ms = probe.family_replay_ms()
-        except Exception as err:                                   # a measurement aid: never fails the bench line
-            probe.replay_ms = {'error': repr(err)[:200]}
-        probe.calls = {}
+        if isinstance(step, GraphedTrainStep) and args.probe_steps:
+            per_tvis = per_tvis_families(step, batches[0], nn_ops)      # the `roofline` families, per visible-token count
+        model.require_sync = True
         probe_mode = ('HIP events around every launch of the kernel over %d eager steps run right after the '
                       'timed hipGraph region' % args.probe_steps)
     nn_ops.set_probe(None)
@@ -629,28 +715,36 @@ def main():
     if rank == 0:
         clouds_per_s = args.batch * world * args.steps / elapsed
         kern = probe.summary()
+        from point_dae_amd import _lib as _L
+        bf16x3 = _L.gemm_arith() == _L.GEMM_BF16X3
         roof = None
         if kern:
             ach = kern['flops'] / (kern['avg_ms'] * 1e-3) / 1e12
-            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot
-            # be collected inside this run); the newest committed profile of the same kernel and shape, or null
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be collected
+            # inside this run); the newest committed profile that has this kernel at this shape, or null
+            kname = 'rows3::conv3_kernel<0, 3>' if bf16x3 else 'gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>'
             traffic, traffic_src = None, None
             for rnd in range(ROUND, 0, -1):
                 pmc = os.path.join(ROOT, 'profiles', 'pmc_r%02d.json' % rnd)
                 if os.path.exists(pmc) and args.batch == 128 and args.num_group == 64 and args.npoints == 1024:
-                    rec = json.load(open(pmc)).get('gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS>')
+                    rec = json.load(open(pmc)).get(kname)
                     if rec:
                         traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/pmc_r%02d.json (rocprofv3 --pmc, not this run)' % rnd
                         break
-            roof = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kern['name'],
+            peak = BF16X3_PEAK_TFLOPS if bf16x3 else MFMA_F32_PEAK_TFLOPS
+            R_, c3_, c2_ = args.batch * args.num_group * 32, 512, 256
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                    'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS,
+                    'traffic': traffic, 'traffic_source': traffic_src,
+                    'algorithmic_bytes': 4.0 * (R_ * c2_ + c3_ * c2_ + R_ * c3_ + (R_ // 32) * c3_),
+                    'kernel': ('pdae::' + kname) + ': ' + kern['name'],
                     'avg_us': kern['avg_ms'] * 1e3, 'launches': kern['launches'],
                     'flops_per_launch': kern['flops'], 'timing': probe_mode,
-                    'peak_note': 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
-        from point_dae_amd import _lib as _L
-        bf16x3 = _L.gemm_arith() == _L.GEMM_BF16X3
+                    'peak_note': ('exact-split bf16 ceiling (bf16 dense %.0f / 6 products); fp32-input MFMA peak %.1f alongside'
+                                  % (MFMA_BF16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)) if bf16x3
+                                 else 'fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak, MI355X_MICROARCH.md'}
         best = roof                                   # the single largest hand-written kernel (the embedder's conv3)
-        dom = dominant_roofline(probe, args.probe_steps if not args.eager else args.steps, bf16x3)
+        dom = dominant_roofline(per_tvis, args.num_group, bf16x3)
         line = {
             'metric': 'pretrain point-clouds/sec (N=%d,G=%d)' % (args.npoints, args.num_group), 'value': clouds_per_s, 'unit': 'clouds/s',
             'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if world > 1 and backend == 'nccl' else (1 if world == 1 else 0)),
@@ -670,25 +764,38 @@ def main():
                                           else 'one flat all-reduce after the replay'),
                        'dense_layers': ('hand-written MFMA kernels, no BLAS library in the step: Linear layers and weight gradients on '
                                         'exact-split bf16 (csrc/rows3_kernel.h: fp32 = three bf16 terms, six products, fp32 accumulate; '
-                                        'PDAE_GEMM=f32mfma selects the fp32-input kernels), the patch embedder on fp32-input MFMA (csrc/gemm.hip)')
+                                        'PDAE_GEMM=f32mfma selects the fp32-input kernels), the patch embedder\'s fused convolutions on the same '
+                                        'arithmetic (rows3::conv3_kernel); only the K = 3 / K = 4 layers stay on fp32-input MFMA')
                                        if bf16x3 else 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
             'roofline': dom if dom else best,
             'roofline_best': best if dom else None,
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
-        fams = probe.family_summary()
-        if fams and args.probe_steps and not args.eager:
-            gf = sum(r['flops'] for r in fams.values()) / args.probe_steps / 1e9
-            tf = gf / (elapsed / args.steps * 1e3)            # GFLOP / ms = TFLOP/s
-            line['whole_step'] = {'gflop_executed': gf, 'achieved': tf, 'unit': 'TFLOP/s',
-                                  'frac_of_f32_mfma_peak': tf / MFMA_F32_PEAK_TFLOPS,
-                                  'frac_of_bf16x3_peak': tf / BF16X3_PEAK_TFLOPS,
-                                  'gflop_by_family': {k: r['flops'] / args.probe_steps / 1e9 for k, r in fams.items()},
-                                  'note': 'fp32 FLOPs of every dense product the step executes (row GEMMs, weight gradients, the '
-                                          "embedder's fused convolutions: counted at the launch sites over the probe steps, which draw "
-                                          'their own mask ratios) over the timed ms/step; the embedder runs on the fp32-input pipe, the rest '
-                                          'on exact-split bf16 unless PDAE_GEMM=f32mfma'}
+        if per_tvis:
+            # every dense FLOP of the step (row GEMMs, weight gradients, the embedder's fused convolutions) as the
+            # EXPECTATION over P(T_vis) of the per-T_vis launch-site counts -- deterministic -- over the matching
+            # expectation of the replay time (tvis_table) and over the timed ms/step (which includes AdamW)
+            pt = tvis_distribution(args.num_group)
+            ts = [t for t in sorted(per_tvis) if t in pt]
+            z = sum(pt[t] for t in ts)
+            by_fam = {}
+            for t in ts:
+                for k, r in per_tvis[t].items():
+                    by_fam[k] = by_fam.get(k, 0.0) + pt[t] / z * r['gflop']
+            gf = sum(by_fam.values())
+            line['whole_step'] = {'gflop_executed': gf, 'unit': 'TFLOP/s', 'gflop_by_family': by_fam,
+                                  'timed_ms_per_step': elapsed / args.steps * 1e3,
+                                  'achieved_on_timed_ms': gf / (elapsed / args.steps * 1e3),
+                                  'note': 'fp32 FLOPs of every dense product the step executes, counted at the launch sites per '
+                                          'visible-token count and weighted with P(T_vis); `achieved` = over the same expectation of '
+                                          'the forward + loss + backward replay time (tvis_table), `achieved_on_timed_ms` over the '
+                                          'timed ms/step (its own mask draws, AdamW included)'}
+            if table and all(t in table for t in ts):
+                exp_ms = sum(pt[t] / z * table[t] for t in ts)
+                line['whole_step'].update(expected_replay_ms=exp_ms, achieved=gf / exp_ms,
+                                          frac_of_f32_mfma_peak=gf / exp_ms / MFMA_F32_PEAK_TFLOPS,
+                                          frac_of_bf16x3_peak=gf / exp_ms / BF16X3_PEAK_TFLOPS)
         if table:
             line['tvis_table'] = {'unit': 'ms per replay (forward + loss + backward graph(s), no AdamW)',
                                   'ms': {str(t): round(v, 4) for t, v in table.items()}}
@@ -702,6 +809,7 @@ def main():
                 line['also'] = {'cfg2': cfg2_leg(args, device, rank)}
                 line['also']['published_variant'] = published_leg(args, device, rank)
                 line['also']['dgcnn'] = dgcnn_leg(args, device, rank)
+                line['also']['cfg5_shape'] = cfg5_leg(args, device, rank)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
         print(json.dumps(line), flush=True)

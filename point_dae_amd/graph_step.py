@@ -174,13 +174,17 @@ class GraphedTrainStep:
             return self.w_dev * ln.sum()
         return lx + self.w_dev * ln.sum()
 
-    def _draw(self):
+    def _draw(self, tvis=None):
         """Host RNG, in the order the eager forward consumes it: corruption
-        (corrupt_util_tensor.py:706-727) first, then the mask (:395-422; none for the un-masked model)."""
+        (corrupt_util_tensor.py:706-727) first, then the mask (:395-422; none for the un-masked model).
+        tvis: (measurement aid, bench.py's per-T_vis tables) mask exactly G - tvis groups instead of drawing the ratio."""
         enc = self.net.MAE_encoder
         steps = draw_corruption(self.net.corrupt_type, self.B)
         if self.masked:
-            mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
+            if tvis is None:
+                mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
+            else:
+                mask, _ = draw_mask(self.B, self.G, (self.G - tvis + 0.5) / self.G, 'False')
             enc.num_mask = int(enc.mask_ratio * self.G)
         n = steps.shape[0]
         slot = self.ring[self.slot]

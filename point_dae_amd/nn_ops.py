@@ -382,7 +382,8 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False, big_c
     y = _empty((splits, M, N) if splits > 1 else (M, N), x)
     probed_family('rows_gemm', 2.0 * M * N * K,
                   lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
-                                    epi, _lib.ptr(z), _lib.ptr(y), cfg, splits, sb))
+                                    epi, _lib.ptr(z), _lib.ptr(y), cfg, splits, sb),
+                  nbytes=4.0 * (M * K + N * K + y.numel() + (M * N if z is not None else 0)))
     return y
 
 
@@ -442,7 +443,8 @@ def flush_wgrad_queue(owner):
                 _lib.rows_wgrad_multi(q)
             owner.wgrad_inflight.append(q)           # operands stay alive until the join
         else:
-            probed_family('rows_wgrad', flops, lambda: _lib.rows_wgrad_multi(q))
+            probed_family('rows_wgrad', flops, lambda: _lib.rows_wgrad_multi(q),
+                          nbytes=4.0 * sum(dy.shape[0] * (dy.shape[1] + x.shape[1]) + dy.shape[1] * x.shape[1] for dy, x, _, _ in q))
         owner.wgrad_queue = []
 
 
@@ -465,7 +467,8 @@ def rows_wgrad(dys, xs, with_bias, outs=None, db_outs=None):
     it = iter(db_outs) if db_outs is not None else None
     dbs = [(next(it) if it is not None else _empty((n,), dys[0])) if f else None for n, f in zip(Ns, with_bias)]
     probed_family('rows_wgrad', 2.0 * M * sum(n * k for n, k in zip(Ns, Ks)),
-                  lambda: _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws))
+                  lambda: _lib.rows_wgrad(dys[0], M, dys, xs, dws, dbs, ws),
+                  nbytes=4.0 * sum(M * (n + k) + n * k for n, k in zip(Ns, Ks)))
     return dws, dbs
 
 

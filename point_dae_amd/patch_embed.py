@@ -57,7 +57,7 @@ def _gemm(x, w, w_kn=False, bias=None):
     y = _empty((M, N), x)
     probed_family('rows_gemm', 2.0 * M * N * K,
                   lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
-                                    0, None, _lib.ptr(y), cfg, 1, 0))
+                                    0, None, _lib.ptr(y), cfg, 1, 0), nbytes=4.0 * (M * K + N * K + M * N))
     return y
 
 
@@ -77,7 +77,7 @@ def _wgrad_listed(M, dy, a_groups, x, b_groups, scale=None, shift=None, bias=Fal
         probed_family('rows_wgrad', 2.0 * M * N * K,
                       lambda: _lib.call('pdae_rows_wgrad_listed', x, M, N, K, _lib.ptr(dy), _lib.ptr(a_groups), _lib.ptr(x),
                                         _lib.ptr(b_groups), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(dw), _lib.ptr(db),
-                                        _lib.ptr(ws)))
+                                        _lib.ptr(ws)), nbytes=4.0 * (M * (N + K) + N * K))
     elif scale is not None:
         assert a_groups is None
         _lib.call('pdae_bnrelu_linear_backward_weight', x, M, N, K, _lib.ptr(dy), _lib.ptr(x), _lib.ptr(scale),
@@ -94,7 +94,8 @@ def _wgrad(dy, x):
     Ns, Ks = [dy.shape[1]], [x.shape[1]]
     ws = _empty((max(_lib.rows_wgrad_workspace(M, Ns, Ks), 1),), dy)
     dw = _empty((Ns[0], Ks[0]), dy)
-    probed_family('rows_wgrad', 2.0 * M * Ns[0] * Ks[0], lambda: _lib.rows_wgrad(dy, M, [dy], [x], [dw], [None], ws))
+    probed_family('rows_wgrad', 2.0 * M * Ns[0] * Ks[0], lambda: _lib.rows_wgrad(dy, M, [dy], [x], [dw], [None], ws),
+                  nbytes=4.0 * (M * (Ns[0] + Ks[0]) + Ns[0] * Ks[0]))
     return dw
 
 
@@ -172,7 +173,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         stats = _empty((8, 2, c3), x)
         # the largest hand-written kernel of the step: bench.py's roofline kernel
         probed_family('embed_gemm', 2.0 * R * c3 * c2, lambda: probed(
-            'gemm_nt_kernel<256,256,NONE,GROUPBIAS_STATS> patch_embed.second_conv[0] fwd %dx%dx%d' % (R, c3, c2),
+            'patch_embed.second_conv[0] forward (group bias + BatchNorm statistics epilogue) %dx%dx%d' % (R, c3, c2),
             2.0 * R * c3 * c2,
             lambda: _lib.call('pdae_embed_conv_groupbias_stats', x, R, c3, c2, _lib.ptr(f), _lib.ptr(wl),
                               _lib.ptr(gb), _lib.ptr(h3), _lib.ptr(stats))))

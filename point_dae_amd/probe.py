@@ -1,7 +1,7 @@
 """HIP-event timers for bench.py's rooflines.
 
 `probed(name, flops, fn)`: ONE named kernel launch site (the `roofline` object).
-`probed_family(family, flops, fn)`: every launch of a kernel FAMILY (the row GEMMs, the grouped weight
+`probed_family(family, flops, fn, nbytes)`: every launch of a kernel FAMILY (the row GEMMs, the grouped weight
 gradients: `roofline_dominant`, the time-weighted figure of the kernels that own most of the step).
 
 Events are recorded on the stream the kernel is launched on, around every launch, and read afterwards."""
@@ -27,9 +27,9 @@ class Probe:
         self.events.append((s, e))
         return out
 
-    def record_family(self, family, flops, fn):
+    def record_family(self, family, flops, fn, nbytes=0.0):
         out, s, e = self._time(fn)
-        self.families.setdefault(family, []).append((s, e, flops))
+        self.families.setdefault(family, []).append((s, e, flops, nbytes))
         if self.keep_calls:
             self.calls.setdefault(family, []).append(fn)      # (the closure keeps its operand tensors alive)
         return out
@@ -67,8 +67,8 @@ class Probe:
         """-> {family: {'launches', 'ms', 'flops'}} summed over every recorded launch."""
         out = {}
         for fam, recs in self.families.items():
-            out[fam] = {'launches': len(recs), 'ms': sum(s.elapsed_time(e) for s, e, _ in recs),
-                        'flops': float(sum(f for _, _, f in recs))}
+            out[fam] = {'launches': len(recs), 'ms': sum(r[0].elapsed_time(r[1]) for r in recs),
+                        'flops': float(sum(r[2] for r in recs)), 'bytes': float(sum(r[3] for r in recs))}
         return out
 
 
@@ -84,5 +84,6 @@ def probed(name, flops, fn):
     return _probe.record(name, flops, fn) if _probe is not None else fn()
 
 
-def probed_family(family, flops, fn):
-    return _probe.record_family(family, flops, fn) if _probe is not None else fn()
+def probed_family(family, flops, fn, nbytes=0.0):
+    """nbytes: the launch's ALGORITHMIC bytes -- every operand and the result once (bench.py roofline.algorithmic_bytes)."""
+    return _probe.record_family(family, flops, fn, nbytes) if _probe is not None else fn()

@@ -9,7 +9,10 @@ python bench.py > gpurun_out/preflight_bench.json 2> gpurun_out/preflight_bench.
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/preflight_bench.json').read().strip().splitlines()[-1])
-print('ms/step %.3f  clouds/s %.0f  roofline %.3f  dominant %.3f / replayed %.3f  cfg2 %.2f ms  published %.2f ms  cpu %.1f clouds/s' % (
-    d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline_dominant']['frac'], d['roofline_dominant']['replayed']['frac'],
-    d['also']['cfg2']['ms_per_step'], d['also']['published_variant']['ms_per_step'], d['cpu_baseline']['value']))
+a = d['also']
+print('ms/step %.3f  clouds/s %.0f  roofline %.3f (%.1f TFLOP/s-eq, %.2f ms of families)  best %.3f  whole-step %.1f TFLOP/s  cfg2 %.2f ms  published %.2f ms  '
+      'dgcnn %.2f ms  cfg5-shape %.2f ms  cpu %.1f clouds/s' % (
+          d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['achieved'], d['roofline']['ms_per_step'],
+          d['roofline_best']['frac'], d['whole_step'].get('achieved', 0.0), a['cfg2']['ms_per_step'],
+          a['published_variant']['ms_per_step'], a['dgcnn']['ms_per_step'], a['cfg5_shape']['ms_per_step'], d['cpu_baseline']['value']))
 PY
