@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdae_hip.so")
+LIB_PATH = os.environ.get("PDAE_LIB") or os.path.join(_HERE, "libpdae_hip.so")     # PDAE_LIB: another build of the library (A/B runs, tools/lab/ab.sh)
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -366,10 +366,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
             float v = (DUAL ? hi[i][j][e] + lo[i][j][e] : hi[i][j][e]) + bv;
             if (EPI == rows::EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
             if (EPI == rows::EPI_BIAS_GELU2) {
-              const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-              const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-              p.Z[off + (unsigned)lr * ldc] = cdf + v * pdf;
-              v = v * cdf;
+              float ge, gr;
+              gelu_pair_f(v, ge, gr);                             // (common.h: one exponential for GELU and GELU')
+              p.Z[off + (unsigned)lr * ldc] = gr;
+              v = ge;
             }
             if (EPI == rows::EPI_MUL_GELUGRAD) v *= zv[e];
             if (EPI == rows::EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;

@@ -346,11 +346,11 @@ void rows_gemm_kernel(const Args p) {
           float v = acc[i][j][e] + bv;
           if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
           if (EPI == EPI_BIAS_GELU2) {
-            // one erf for both: GELU(z) = z Phi(z), GELU'(z) = Phi(z) + z phi(z)
-            const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-            p.Z[off + (unsigned)lr * ldc] = cdf + v * pdf;
-            v = v * cdf;
+            // one exponential for both: GELU(z) = z Phi(z), GELU'(z) = Phi(z) + z phi(z) (common.h gelu_pair_f)
+            float ge, gr;
+            gelu_pair_f(v, ge, gr);
+            p.Z[off + (unsigned)lr * ldc] = gr;
+            v = ge;
           }
           if (EPI == EPI_MUL_GELUGRAD) v *= zv[e];
           if (EPI == EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;      // ReLU backward: relu'(0) = 0 as ATen's threshold
