@@ -792,6 +792,14 @@ int pdae_scale_residual(int M, int C, int T, const float* a,
  *   centre rows `rows` (int64 indices into xyz (.,3); NULL = all rows in order): h = GELU(z), gp = GELU'(z) for
  *   z = xyz . W1^T + b1, and xp (M,4) = the gathered rows zero-padded (the backward's weight-gradient operand). */
 int pdae_drop_path_keep(int sites, int B, const float* r, const float* keep, float* out, pdae_stream_t stream);
+/* tail_rows_gather / _scatter: TransformerDecoder.forward returns x[:, -return_token_num:] (models/PointCAE_transformer.py:
+ *   225-232), so the last block's row-wise second half runs on the last `tail` tokens of every sample only.
+ *   gather:  a_t (B tail, C) = rows T - tail .. T - 1 of every sample of a (B T, C); the same for b -> b_t (b nullable).
+ *   scatter: da (B T, C) = da_t on those rows, ZERO elsewhere; the same for db_t -> db (db nullable).  C % 4 == 0. */
+int pdae_tail_rows_gather(int B, int T, int tail, int C, const float* a, const float* b /*nullable*/, float* a_t,
+                          float* b_t /*nullable*/, pdae_stream_t stream);
+int pdae_tail_rows_scatter(int B, int T, int tail, int C, const float* da_t, const float* db_t /*nullable*/, float* da,
+                           float* db /*nullable*/, pdae_stream_t stream);
 int pdae_pos_embed_fc1(int M, int H, const float* xyz, const int64_t* rows, const float* w1, const float* b1, float* h,
                        float* gp, float* xp, pdae_stream_t stream);
 int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,

@@ -647,7 +647,69 @@ __global__ __launch_bounds__(256) void pos_embed_fc1_kernel(int M, int H, const 
   *reinterpret_cast<float4*>(gp + (size_t)m * H + c) = make_float4(gv[0], gv[1], gv[2], gv[3]);
 }
 
+// The decoder's last block returns only the last `tail` tokens of every sample (TransformerDecoder.forward,
+// models/PointCAE_transformer.py:225-232: x[:, -return_token_num:]): its row-wise second half runs on those rows alone.
+// gather: out[b tail + t] = in[b T + (T - tail) + t] for up to two tensors in one launch; scatter: the reverse into
+// full-size gradients, zero outside the tail (the framework ran two strided copies forward, a fill and four copies back).
+__global__ __launch_bounds__(256) void tail_rows_gather_kernel(long long n4, int C4, int T, int tail, const float4* __restrict__ a,
+                                                               const float4* __restrict__ b, float4* __restrict__ a_t,
+                                                               float4* __restrict__ b_t) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const long long row = i / C4;
+  const int c = (int)(i - row * C4);
+  const long long smp = row / tail;
+  const long long src = (smp * T + (T - tail) + (row - smp * tail)) * C4 + c;
+  a_t[i] = a[src];
+  if (b) b_t[i] = b[src];
+}
+__global__ __launch_bounds__(256) void tail_rows_scatter_kernel(long long n4, int C4, int T, int tail, const float4* __restrict__ da_t,
+                                                                const float4* __restrict__ db_t, float4* __restrict__ da,
+                                                                float4* __restrict__ db) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over the FULL rows
+  if (i >= n4) return;
+  const long long row = i / C4;
+  const int c = (int)(i - row * C4);
+  const long long smp = row / T;
+  const int t = (int)(row - smp * T) - (T - tail);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long src = (smp * tail + t) * C4 + c;
+  da[i] = t >= 0 ? da_t[src] : zero;
+  if (db) db[i] = t >= 0 ? db_t[src] : zero;
+}
+
 }  // namespace pdae
+
+static int tail_check(int B, int T, int tail, int C) {
+  if (B < 0 || T <= 0 || tail <= 0 || tail > T || C <= 0 || C % 4 != 0) return bad_arg("tail_rows: B >= 0, 0 < tail <= T, C a positive multiple of 4");
+  return PDAE_OK;
+}
+extern "C" int pdae_tail_rows_gather(int B, int T, int tail, int C, const float* a, const float* b, float* a_t, float* b_t,
+                                     pdae_stream_t stream) {
+  using namespace pdae;
+  int rc = tail_check(B, T, tail, C);
+  if (rc) return rc;
+  if (B == 0) return PDAE_OK;
+  if (!a || !a_t || (b && !b_t)) return bad_arg("tail_rows_gather: null pointer");
+  const long long n4 = (long long)B * tail * (C / 4);
+  hipLaunchKernelGGL(tail_rows_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), n4, C / 4, T, tail,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(a_t),
+                     reinterpret_cast<float4*>(b_t));
+  return check_launch("tail_rows_gather");
+}
+extern "C" int pdae_tail_rows_scatter(int B, int T, int tail, int C, const float* da_t, const float* db_t, float* da, float* db,
+                                      pdae_stream_t stream) {
+  using namespace pdae;
+  int rc = tail_check(B, T, tail, C);
+  if (rc) return rc;
+  if (B == 0) return PDAE_OK;
+  if (!da_t || !da || (db && !db_t)) return bad_arg("tail_rows_scatter: null pointer");
+  const long long n4 = (long long)B * T * (C / 4);
+  hipLaunchKernelGGL(tail_rows_scatter_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), n4, C / 4, T, tail,
+                     reinterpret_cast<const float4*>(da_t), reinterpret_cast<const float4*>(db_t), reinterpret_cast<float4*>(da),
+                     reinterpret_cast<float4*>(db));
+  return check_launch("tail_rows_scatter");
+}
 
 extern "C" int pdae_drop_path_keep(int sites, int B, const float* r, const float* keep, float* out, pdae_stream_t stream) {
   using namespace pdae;

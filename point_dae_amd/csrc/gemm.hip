@@ -231,7 +231,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_nt_kernel(con
 #ifndef PDAE_NT_NO_SGB
       // issue order: one fragment read of the next k-group behind every four MFMAs (the reads
       // then never queue up in front of an MFMA that needs them; measured 99 -> 104 TFLOP/s in
-      // tools/lab/gemm_lab2.hip), the next slab's global loads behind the first MFMAs
+      // tools/lab/NOTES.md), the next slab's global loads behind the first MFMAs
       if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, LA + LB, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

@@ -185,7 +185,7 @@ void rows_gemm_kernel(const Args p) {
   // register set `ld` and the set `st` (tile kt + 1) goes to LDS[buf ^ 1]; one barrier.
   // ONE wave per SIMD issues in order: eight global loads in a row in front of the MFMAs leave the
   // matrix pipe idle for ~640 cycles per k-tile, eight ds_write_b128 in a row for ~370 (in-kernel
-  // stamps, tools/lab/stamps.py), while one or two memory instructions behind a group of four
+  // stamps: tools/lab/NOTES.md), while one or two memory instructions behind a group of four
   // MFMAs (256 cycles) are free.  So the order is written out -- after MFMA group (s, i, j) come
   // its share of the global loads (slab 0), of the LDS stores (slab 1 with two register sets: their
   // data landed a k-tile ago) and of the next slab's fragment reads -- and a sched_barrier keeps the
@@ -666,7 +666,7 @@ static void plan_rows(int M, int N, int K, bool bkn, bool may_split, int* cfg, i
     const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
     const int kt = (K + BK - 1) / BK;
     // the first grid whose tiles are cut into at most THREE pieces: a slab is a 5.5 MB write for the producer and a
-    // 5.5 MB read for the LayerNorm that adds it (tools/lab/stream_sweep.sh: 4 slabs 12.71, 3 slabs 12.68, 2 slabs
+    // 5.5 MB read for the LayerNorm that adds it (tools/lab/NOTES.md: 4 slabs 12.71, 3 slabs 12.68, 2 slabs
     // 12.71 ms/step; 768 / 512 blocks at most 12.71-12.73)
     constexpr int lab_pmax = 1024, lab_smax = 3;
     constexpr bool lab_768 = false;

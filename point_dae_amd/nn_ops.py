@@ -677,8 +677,12 @@ class _TransformerBlock(torch.autograd.Function):
             # masked tokens, PointCAE_transformer.py:229-231): everything after the attention core is
             # row-wise, so it runs on those rows alone.  Same values on them, zero gradient elsewhere.
             Tt = tail
-            o_t = o.view(B, T, -1)[:, T - tail:].reshape(B * tail, -1)
-            x1_t = x1.view(B, T, C)[:, T - tail:].reshape(B * tail, C)
+            o_t, x1_t = _empty((B * tail, H * D), res), _empty((B * tail, C), res)
+            if H * D == C:                     # both slices in one launch (csrc/block.hip tail_rows_gather)
+                _lib.call('pdae_tail_rows_gather', res, B, T, tail, C, _lib.ptr(o), _lib.ptr(x1), _lib.ptr(o_t), _lib.ptr(x1_t))
+            else:
+                _lib.call('pdae_tail_rows_gather', res, B, T, tail, H * D, _lib.ptr(o), None, _lib.ptr(o_t), None)
+                _lib.call('pdae_tail_rows_gather', res, B, T, tail, C, _lib.ptr(x1), None, _lib.ptr(x1_t), None)
         else:
             Tt, o_t, x1_t = T, o, x1
         a1 = rows_gemm(o_t, wproj, may_split=True)
@@ -714,11 +718,11 @@ class _TransformerBlock(torch.autograd.Function):
         o_t = o
         if tail:                               # rows outside the tail: zero gradient from this block's second half
             C = x1.shape[1]
-            o_t = o.view(B, T, -1)[:, T - tail:].reshape(B * tail, -1)
-            full = torch.zeros(2, B, T, C, device=x1.device, dtype=x1.dtype)
-            full[0, :, T - tail:] = do.view(B, tail, C)
-            full[1, :, T - tail:] = dx1.view(B, tail, C)
-            do, dx1 = full[0].view(B * T, C), full[1].view(B * T, C)
+            o_t = _empty((B * tail, o.shape[1]), x1)
+            _lib.call('pdae_tail_rows_gather', x1, B, T, tail, o.shape[1], _lib.ptr(o), None, _lib.ptr(o_t), None)
+            full = _empty((2, B * T, C), x1)
+            _lib.call('pdae_tail_rows_scatter', x1, B, T, tail, C, _lib.ptr(do), _lib.ptr(dx1), _lib.ptr(full[0]), _lib.ptr(full[1]))
+            do, dx1 = full[0], full[1]
         dqkv = torch.empty_like(qkv)
         _lib.call('pdae_attention_backward', qkv, B, T, H, D, scale, _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse),
                   _lib.ptr(do), _lib.ptr(dqkv))
