@@ -78,3 +78,15 @@ def test_product_has_no_library_gemm_call_sites():
                 if pat.search(code) or re.search(r'[\w\)\]] @ [\w\(]', code):
                     hits.append('%s:%d %s' % (name, i, line.strip()))
     assert not hits, hits
+
+
+def test_library_is_built_without_slp_packed_fp32():
+    """csrc/Makefile keeps `-fno-slp-vectorize`: hipcc's SLP vectoriser packs scalar fp32 accumulations into
+    v_pk_{fma,mul,add}_f32 with operand selects, which gfx950 computes wrongly (low halves, lanes 16-31) while another
+    wave of the CU runs bf16 MFMAs beside ds_read_b128 -- another stream or another process (tools/xproc_repro.hip,
+    INTEGRATION.md).  __graft_entry__.build() must not override the flags either."""
+    with open(os.path.join(ROOT, 'point_dae_amd', 'csrc', 'Makefile')) as f:
+        flags = [ln for ln in f if ln.startswith('FLAGS')]
+    assert flags and '-fno-slp-vectorize' in flags[0] and '-ffp-contract=off' in flags[0], flags
+    with open(os.path.join(ROOT, '__graft_entry__.py')) as f:
+        assert 'FLAGS=' not in f.read()

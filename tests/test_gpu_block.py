@@ -220,3 +220,32 @@ def test_residual_layernorm_equals_unfused(B, T, C, with_keep, with_pos):
     for x, y_ in zip(f[2:], u[2:]):
         if x is not None:
             _close(x, y_, 2e-5)
+
+
+@pytest.mark.parametrize('B,T,tail,C', [(128, 64, 41, 384), (3, 7, 7, 8), (5, 9, 1, 12)])
+def test_tail_rows_gather_and_scatter(B, T, tail, C):
+    """The decoder's last block works on the returned (last `tail`) tokens of every sample only
+    (models/PointCAE_transformer.py:225-232): one gather launch for up to two tensors, one scatter launch back into
+    full-size gradients that are ZERO outside the tail -- against plain slicing."""
+    from point_dae_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(B * 100 + T)
+    a = torch.randn(B * T, C, device='cuda', generator=g)
+    b = torch.randn(B * T, C, device='cuda', generator=g)
+    a_t = torch.full((B * tail, C), float('nan'), device='cuda')
+    b_t = torch.full((B * tail, C), float('nan'), device='cuda')
+    _lib.call('pdae_tail_rows_gather', a, B, T, tail, C, a.data_ptr(), b.data_ptr(), a_t.data_ptr(), b_t.data_ptr())
+    assert torch.equal(a_t, a.view(B, T, C)[:, T - tail:].reshape(B * tail, C))
+    assert torch.equal(b_t, b.view(B, T, C)[:, T - tail:].reshape(B * tail, C))
+    one = torch.full((B * tail, C), float('nan'), device='cuda')
+    _lib.call('pdae_tail_rows_gather', a, B, T, tail, C, a.data_ptr(), None, one.data_ptr(), None)
+    assert torch.equal(one, a_t)
+    da = torch.full((B * T, C), float('nan'), device='cuda')
+    db = torch.full((B * T, C), float('nan'), device='cuda')
+    _lib.call('pdae_tail_rows_scatter', a, B, T, tail, C, a_t.data_ptr(), b_t.data_ptr(), da.data_ptr(), db.data_ptr())
+    want = torch.zeros(B, T, C, device='cuda')
+    want[:, T - tail:] = a_t.view(B, tail, C)
+    assert torch.equal(da, want.view(B * T, C))
+    want[:, T - tail:] = b_t.view(B, tail, C)
+    assert torch.equal(db, want.view(B * T, C))
+    with pytest.raises(RuntimeError, match='tail'):
+        _lib.call('pdae_tail_rows_gather', a, B, T, T + 1, C, a.data_ptr(), None, one.data_ptr(), None)
