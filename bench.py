@@ -346,11 +346,38 @@ def cfg2_leg(args, device, rank):
     us = _event_time_us(lambda: _lib.call('pdae_chamfer_forward', fine, B, 16384, _lib.ptr(fine), N, _lib.ptr(gt),
                                           _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2)), iters=5, warm=2)
     pairs = B * 2 * 16384 * N
+    # the leg's dominant kernels are GEMMs too (the FoldingNet stage's 2.1 M-row products and their weight gradients): one
+    # eager pass of the step body under the launch-site probe, the families' launches replayed as one hipGraph each
+    from point_dae_amd import nn_ops
+    gemm_roof = None
+    try:
+        probe = nn_ops.Probe()
+        probe.keep_calls = True
+        nn_ops.set_probe(probe)
+        gstep._fwd_bwd()
+        torch.cuda.synchronize()
+        nn_ops.set_probe(None)
+        probe.keep_calls = False
+        fam = probe.family_summary()
+        rep = probe.family_replay_ms(replays=3)
+        probe.calls = {}
+        keys = [k for k in ('rows_gemm', 'rows_wgrad') if k in fam and k in rep]
+        gf, ms = sum(fam[k]['flops'] for k in keys) / 1e9, sum(rep[k] for k in keys)
+        gemm_roof = {'kernel': 'rows3::gemm3_kernel + rows3::wgrad3b_kernel (row-GEMM family of the cfg2 step)', 'bound': 'mfma',
+                     'gflop_per_step': gf, 'ms_per_step': ms, 'achieved': gf / ms, 'peak': BF16X3_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': gf / ms / BF16X3_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': gf / ms / MFMA_F32_PEAK_TFLOPS,
+                     'algorithmic_bytes': sum(fam[k]['bytes'] for k in keys),
+                     'families': {k: {'gflop': fam[k]['flops'] / 1e9, 'ms': rep[k], 'launches': fam[k]['launches']} for k in keys}}
+    except Exception as err:                                   # a measurement aid: never fails the bench line
+        nn_ops.set_probe(None)
+        gemm_roof = {'error': repr(err)[:200]}
+    model.zero_grad()
     del model, optimizer, gstep
     return {'workload': 'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2), '
                         'B=128, N=1024, full train step, hipGraph replay',
             'value': B * args.also_steps / dt, 'unit': 'clouds/s', 'ms_per_step': dt / args.also_steps * 1e3,
             'steps': args.also_steps,
+            'roofline_gemm': gemm_roof,
             'roofline': {'kernel': 'chamfer_fwd_tiled (128 x 16384 x 1024)', 'bound': 'valu', 'avg_us': us,
                          'achieved': pairs * 9 / (us * 1e-6) / 1e12, 'peak': VALU_F32_PEAK_TOPS, 'unit': 'T op/s',
                          'frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),

@@ -13,12 +13,12 @@ def split3(x):
     out = torch.empty(3, *x.shape, device=x.device, dtype=torch.int16)
     assert lab.lab_split3(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), st()) == 0
     return out
-for (M, N, K, zero) in [(512, 512, 16384, 0), (2048, 2048, 16384, 0), (2048, 2048, 16384, 1), (4096, 4096, 4096, 0), (65536, 512, 512, 0)]:
+for (M, N, K, zero) in [tuple(int(t) for t in sh.split('x')) for sh in os.environ.get('SHAPES', '512x512x16384x0,2048x2048x16384x0,2048x2048x16384x1,4096x4096x4096x0,65536x512x512x0').split(',')]:
     A = torch.randn(M, K, device='cuda') * (0 if zero else 1)
     W = torch.randn(N, K, device='cuda') * (0 if zero else 1)
     A3, W3 = split3(A), split3(W)
     C = torch.empty(M, N, device='cuda')
-    for v in (0, 5):
+    for v in [int(t) for t in os.environ.get('VARIANTS', '0,5').split(',')]:
         stamps = torch.zeros(4096, 4, dtype=torch.int64, device='cuda')
         f = lambda: lab.lab_gemm3p(v, M, N, K, A3.data_ptr(), W3.data_ptr(), C.data_ptr(), 1, st(), stamps.data_ptr())
         for _ in range(20):

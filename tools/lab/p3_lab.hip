@@ -12,14 +12,14 @@ extern "C" int lab_split3(const float* x, long long R, int C, unsigned short* ou
   return (int)hipGetLastError();
 }
 
-template <int TJ, int NBUF, int SCHED = 0>
+template <int TJ, int NBUF, int SCHED = 0, int ABL = 0>
 static int launch(PArgs a, int splits, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TJ;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
   a.kchunk = ((a.K / splits + 31) / 32) * 32;
   const size_t lds = (size_t)NBUF * 3 * (BM + BN) * 64;
-  auto k = gemm3p_kernel<TJ, rows::EPI_STORE, NBUF, SCHED>;
+  auto k = gemm3p_kernel<TJ, rows::EPI_STORE, NBUF, SCHED, ABL>;
   static bool once = false;
   if (!once) {
     once = true;
@@ -46,5 +46,11 @@ extern "C" int lab_gemm3p(int variant, int M, int N, int K, const unsigned short
   if (variant == 4) return launch<1, 2>(a, splits, s);
   if (variant == 5) return launch<2, 3, 1>(a, splits, s);
   if (variant == 6) return launch<1, 3, 1>(a, splits, s);
+  if (variant == 11) return launch<2, 3, 1, 1>(a, splits, s);
+  if (variant == 12) return launch<2, 3, 1, 2>(a, splits, s);
+  if (variant == 14) return launch<2, 3, 1, 4>(a, splits, s);
+  if (variant == 18) return launch<2, 3, 1, 8>(a, splits, s);
+  if (variant == 15) return launch<2, 3, 1, 15>(a, splits, s);
+  if (variant == 13) return launch<2, 3, 1, 3>(a, splits, s);
   return -1;
 }

@@ -64,7 +64,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 //                              wave has read tile t's last fragments)
 //   slots [SB, S)            + the LDS-DMAs of tile t + NBUF into the buffer tile t occupied, the fragment reads of
 //                              tile t + 1, step 0
-template <int TJ, int EPI, int NBUF, int SCHED = 0>
+template <int TJ, int EPI, int NBUF, int SCHED = 0, int ABL = 0>   // ABL (lab, SCHED 1): 1 no barrier, 2 no fragment reads, 4 no DMAs, 8 no vmcnt wait
 __global__ __launch_bounds__(512) void gemm3p_kernel(const PArgs p) {
   constexpr int TI = 1, WN = 2, BM = 128, BN = 64 * TJ, G = TI * TJ;
   constexpr int ROWB = 64, BKT = 32;
@@ -212,24 +212,26 @@ __global__ __launch_bounds__(512) void gemm3p_kernel(const PArgs p) {
       constexpr int s = decltype(s_c)::value;
       constexpr int step = s / HS, g = (s % HS) / 6, q = s % 6;
       mfma_one<DUAL, q>(fa[step][g / TJ], fb[step][g % TJ], hi[g / TJ][g % TJ], lo[g / TJ][g % TJ]);
-      if constexpr (s < HS) {
+      if constexpr (s < HS && !(ABL & 2)) {
         static_for<NF>([&](auto f_c) {
           constexpr int f = decltype(f_c)::value;
           if constexpr (f * HS / NF == s) frag_one(f_c, C1{}, cur, 1);
         });
       }
-      if (more) {
+      if (more && !(ABL & 4)) {
         static_for<CW>([&](auto j_c) {
           constexpr int j = decltype(j_c)::value;
           if constexpr ((j * S) / CW == s) issue(j_c, kt + 2, fill);
         });
       }
       if constexpr (s == SBAR) {
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 8)) {
+          if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
       }
-      if constexpr (s >= HS) {
+      if constexpr (s >= HS && !(ABL & 2)) {
         static_for<NF>([&](auto f_c) {
           constexpr int f = decltype(f_c)::value;
           if constexpr (f * FS / NF == s - HS) frag_one(f_c, C0{}, nxt, 0);
