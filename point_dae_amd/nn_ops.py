@@ -372,8 +372,12 @@ def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False, big_c
             cfg, _, _ = _lib.rows_gemm_plan(m1 - m0, N, K, w_kn, False)
             if big_cfg is not None and cfg < 16 and BIG_TILES and m1 - m0 >= BIG_ROWS:
                 cfg = big_cfg
-            _lib.call('pdae_rows_gemm', x, m1 - m0, N, K, _lib.ptr(x[m0:m1]), _lib.ptr(w), int(w_kn), _lib.ptr(bias),
-                      epi, _lib.ptr(z[m0:m1]) if z is not None else None, _lib.ptr(y[m0:m1]), cfg, 1, 0)
+            rows_c = m1 - m0
+            probed_family('rows_gemm', 2.0 * rows_c * N * K,
+                          lambda m0=m0, m1=m1, rows_c=rows_c, cfg=cfg: _lib.call(
+                              'pdae_rows_gemm', x, rows_c, N, K, _lib.ptr(x[m0:m1]), _lib.ptr(w), int(w_kn), _lib.ptr(bias), epi,
+                              _lib.ptr(z[m0:m1]) if z is not None else None, _lib.ptr(y[m0:m1]), cfg, 1, 0),
+                          nbytes=4.0 * (rows_c * K + N * K + rows_c * N + (rows_c * N if z is not None else 0)))
         return y
     cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, may_split)
     if big_cfg is not None and cfg < 16 and M >= BIG_ROWS and splits == 1 and BIG_TILES:
