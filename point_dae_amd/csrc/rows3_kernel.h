@@ -454,6 +454,16 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
 
     float ra[2][8], rb[2][8];
     u32x4 pka[3], pkb[3];
+    // byte offsets of this thread's patch (rows 8 kg .. 8 kg + 7 of a 32-row tile, one column) from the tile's first row:
+    // with them a whole tile's sixteen loads share ONE scalar base per operand (global_load_dword v, voff, s[base]) -- the
+    // per-row 64-bit pointer arithmetic was 142 of this loop's 388 instructions per tile and wave, and a wave issues one
+    // instruction every ~4 cycles: more than the 1536 cycles the matrix pipe needs for the tile (tools/lab/NOTES.md)
+    unsigned voa[8], vob[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      voa[q] = ((unsigned)(8 * kg + q) * lda + acol) * 4u;
+      vob[q] = ((unsigned)(8 * kg + q) * ldb + bcol) * 4u;
+    }
     auto gload = [&](auto set_c, int kt) __attribute__((always_inline)) {
       constexpr int set = decltype(set_c)::value;
       const int mt = mbeg + min(kt, KT - 1) * BKT;
@@ -463,11 +473,21 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
         if (grp_a) offa = (grp_a[gq] - gq) * 32;
         if (grp_b) offb = (grp_b[gq] - gq) * 32;
       }
+      if (mt + BKT <= mend) {                          // (block-uniform) a whole tile: no row clamps
+        const char* pa = reinterpret_cast<const char*>(Ab + (size_t)(mt + offa) * lda);
+        const char* pb = reinterpret_cast<const char*>(Bb + (size_t)(mt + offb) * ldb);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int m = min(mt + 8 * kg_u + q, mlast);   // (scalar; rows past the end re-read the last row)
-        ra[set][q] = *(Ab + (size_t)(m + offa) * lda + acol);
-        rb[set][q] = *(Bb + (size_t)(m + offb) * ldb + bcol);
+        for (int q = 0; q < 8; ++q) {
+          ra[set][q] = *reinterpret_cast<const float*>(pa + voa[q]);
+          rb[set][q] = *reinterpret_cast<const float*>(pb + vob[q]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int m = min(mt + 8 * kg_u + q, mlast);   // (scalar; rows past the end re-read the last row)
+          ra[set][q] = *(Ab + (size_t)(m + offa) * lda + acol);
+          rb[set][q] = *(Bb + (size_t)(m + offb) * ldb + bcol);
+        }
       }
     };
     // what a register set still needs before it is split: producer, zeros past the edges, the column sums
