@@ -38,16 +38,17 @@ def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
-def feature_knn(x_rows, B, N, k=K_GRAPH):
+def feature_knn(x_rows, B, N, k=K_GRAPH, out=None):
     """x_rows (B*N, C), C % 4 == 0 -> (B, N, k) int32 neighbour ids within the cloud (dgcnn_util.knn :7-12):
-    Gram matrices on the batched row GEMM, the reference's distance expression and its top-k on one wave per row."""
+    Gram matrices on the batched row GEMM, the reference's distance expression and its top-k on one wave per row.
+    out: a (B, N, k) int32 tensor to fill (the encoder keeps its four graphs in one allocation)."""
     x = x_rows.detach()
     C = x.shape[1]
     gram = _empty((B, N, N), x)
     _lib.call('pdae_rows_gemm_batched', x, B, N, N, C, _lib.ptr(x), N * C, _lib.ptr(x), N * C, _lib.ptr(gram), N * N)
     xx = _empty((B * N,), x)
     _lib.call('pdae_rows_sqnorm', x, B * N, C, _lib.ptr(x), _lib.ptr(xx))
-    idx = _empty((B, N, k), x, torch.int32)
+    idx = _empty((B, N, k), x, torch.int32) if out is None else out
     _lib.call('pdae_gram_topk', x, B, N, k, _lib.ptr(gram), _lib.ptr(xx), _lib.ptr(idx))
     return idx
 
@@ -78,12 +79,13 @@ class _Encoder(torch.autograd.Function):
         _lib.call('pdae_rows_pad', pts, R, cin, x.shape[1], _lib.ptr(pts.contiguous()), _lib.ptr(x))
         cat = _empty((R, sum(w.shape[0] for w in convs[:4])), pts)
         saved, off = [], 0
+        graphs = _empty((4, B, N, k), pts, torch.int32)            # the four layers' graphs: ONE reverse-graph launch backward
         for li in range(4):
             gamma, bn = gammas[li], bns[li]
             co, kp = convs[li].shape[0], x.shape[1]
             w = _empty((2 * co, kp), x)                             # [W1; W2 - W1], K padded like x
             _lib.call('pdae_edge_weight_stack', x, co, cin, kp, _lib.ptr(convs[li].contiguous()), _lib.ptr(w))
-            idx = feature_knn(x, B, N, k)
+            idx = feature_knn(x, B, N, k, out=graphs[li])
             pq = nn_ops.rows_gemm(x, w)
             esel, psum = _empty((R, co), x), _empty((R, co), x)
             sel = _empty((R, co), x, torch.int16)
@@ -114,7 +116,7 @@ class _Encoder(torch.autograd.Function):
             sc5, sh5, mean5, is5 = (t.contiguous() for t in _eval_affine(bn5))
         feat = _empty((B, C5), x)
         _lib.call('pdae_bn_lrelu_rows', x, B, C5, _lib.ptr(ysel), _lib.ptr(sc5), _lib.ptr(sh5), _lib.ptr(feat), None, 0)
-        ctx.layers, ctx.top = saved, (cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5)
+        ctx.layers, ctx.top, ctx.graphs = saved, (cat, w5, y5, ysel, arow, sc5, sh5, mean5, is5), graphs
         ctx.dims = (B, N, k)
         ctx.training = bool(training)
         ctx.shapes = [c.shape for c in convs]
@@ -145,6 +147,9 @@ class _Encoder(torch.autograd.Function):
         grads[12], grads[13], grads[14] = nn_ops.rows_wgrad([dy5], [cat], [False])[0][0].view(ctx.shapes[4]), dgamma, dbeta
         del dy5
         dx, off = None, cat.shape[1]
+        # the reverse graphs (for every point the points that list it) of all four layers in one launch of 4 B blocks
+        rev_start, rev_src = _empty((4, B, N + 1), dfeat, torch.int32), _empty((4, B, N * k), dfeat, torch.int32)
+        _lib.call('pdae_knn_reverse', dfeat, 4 * B, N, k, _lib.ptr(ctx.graphs), _lib.ptr(rev_start), _lib.ptr(rev_src))
         for li in (3, 2, 1, 0):
             x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd, cin = ctx.layers[li]
             co = w.shape[0] // 2
@@ -157,11 +162,9 @@ class _Encoder(torch.autograd.Function):
                       _lib.ptr(part), _lib.ptr(sums), _lib.ptr(dgamma), _lib.ptr(dbeta))
             if not ctx.training:
                 sums.zero_()
-            rev_start, rev_src = _empty((B, N + 1), dfeat, torch.int32), _empty((B, N * k), dfeat, torch.int32)
-            _lib.call('pdae_knn_reverse', dfeat, B, N, k, _lib.ptr(idx), _lib.ptr(rev_start), _lib.ptr(rev_src))
             dpq = _empty((R, 2 * co), dfeat)
             _lib.call('pdae_edge_backward', dfeat, B, N, k, co, _lib.ptr(g), _lib.ptr(pq), _lib.ptr(sel), _lib.ptr(psum),
-                      _lib.ptr(rev_start), _lib.ptr(rev_src), _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd),
+                      _lib.ptr(rev_start[li]), _lib.ptr(rev_src[li]), _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd),
                       _lib.ptr(sums), _lib.ptr(dpq))
             dws = nn_ops.rows_wgrad([dpq], [x], [False])[0][0]
             dconv = _empty(ctx.shapes[li], dfeat)

@@ -105,7 +105,7 @@ def test_encoder_equals_the_dense_edge_formulation(B, N, monkeypatch):
                 bn.bias.copy_(torch.linspace(-0.3, 0.3, bn.bias.numel()))
     x = torch.randn(B, 3, N, device='cuda')
     graphs = []
-    monkeypatch.setattr(D, 'feature_knn', lambda *a: graphs.append(feature_knn(*a)) or graphs[-1])
+    monkeypatch.setattr(D, 'feature_knn', lambda *a, **kw: graphs.append(feature_knn(*a, **kw)) or graphs[-1])
     feat = enc(x)
     tgt = torch.randn_like(feat)
     (feat * tgt).sum().backward()
@@ -149,7 +149,7 @@ def test_eval_mode_uses_the_running_estimates(monkeypatch):
     enc.eval()
     x = torch.randn(B, 3, N, device='cuda')
     graphs = []
-    monkeypatch.setattr(D, 'feature_knn', lambda *a: graphs.append(feature_knn(*a)) or graphs[-1])
+    monkeypatch.setattr(D, 'feature_knn', lambda *a, **kw: graphs.append(feature_knn(*a, **kw)) or graphs[-1])
     with torch.no_grad():
         feat = enc(x)
         rows = x.transpose(1, 2).reshape(B * N, 3)
@@ -186,7 +186,7 @@ def test_eval_mode_gradients_have_no_batch_statistic_terms(monkeypatch):
     enc.eval()
     x = torch.randn(B, 3, N, device='cuda')
     graphs = []
-    monkeypatch.setattr(D, 'feature_knn', lambda *a: graphs.append(feature_knn(*a)) or graphs[-1])
+    monkeypatch.setattr(D, 'feature_knn', lambda *a, **kw: graphs.append(feature_knn(*a, **kw)) or graphs[-1])
     feat = enc(x)
     tgt = torch.randn_like(feat)
     (feat * tgt).sum().backward()
