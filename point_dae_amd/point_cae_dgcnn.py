@@ -150,6 +150,7 @@ class _Encoder(torch.autograd.Function):
         # the reverse graphs (for every point the points that list it) of all four layers in one launch of 4 B blocks
         rev_start, rev_src = _empty((4, B, N + 1), dfeat, torch.int32), _empty((4, B, N * k), dfeat, torch.int32)
         _lib.call('pdae_knn_reverse', dfeat, 4 * B, N, k, _lib.ptr(ctx.graphs), _lib.ptr(rev_start), _lib.ptr(rev_src))
+        queue = []
         for li in (3, 2, 1, 0):
             x, w, idx, pq, esel, sel, psum, scale, shift, mean, invstd, cin = ctx.layers[li]
             co = w.shape[0] // 2
@@ -166,11 +167,16 @@ class _Encoder(torch.autograd.Function):
             _lib.call('pdae_edge_backward', dfeat, B, N, k, co, _lib.ptr(g), _lib.ptr(pq), _lib.ptr(sel), _lib.ptr(psum),
                       _lib.ptr(rev_start[li]), _lib.ptr(rev_src[li]), _lib.ptr(scale), _lib.ptr(mean), _lib.ptr(invstd),
                       _lib.ptr(sums), _lib.ptr(dpq))
-            dws = nn_ops.rows_wgrad([dpq], [x], [False])[0][0]
-            dconv = _empty(ctx.shapes[li], dfeat)
-            _lib.call('pdae_edge_weight_unstack', dfeat, co, cin, x.shape[1], _lib.ptr(dws), _lib.ptr(dconv))
-            grads[3 * li], grads[3 * li + 1], grads[3 * li + 2] = dconv, dgamma, dbeta
+            queue.append((li, dpq, x, co, cin))
+            grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
             dx = nn_ops.rows_gemm(dpq, w, True) if li > 0 else None
+        # the four stacked-weight gradients [dW1; d(W2 - W1)] = dpq^T x share their rows: ONE grouped launch (+ one ordered
+        # reduction) instead of four of each
+        dws = nn_ops.rows_wgrad([q[1] for q in queue], [q[2] for q in queue], [False] * len(queue))[0]
+        for (li, _, x, co, cin), dw in zip(queue, dws):
+            dconv = _empty(ctx.shapes[li], dfeat)
+            _lib.call('pdae_edge_weight_unstack', dfeat, co, cin, x.shape[1], _lib.ptr(dw), _lib.ptr(dconv))
+            grads[3 * li] = dconv
         return (None, None, None, None, None) + tuple(grads)
 
 
