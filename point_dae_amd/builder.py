@@ -121,10 +121,13 @@ def build_opti_sche(base_model, config):
     else:
         raise NotImplementedError(sc.type)
     if config.get('bnmscheduler') is not None:
-        # builder.py:147-151 adds a BatchNorm-momentum schedule (utils/misc.py:34-40, :97-127); no shipped pretraining
-        # YAML has one, and the captured step graphs bake the momentum into their kernel arguments: refused rather
-        # than silently ignored
-        raise NotImplementedError('bnmscheduler: BatchNorm momentum schedules are not supported by the graphed steps')
+        # builder.py:147-151: a BatchNorm-momentum schedule beside the learning-rate one (utils/misc.py:34-40, :97-127);
+        # the runner steps both per epoch and lets a changed momentum invalidate the captured step graphs
+        from .misc import build_lambda_bnsche
+        bc = config.bnmscheduler
+        if bc.type != 'Lambda':
+            raise NotImplementedError('bnmscheduler type %r' % (bc.type,))
+        scheduler = [scheduler, build_lambda_bnsche(base_model, bc.kwargs)]
     return optimizer, scheduler
 
 

@@ -155,6 +155,12 @@ class GraphedTrainStep:
         self.micro = 0
         self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
 
+    def invalidate(self):
+        """Drop the captured graphs: a value they hold as a kernel argument changed (the BatchNorm momentum of
+        misc.BNMomentumScheduler); the next step of every T_vis captures again."""
+        self.graphs.clear()
+        self.outputs.clear()
+
     def reset_micro(self):
         """the reference restarts its micro-step counter at every epoch (runner_pretrain.py:112), gradients carry over"""
         self.micro = 0
@@ -404,6 +410,10 @@ class GraphedStaticStep:
         self.eager_left = warmup_eager
         self.spu, self.micro = int(step_per_update), 0
         self.accum = torch.zeros_like(model.flat_grad) if self.spu > 1 else None
+
+    def invalidate(self):
+        """Drop the captured graph (misc.BNMomentumScheduler: the momentum is a kernel argument); re-captured by the next step."""
+        self.graph, self.out = None, None
 
     def reset_micro(self):
         self.micro = 0

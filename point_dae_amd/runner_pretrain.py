@@ -115,6 +115,10 @@ def run_net(args, config, train_writer=None, val_writer=None, log=print, log_eve
         # a model that draws a corruption on the host inside forward (`dropout_global`) cannot be captured -- the
         # draw would be frozen into the graph, and the surviving point count changes from step to step
         step_fn = None
+    if graphed is not None:
+        for item in (scheduler if isinstance(scheduler, list) else []):
+            if hasattr(item, 'listeners'):                  # misc.BNMomentumScheduler: a new momentum re-captures the graphs
+                item.listeners.append(graphed.invalidate)
     if rank == 0:
         log('step: %s' % ('eager' if step_fn is None else 'hipGraph replay (%s, step_per_update %d, loss_type %s)' % (
             type(graphed).__name__, spu, config.loss_type)))

@@ -183,8 +183,9 @@ def test_writes_the_reference_checkpoint_layout(tmp_path):
     assert len(sd['optimizer']['state']) == LAYOUT['optimizer']['state_entries']
 
 
-def test_lambda_lr_schedule_and_refused_bn_momentum_schedule():
-    """builder.py:117-118 -> utils/misc.py:26-32: lr(e) = lr * max(lr_decay ** (e / decay_step), lowest_decay)."""
+def test_lambda_lr_schedule_and_bn_momentum_schedule():
+    """builder.py:117-118 -> utils/misc.py:26-32: lr(e) = lr * max(lr_decay ** (e / decay_step), lowest_decay);
+    builder.py:147-151 -> utils/misc.py:34-40, :97-127: the BatchNorm momentum schedule beside it, as a [lr, bn] list."""
     from point_dae_amd.config import cfg_from_yaml_file
     config = cfg_from_yaml_file(os.path.join(
         ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
@@ -196,6 +197,22 @@ def test_lambda_lr_schedule_and_refused_bn_momentum_schedule():
     for e in (0, 1, 21, 100, 400):
         sch.step(e)
         assert opt.param_groups[0]['lr'] == pytest.approx(lr * max(0.76 ** (e / 21), 0.02), rel=1e-12)
-    config.bnmscheduler = type(config.scheduler)(type='Lambda', kwargs={})
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4), torch.nn.Sequential(torch.nn.BatchNorm2d(2)))
+    config.bnmscheduler = type(config.scheduler)(
+        type='Lambda', kwargs=type(config.scheduler.kwargs)(decay_step=21, bn_decay=0.5, bn_momentum=0.9, lowest_decay=0.01))
+    opt, sch = builder.build_opti_sche(net, config)
+    assert isinstance(sch, list) and len(sch) == 2
+    bns = [m for m in net.modules() if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d))]
+    assert len(bns) == 2 and all(m.momentum == 0.9 for m in bns)           # the constructor steps to epoch 0 (:114)
+    calls = []
+    sch[1].listeners.append(lambda: calls.append(sch[1].current))
+    for e in (0, 1, 21, 42, 400, 401):
+        for item in sch:                                                       # runner_pretrain.py:237-241
+            item.step(e)
+        want = max(0.9 * 0.5 ** (e / 21), 0.01)
+        assert all(m.momentum == pytest.approx(want, rel=1e-12) for m in bns)
+        assert sch[1].get_momentum(e) == pytest.approx(want, rel=1e-12)
+    assert len(calls) == 4 and calls[-1] == 0.01                              # epoch 0 and 401 changed nothing: no re-capture
+    config.bnmscheduler.type = 'Step'
     with pytest.raises(NotImplementedError, match='bnmscheduler'):
         builder.build_opti_sche(net, config)

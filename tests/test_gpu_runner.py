@@ -220,3 +220,52 @@ def test_graphed_gradient_accumulation_equals_eager_accumulation():
         assert rel <= 1e-4, rel              # (measured 2.3e-5; a dropped micro-step would be ~5e-2)
     finally:
         _lib.set_deterministic(False)
+
+
+def test_bn_momentum_schedule_recaptures_the_step_graphs():
+    """builder.py:147-151 / utils/misc.py:97-127: the captured graphs hold the BatchNorm momentum as a kernel argument; a
+    scheduler step that changes it drops them (GraphedTrainStep.invalidate), so the next replay uses the new value --
+    checked with momentum 0, under which a training step must leave the running estimates where they are."""
+    import os
+    from point_dae_amd import builder
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.misc import set_random_seed
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(
+        root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    # momentum 0.1 at epoch 0, 0 from epoch 1 on
+    config.bnmscheduler = type(config.scheduler)(
+        type='Lambda', kwargs=type(config.scheduler.kwargs)(decay_step=1, bn_decay=0.0, bn_momentum=0.1, lowest_decay=0.0))
+    set_random_seed(0)
+    model = FlatDataParallel(builder.model_builder(config.model).cuda())
+    opt, sch = builder.build_opti_sche(model, config)
+    assert isinstance(sch, list)
+    model.train()
+    model.zero_grad()
+    B = 16
+    pts = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=3)).cuda()
+    step = GraphedTrainStep(model, opt, config, B, 1024, warmup_eager=1)
+    sch[1].listeners.append(step.invalidate)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    assert bns and all(m.momentum == 0.1 for m in bns)
+    for _ in range(6):                                   # eager warm-up, then captures: the estimates move
+        before = [m.running_mean.clone() for m in bns]
+        step(pts)
+        assert any(not torch.equal(a, m.running_mean) for a, m in zip(before, bns))
+    assert len(step.graphs) >= 1
+    for item in sch:
+        if item is not None:
+            item.step(1)
+    assert all(m.momentum == 0.0 for m in bns) and len(step.graphs) == 0
+    for _ in range(6):                                   # re-captured with momentum 0: the estimates stay
+        before = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
+        out = step(pts)
+        assert torch.isfinite(out[0]).all()
+        for (mean, var), m in zip(before, bns):
+            assert torch.equal(mean, m.running_mean) and torch.equal(var, m.running_var)
+    assert len(step.graphs) >= 1
