@@ -436,7 +436,11 @@ int pdae_linear_backward_weight(int M, int N, int K, const float* dY,
  *                piece of a tile goes to slab q of Y, unused slabs of a tile are
  *                zero-filled (`splits` = number of slabs, as planned).
  *   rows_gemm_plan: the (cfg, splits, stream_blocks) rows_gemm would pick;
- *       may_split = 0 keeps splits = 1 and stream_blocks = 0.
+ *       may_split = 0 keeps splits = 1 and stream_blocks = 0; 1 allows up to 4 slabs (what the LayerNorm
+ *       kernels add on their way); 2..8 up to that many (a caller with its own consumer: slab_sum_epi).
+ *   slab_sum_epi: Y (M,N) = epi(sum_s slabs[s] + bias) in slab order, epi 0 store | 1 ReLU | 4 Z > 0 ? . : 0 --
+ *       the Linear layers of the coarse heads (models/PointCAE_DGCNN.py:160-166 recfc, PointCAE_pointnetv2.py:151-156
+ *       folding1, PointCAE_transformer.py coarse_pred) run on 32-128 rows: their reductions are split 8 ways.
  *   rows_wgrad: weight gradients of a GROUP of nprob <= 8 Linear layers that
  *       share M in one launch: dW_p[N_p,K_p] = dY_p[M,N_p]^T . X_p[M,K_p],
  *       db_p[N_p] = column sums of dY_p (db or db[p] nullable).  Pointer arrays
@@ -547,6 +551,8 @@ int pdae_rows_gemm_batched(int batch, int M, int N, int K, const float* X,
                            float* Y, long long strideY, pdae_stream_t stream);
 int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split, int* cfg,
                         int* splits, int* stream_blocks);
+int pdae_slab_sum_epi(int S, int M, int N, const float* slabs /*[S][M][N]*/, const float* bias /*nullable*/, int epi,
+                      const float* Z /*epi 4*/, float* Y, pdae_stream_t stream);
 /* GEMM arithmetic of the row-GEMM family (rows_gemm, rows_wgrad*; the Linear layers the reference runs through
  * cuBLAS sgemm: models/PointCAE_transformer.py:94-158).  Both are fp32 in, fp32 out, fp32 accumulation:
  *   PDAE_GEMM_BF16X3  (default) every operand element is split EXACTLY into three bf16 terms, x = h + m + l, and a

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "pdae_tail_rows_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_tail_rows_scatter": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_pos_embed_fc1": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_slab_sum_epi": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "pdae_residual_layernorm_forward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp],
     "pdae_residual_layernorm_backward": [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "pdae_scale_colsum": [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],

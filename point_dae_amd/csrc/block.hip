@@ -678,6 +678,31 @@ __global__ __launch_bounds__(256) void tail_rows_scatter_kernel(long long n4, in
   if (db) db[i] = t >= 0 ? db_t[src] : zero;
 }
 
+// Y = epi(sum_s slabs[s] + bias): the consumer of split-K slabs where no LayerNorm follows (the coarse heads' Linear
+// layers on a handful of rows: 32 x 1024 x 1024 as ONE 64 x 128 tile per 128 columns keeps 8 CUs busy for 32 k-tiles;
+// in 8 slabs it is 64 blocks of 4 k-tiles + this pass).  Slabs are added in slab order.  epi 0 | 1 ReLU | 4 Z > 0 ? . : 0.
+__global__ __launch_bounds__(256) void slab_sum_epi_kernel(long long n4, int N4, int S, const float4* __restrict__ slabs,
+                                                           const float4* __restrict__ bias, int epi,
+                                                           const float4* __restrict__ z, float4* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = slabs[i];
+  for (int q = 1; q < S; ++q) {
+    const float4 v = slabs[(size_t)q * n4 + i];
+    a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+  }
+  if (bias) {
+    const float4 b = bias[i % N4];
+    a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+  }
+  if (epi == 1) a.x = a.x > 0.f ? a.x : 0.f, a.y = a.y > 0.f ? a.y : 0.f, a.z = a.z > 0.f ? a.z : 0.f, a.w = a.w > 0.f ? a.w : 0.f;
+  if (epi == 4) {
+    const float4 m = z[i];
+    a.x = m.x > 0.f ? a.x : 0.f, a.y = m.y > 0.f ? a.y : 0.f, a.z = m.z > 0.f ? a.z : 0.f, a.w = m.w > 0.f ? a.w : 0.f;
+  }
+  y[i] = a;
+}
+
 }  // namespace pdae
 
 static int tail_check(int B, int T, int tail, int C) {
@@ -709,6 +734,20 @@ extern "C" int pdae_tail_rows_scatter(int B, int T, int tail, int C, const float
                      reinterpret_cast<const float4*>(da_t), reinterpret_cast<const float4*>(db_t), reinterpret_cast<float4*>(da),
                      reinterpret_cast<float4*>(db));
   return check_launch("tail_rows_scatter");
+}
+
+extern "C" int pdae_slab_sum_epi(int S, int M, int N, const float* slabs, const float* bias, int epi, const float* Z, float* Y,
+                                 pdae_stream_t stream) {
+  using namespace pdae;
+  if (S <= 0 || S > 8 || M < 0 || N <= 0 || N % 4 != 0) return bad_arg("slab_sum_epi: 1..8 slabs, M >= 0, N a positive multiple of 4");
+  if (epi != 0 && epi != 1 && epi != 4) return bad_arg("slab_sum_epi: epi 0 (store), 1 (ReLU) or 4 (mask by Z > 0)");
+  if (M == 0) return PDAE_OK;
+  if (!slabs || !Y || (epi == 4 && !Z)) return bad_arg("slab_sum_epi: null pointer");
+  const long long n4 = (long long)M * (N / 4);
+  hipLaunchKernelGGL(slab_sum_epi_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), n4, N / 4, S,
+                     reinterpret_cast<const float4*>(slabs), reinterpret_cast<const float4*>(bias), epi,
+                     reinterpret_cast<const float4*>(Z), reinterpret_cast<float4*>(Y));
+  return check_launch("slab_sum_epi");
 }
 
 extern "C" int pdae_drop_path_keep(int sites, int B, const float* r, const float* keep, float* out, pdae_stream_t stream) {

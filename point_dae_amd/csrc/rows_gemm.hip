@@ -775,14 +775,17 @@ static double plan3_cost(int M, int N, int K, int c3, int splits) {
   if (splits > 1) cost += 0.7 * (splits - 1);
   return cost;
 }
-static void plan_rows3(int M, int N, int K, bool may_split, int* cfg, int* splits, int* stream_blocks) {
+// may_split: 0 = one slab; 1 = up to 4 slabs (the LayerNorm kernels add them on their way); 2..8 = up to that many (a
+// caller with its own slab consumer: a handful of rows against a long reduction, nn_ops.mlp_chain + pdae_slab_sum_epi)
+static void plan_rows3(int M, int N, int K, int may_split, int* cfg, int* splits, int* stream_blocks) {
   double best = 1e300;
   *cfg = rows3::CFG3_BASE, *splits = 1, *stream_blocks = 0;
   static const char* force = getenv("PDAE_ROWS3_FORCE");       // lab: "cfg,splits" overrides every plan
   int fc = -1, fs = -1;
   if (force) sscanf(force, "%d,%d", &fc, &fs);
+  const int smax = may_split <= 0 ? 1 : (may_split == 1 ? 4 : (may_split > 8 ? 8 : may_split));
   for (int c = 0; c < rows3::NCFG3; ++c)
-    for (int s = 1; s <= (may_split ? 4 : 1); ++s) {
+    for (int s = 1; s <= smax; ++s) {
       if (s > 1 && K / s < 128) continue;
       const double t = plan3_cost(M, N, K, c, s);
       if (t < best * 0.995) best = t, *cfg = rows3::CFG3_BASE + c, *splits = s;
@@ -798,7 +801,7 @@ extern "C" int pdae_rows_gemm_plan(int M, int N, int K, int w_kn, int may_split,
                                    int* stream_blocks) {
   if (M < 0 || N <= 0 || K <= 0 || !cfg || !splits || !stream_blocks) return bad_arg("rows_gemm_plan: bad argument");
   if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0))
-    plan_rows3(M > 0 ? M : 1, N, K, may_split != 0, cfg, splits, stream_blocks);
+    plan_rows3(M > 0 ? M : 1, N, K, may_split, cfg, splits, stream_blocks);
   else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, may_split != 0, cfg, splits, stream_blocks);
   return PDAE_OK;
 }
@@ -822,7 +825,7 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   }
   if (cfg < 0 || splits < 0) {
     int c, s, b;
-    if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, false, &c, &s, &b);
+    if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, w_kn != 0)) plan_rows3(M > 0 ? M : 1, N, K, 0, &c, &s, &b);
     else plan_rows(M > 0 ? M : 1, N, K, w_kn != 0, false, &c, &s, &b);
     if (cfg < 0) cfg = c;
     if (splits < 0) splits = 1, stream_blocks = 0;

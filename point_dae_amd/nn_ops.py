@@ -498,6 +498,71 @@ class _Linear(torch.autograd.Function):
         return dx, dws[0], dbs[0], None
 
 
+def _rows_gemm_few_rows(x, w, w_kn, bias, epi, z=None):
+    """rows_gemm for a handful of rows against a long reduction: planned with up to 8 split-K slabs, which
+    pdae_slab_sum_epi adds with the bias and the epilogue (one GEMM launch when the plan keeps one slab)."""
+    M, K = x.shape
+    N = w.shape[1] if w_kn else w.shape[0]
+    cfg, splits, _ = _lib.rows_gemm_plan(M, N, K, w_kn, 8)
+    if splits == 1:
+        return rows_gemm(x, w, w_kn, bias, epi, z)
+    slabs = _empty((splits, M, N), x)
+    probed_family('rows_gemm', 2.0 * M * N * K,
+                  lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), None, 0, None,
+                                    _lib.ptr(slabs), cfg, splits, 0),
+                  nbytes=4.0 * (M * K + N * K + slabs.numel()))
+    y = _empty((M, N), x)
+    _lib.call('pdae_slab_sum_epi', x, splits, M, N, _lib.ptr(slabs), _lib.ptr(bias), epi, _lib.ptr(z), _lib.ptr(y))
+    return y
+
+
+class _MLPChain(torch.autograd.Function):
+    """Linear -> ReLU -> Linear -> ReLU -> ... -> Linear on rows as ONE node (the coarse heads: models/PointCAE_DGCNN.py
+    recfc, PointCAE_pointnetv2.py folding1, PointCAE_transformer.py coarse_pred): forward = the layers' row GEMMs with
+    bias (+ ReLU) in the epilogue; backward = each data gradient masked in ITS epilogue by the ReLU output it flows into
+    (rows_gemm epi 4: no compare / multiply passes), and the weight + bias gradients of ALL layers as one grouped launch
+    (they share their rows).  Inputs: x, then (w, b) per layer; every layer but the last is followed by a ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ws, bs = params[0::2], params[1::2]
+        acts = [x.contiguous()]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            acts.append(_rows_gemm_few_rows(acts[-1], w, False, b, 1 if i + 1 < len(ws) else 0))
+        ctx.save_for_backward(*acts[:-1], *ws)
+        ctx.n, ctx.has_bias = len(ws), [b is not None for b in bs]
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dys = [None] * n
+        dys[n - 1] = dy.contiguous()
+        for i in range(n - 1, 0, -1):                   # acts[i] = relu(layer i - 1): its sign masks the gradient
+            dys[i - 1] = _rows_gemm_few_rows(dys[i], ws[i], True, None, 4, acts[i])
+        dx = _rows_gemm_few_rows(dys[0], ws[0], True, None, 0) if ctx.needs_input_grad[0] else None
+        dws, dbs = rows_wgrad(dys, list(acts), ctx.has_bias)
+        out = [dx]
+        for dw, db in zip(dws, dbs):
+            out += [dw, db]
+        return tuple(out)
+
+
+def mlp_chain(x, layers):
+    """layers: the nn.Linear modules of a Linear / ReLU / ... / Linear head, in order -> the last layer's output."""
+    if not (x.dim() == 2 and x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError('mlp_chain: rows must be a 2-D fp32 tensor on the GPU (there is no CPU / library path)')
+    if any(l.weight.shape[0] % 4 or l.weight.shape[1] % 4 or l.bias is None for l in layers):
+        for i, l in enumerate(layers):              # ragged widths: layer by layer (linear_any pads them)
+            x = linear(x, l, 'relu' if i + 1 < len(layers) else None)
+        return x
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+    return _MLPChain.apply(x, *params)
+
+
 class _FoldMLP(torch.autograd.Function):
     """The FoldingNet stage of Point_CAE_PointNetv2 (models/PointCAE_pointnetv2.py:157-167: folding2 =
     Conv1d(1029,512) ReLU Conv1d(512,512) ReLU Conv1d(512,3)) on rows, given the first conv's three

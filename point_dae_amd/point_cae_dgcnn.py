@@ -241,7 +241,7 @@ class Point_CAE_DGCNN_FCOnly(nn.Module):
         corrupted_pts = corrupt_in_forward(corrupted_pts, self.corrupt_type)      # (:198-221: the CUDA-side dropouts)
         feature = self.dgcnn_encoder.forward_rows(corrupted_pts)
         r = self.recfc
-        coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(feature, r[0], 'relu'), r[2], 'relu'), r[4])
+        coarse = nn_ops.mlp_chain(feature, [r[0], r[2], r[4]])
         coarse = coarse.view(-1, self.num_coarse, 3)
         if capture is not None:
             capture.update(feature=feature, coarse=coarse)

@@ -200,7 +200,7 @@ class Point_CAE_PointNetv2(nn.Module):
         B = pts.shape[0]
         feature = self.pointnetv2_encoder(corrupted_pts)                       # (B, 1024)
         f1 = self.folding1
-        coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(feature, f1[0], 'relu'), f1[2], 'relu'), f1[4])
+        coarse = nn_ops.mlp_chain(feature, [f1[0], f1[2], f1[4]])
         coarse = coarse.view(B, self.num_coarse, 3)
         # folding2[0] on [grid(2) | coarse point(3) | global feature(1024)], split by column block
         w = self.folding2[0].weight.squeeze(-1)                                # (512, 1029)

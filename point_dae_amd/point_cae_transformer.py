@@ -406,8 +406,7 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
         if return_feat:
             return global_feature
         B, R, C = t['B'], t['R'], t['C']
-        coarse = nn_ops.linear(nn_ops.linear(nn_ops.linear(global_feature, self.coarse_pred[0], 'relu'),
-                                             self.coarse_pred[2], 'relu'), self.coarse_pred[4]).reshape(B, -1, 3)
+        coarse = nn_ops.mlp_chain(global_feature, [self.coarse_pred[0], self.coarse_pred[2], self.coarse_pred[4]]).reshape(B, -1, 3)
         tok = t['x_rec']                                                           # (B*R, C)
         f1 = self._fold(self.folding1, tok, 2, self.fold_grid).reshape(B * R, 36, 3)
         f2 = self._fold(self.folding2, tok, 3, f1).reshape(B * R, 36, 3)

@@ -359,3 +359,86 @@ def test_rows_wgrad_listed(M, N, K, la, lb, bn, bias):
     with pytest.raises(RuntimeError):                              # a list needs whole groups
         L.call('pdae_rows_wgrad_listed', dY, 40, N, K, L.ptr(dY), L.ptr(gb if gb is not None else torch.zeros(2, dtype=torch.int32, device='cuda')),
                L.ptr(X), None, None, None, L.ptr(dw), None, L.ptr(ws))
+
+
+@pytest.mark.parametrize('M,widths', [(32, (1024, 1024, 1024, 3072)), (128, (384, 1024, 1024, 192)), (5, (8, 12, 4)),
+                                      (7, (16, 10, 6))])
+def test_mlp_chain_equals_the_layers_one_by_one(M, widths):
+    """nn_ops.mlp_chain (Linear / ReLU / ... / Linear as one node: ReLU masks in the data gradients' epilogues, one grouped
+    weight-gradient launch, long reductions on a few rows in split-K slabs) against nn_ops.linear layer by layer and torch in fp64."""
+    from point_dae_amd import _lib, nn_ops
+    torch.manual_seed(M)
+    layers = [torch.nn.Linear(a, b).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    x = torch.randn(M, widths[0], device='cuda')
+    gy = torch.randn(M, widths[-1], device='cuda')
+
+    def run(fn):
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi)
+        y.backward(gy)
+        return [y, xi.grad] + [p.grad.clone() for l in layers for p in (l.weight, l.bias)]
+
+    def one_by_one(t):
+        for i, l in enumerate(layers):
+            t = nn_ops.linear(t, l, 'relu' if i + 1 < len(layers) else None)
+        return t
+
+    _lib.set_deterministic(True)
+    try:
+        a = run(lambda t: nn_ops.mlp_chain(t, layers))
+        b = run(one_by_one)
+    finally:
+        _lib.set_deterministic(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        # (the chain splits long reductions into slabs and groups the weight gradients: other summation orders)
+        assert (u.double() - v.double()).norm().item() <= 2e-6 * max(v.double().norm().item(), 1e-30), i
+    ref = [torch.nn.Linear(l.in_features, l.out_features).cuda().double() for l in layers]
+    for r, l in zip(ref, layers):
+        r.load_state_dict({k: v.double() for k, v in l.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    t = x64
+    for i, r in enumerate(ref):
+        t = r(t)
+        if i + 1 < len(ref):
+            t = torch.relu(t)
+    t.backward(gy.double())
+    want = [t, x64.grad] + [p.grad for r in ref for p in (r.weight, r.bias)]
+    for u, v in zip(a, want):
+        assert (u.double() - v).norm().item() <= 2e-6 * max(v.norm().item(), 1e-30)
+
+
+@pytest.mark.parametrize('S,M,N', [(8, 32, 1024), (3, 5, 12), (1, 7, 8)])
+def test_slab_sum_epi(S, M, N):
+    """pdae_slab_sum_epi: split-K slabs added in slab order, + bias, + ReLU or the ReLU-output mask."""
+    from point_dae_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(S * 100 + M)
+    slabs = torch.randn(S, M, N, device='cuda', generator=g)
+    bias = torch.randn(N, device='cuda', generator=g)
+    z = torch.randn(M, N, device='cuda', generator=g)
+    want = slabs[0].clone()
+    for q in range(1, S):
+        want = want + slabs[q]
+    for epi, b in ((0, None), (0, bias), (1, bias), (4, None)):
+        y = torch.full((M, N), float('nan'), device='cuda')
+        _lib.call('pdae_slab_sum_epi', slabs, S, M, N, slabs.data_ptr(), b.data_ptr() if b is not None else None, epi,
+                  z.data_ptr() if epi == 4 else None, y.data_ptr())
+        ref = want + b if b is not None else want
+        ref = torch.relu(ref) if epi == 1 else (torch.where(z > 0, ref, torch.zeros_like(ref)) if epi == 4 else ref)
+        assert torch.equal(y, ref)
+    with pytest.raises(RuntimeError, match='slab_sum_epi'):
+        _lib.call('pdae_slab_sum_epi', slabs, S, M, N, slabs.data_ptr(), None, 2, None, z.data_ptr())
+
+
+def test_few_rows_plan_splits_a_long_reduction():
+    """pdae_rows_gemm_plan(may_split = 8): 32 rows against K = 1024 / 3072 come back in more than 4 slabs (exact-split
+    arithmetic), every slab at least one 32-deep tile; may_split = 1 keeps the LayerNorm consumers' limit of 4."""
+    from point_dae_amd import _lib
+    if _lib.gemm_arith() != _lib.GEMM_BF16X3:
+        pytest.skip('exact-split arithmetic only')
+    for K in (1024, 3072):
+        cfg, splits, sb = _lib.rows_gemm_plan(32, 1024, K, False, 8)
+        assert 4 < splits <= 8 and sb == 0 and cfg >= 16
+        assert _lib.rows_gemm_plan(32, 1024, K, False, 1)[1] <= 4
+        assert _lib.rows_gemm_plan(32, 1024, K, False, 0)[1] == 1
