@@ -503,13 +503,13 @@ def _rows_gemm_few_rows(x, w, w_kn, bias, epi, z=None):
     pdae_slab_sum_epi adds with the bias and the epilogue (one GEMM launch when the plan keeps one slab)."""
     M, K = x.shape
     N = w.shape[1] if w_kn else w.shape[0]
-    cfg, splits, _ = _lib.rows_gemm_plan(M, N, K, w_kn, 8)
+    cfg, splits, sb = _lib.rows_gemm_plan(M, N, K, w_kn, 8)
     if splits == 1:
         return rows_gemm(x, w, w_kn, bias, epi, z)
     slabs = _empty((splits, M, N), x)
     probed_family('rows_gemm', 2.0 * M * N * K,
                   lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), None, 0, None,
-                                    _lib.ptr(slabs), cfg, splits, 0),
+                                    _lib.ptr(slabs), cfg, splits, sb),
                   nbytes=4.0 * (M * K + N * K + slabs.numel()))
     y = _empty((M, N), x)
     _lib.call('pdae_slab_sum_epi', x, splits, M, N, _lib.ptr(slabs), _lib.ptr(bias), epi, _lib.ptr(z), _lib.ptr(y))

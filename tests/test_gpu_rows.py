@@ -361,9 +361,10 @@ def test_rows_wgrad_listed(M, N, K, la, lb, bn, bias):
                L.ptr(X), None, None, None, L.ptr(dw), None, L.ptr(ws))
 
 
+@pytest.mark.parametrize('arith', [1, 0], ids=['bf16x3', 'f32mfma'])
 @pytest.mark.parametrize('M,widths', [(32, (1024, 1024, 1024, 3072)), (128, (384, 1024, 1024, 192)), (5, (8, 12, 4)),
                                       (7, (16, 10, 6))])
-def test_mlp_chain_equals_the_layers_one_by_one(M, widths):
+def test_mlp_chain_equals_the_layers_one_by_one(M, widths, arith):
     """nn_ops.mlp_chain (Linear / ReLU / ... / Linear as one node: ReLU masks in the data gradients' epilogues, one grouped
     weight-gradient launch, long reductions on a few rows in split-K slabs) against nn_ops.linear layer by layer and torch in fp64."""
     from point_dae_amd import _lib, nn_ops
@@ -385,12 +386,15 @@ def test_mlp_chain_equals_the_layers_one_by_one(M, widths):
             t = nn_ops.linear(t, l, 'relu' if i + 1 < len(layers) else None)
         return t
 
+    before = _lib.gemm_arith()
+    _lib.set_gemm_arith(arith)
     _lib.set_deterministic(True)
     try:
         a = run(lambda t: nn_ops.mlp_chain(t, layers))
         b = run(one_by_one)
     finally:
         _lib.set_deterministic(False)
+        _lib.set_gemm_arith(before)
     for i, (u, v) in enumerate(zip(a, b)):
         # (the chain splits long reductions into slabs and groups the weight gradients: other summation orders)
         assert (u.double() - v.double()).norm().item() <= 2e-6 * max(v.double().norm().item(), 1e-30), i
