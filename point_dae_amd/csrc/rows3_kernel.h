@@ -33,6 +33,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK3 = 32;          // reduction depth of one staged tile (two 16-deep MFMA steps)
+// (lab, tools/lab/gemm3_anatomy.py) -DR3_STAMP: wave 0 of every block writes s_memrealtime (100 MHz) at kernel entry, before
+// the first k-tile, behind the last one and behind the epilogue to Args::Z (4 x u64 per block, + s_memtime, the core clock, in 4 more); never
+// defined in the library
+#ifdef R3_STAMP
+#define R3_STAMP_AT(i)                                                                                              \
+  if (threadIdx.x == 0) {                                                                                           \
+    unsigned long long* st_ = reinterpret_cast<unsigned long long*>(p.Z) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; \
+    st_[i] = __builtin_amdgcn_s_memrealtime(), st_[4 + (i)] = __builtin_amdgcn_s_memtime();                         \
+  }
+#else
+#define R3_STAMP_AT(i)
+#endif
 #ifndef R3_FPS
 #define R3_FPS 3                 // fragment reads per slot behind a tile's barrier (lab: tools/lab/fps_sweep.sh)
 #endif
@@ -111,6 +123,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
+  R3_STAMP_AT(0);
   // Persistent blocks: block (xcd, slot) walks tiles slot, slot + nslots, ... of its XCD's chunk (n fastest inside a chunk:
   // the re-reads of an A row band hit that XCD's L2) and the LDS tiles of consecutive output tiles form ONE stream
   // through the pipeline -- loads run three positions ahead across the tile boundary, so a boundary costs the epilogue
@@ -327,10 +340,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+    R3_STAMP_AT(1);
     for (int kt = 0; kt < KT; kt += 2) {
       ktile(C0{}, kt);
       if (kt + 1 < KT) ktile(C1{}, kt + 1);
     }
+    R3_STAMP_AT(2);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     float* Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)piece * p.slab;
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     const bool full = m0 + BM <= M && n0 + BN <= N;
     if (full) epilogue(std::true_type{}, std::false_type{});
     else epilogue(std::false_type{}, std::false_type{});
+    R3_STAMP_AT(3);
     if (!PERS || next < 0) break;
     slot += nslots;
     tile = next;

@@ -23,6 +23,19 @@ static int launch(rows::Args a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// (built -DR3_STAMP: tools/lab/gemm3_anatomy.py) the same launch with the stamp buffer in Args::Z: 4 x u64 per block
+extern "C" int lab_gemm3_stamped(int variant, int M, int N, int K, const float* A, const float* B, int bkn, float* C,
+                                 unsigned long long* stamps, void* stream) {
+  rows::Args a = {};
+  a.M = M, a.N = N, a.K = K, a.A = A, a.lda = K, a.B = B, a.ldb = bkn ? N : K, a.C = C, a.ldc = N, a.slab = (long long)M * N;
+  a.Z = reinterpret_cast<float*>(stamps);
+  hipStream_t s = (hipStream_t)stream;
+  if (variant == 0) return bkn ? launch<1, 2, 4, 2, 2, true, true>(a, s) : launch<1, 2, 4, 2, 2, false, true>(a, s);
+  if (variant == 2) return bkn ? launch<1, 3, 4, 2, 2, true, true>(a, s) : launch<1, 3, 4, 2, 2, false, true>(a, s);
+  if (variant == 3) return bkn ? launch<1, 1, 4, 2, 2, true, true>(a, s) : launch<1, 1, 4, 2, 2, false, true>(a, s);
+  return -1;
+}
+
 extern "C" int lab_gemm3(int variant, int M, int N, int K, const float* A, const float* B, int bkn, float* C, void* stream) {
   rows::Args a = {};
   a.M = M, a.N = N, a.K = K, a.A = A, a.lda = K, a.B = B, a.ldb = bkn ? N : K, a.C = C, a.ldc = N, a.slab = (long long)M * N;
