@@ -48,6 +48,12 @@ def test_no_cpu_fallback():
         chamfer_dist.ChamferDistanceL2()(x, x)
     with pytest.raises(RuntimeError, match="GPU"):
         KNN(4, transpose_mode=True)(x, x[:, :3])
+    from point_dae_amd import nn_ops
+    lin = torch.nn.Linear(8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        nn_ops.mlp_chain(torch.rand(4, 8), [lin, lin])          # the coarse heads: no CPU / framework path either
+    with pytest.raises(RuntimeError, match="GPU"):
+        nn_ops.linear_any(torch.rand(4, 8), lin.weight, lin.bias)
 
 
 def test_product_does_not_import_oracle():
