@@ -330,6 +330,9 @@ int pdae_emd_matchcost_grad(int b, int n, int m, const float* grad_cost,
  *                 (dgcnn_util.knn's expression -- xx (B, 1, N) broadcasts over the columns first -- each operation
  *                 rounded), best first, the lower id on equal values;
  *                 gram (b, n, n) = X_b X_b^T from pdae_rows_gemm_batched.  k <= 64.
+ *   xyz_topk:     the same idx for the FIRST EdgeConv, whose features are the points themselves: x4 (b n, 4) = xyz rows
+ *                 zero-padded to 4 columns (rows_pad), g_ij = fma(z z', fma(y y', x x')) computed in the kernel -- no
+ *                 (b, n, n) Gram matrix; n <= 6144 (a block keeps its cloud in LDS).  pd_out (nullable, b n n): the -pd values the selection saw (tests).
  *   knn_reverse:  the reverse graph: rev_start (b, n+1), rev_src (b, n k): the points that list point s as a
  *                 neighbour are rev_src[b][rev_start[b][s] .. rev_start[b][s+1]), ascending.  n <= 4096.
  *   edge_gather_stats: pq (R, 2 co) = [p | q], p = W1 x, q = (W2 - W1) x, so that the conv output of edge (r, j) is
@@ -361,6 +364,8 @@ int pdae_rows_pad(long long R, int c, int cp, const float* x, float* out, pdae_s
 int pdae_edge_weight_stack(int co, int cin, int kp, const float* w, float* ws, pdae_stream_t stream);
 int pdae_edge_weight_unstack(int co, int cin, int kp, const float* dws, float* dw, pdae_stream_t stream);
 int pdae_gram_topk(int b, int n, int k, const float* gram, const float* xx, int32_t* idx, pdae_stream_t stream);
+int pdae_xyz_topk(int b, int n, int k, const float* x4, const float* xx, int32_t* idx, float* pd_out /*nullable*/,
+                  pdae_stream_t stream);
 int pdae_knn_reverse(int b, int n, int k, const int32_t* idx, int32_t* rev_start, int32_t* rev_src,
                      pdae_stream_t stream);
 int pdae_edge_parts(void);

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "pdae_emd_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_sqnorm": [_i, _i, _vp, _vp, _vp],
     "pdae_gram_topk": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_xyz_topk": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_knn_reverse": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_edge_gather_stats": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bn_lrelu_rows": [ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -56,32 +56,61 @@ __device__ __forceinline__ float neg_pd(float g, float xi, float xj) { return xi
 // One wave per row: two passes over the (L2-resident) row.  Measured alternatives, both slower (76-81 against 66-69 us
 // at 32 x 1024^2): the row held in registers (one read, 16 more live registers), and four rows per wave (the
 // selection is a dependent chain per row; more resident waves hide it better).
-__global__ __launch_bounds__(256) void gram_topk_kernel(int n, int k, const float* __restrict__ gram_all,
-                                                        const float* __restrict__ xx_all, int* __restrict__ idx_all) {
+// XYZ: the first EdgeConv's graph is built on the points themselves (C = 3, stored as 4 columns): its Gram entries are
+// three products each, computed here (g = fma(z z', fma(y y', x x'))) from the cloud's rows -- staged ONCE per block into
+// LDS (16 B per point; a block then serves 16 rows, four per wave: read per candidate from global the 16-byte rows cost
+// 1 KB of L1 traffic per wave load, 103 us per launch) -- instead of being written as a (b, n, n) matrix by a K = 4 GEMM
+// and read back (42 us + 134 MB each way per step).
+template <bool XYZ>
+__global__ __launch_bounds__(256) void gram_topk_kernel(int n, int k, const float* __restrict__ src_all,
+                                                        const float* __restrict__ xx_all, int* __restrict__ idx_all,
+                                                        float* __restrict__ pd_out) {
   __shared__ unsigned long long stage_all[4][128];
+  extern __shared__ __attribute__((aligned(16))) char lds_xyz[];      // XYZ: the cloud's n rows | their n squared norms
+  constexpr int RPW = XYZ ? 4 : 1;                                     // rows per wave
   const int lane = lane_id(), wave = threadIdx.x / kWave;
   unsigned long long* stage = stage_all[wave];
-  const int bi = blockIdx.y, i = blockIdx.x * 4 + wave;
-  if (i >= n) return;
-  const float* g = gram_all + ((size_t)bi * n + i) * n;
+  const int bi = blockIdx.y;
   const float* xx = xx_all + (size_t)bi * n;
-  const float xi = xx[i];
-  float lane_min = __builtin_huge_valf();
-  for (int p = lane; p < n; p += kWave) lane_min = fminf(lane_min, neg_pd(g[p], xi, xx[p]));
-  const float t = wave_kth_smallest(lane_min, k);
-  KnnSelect st;
-  st.best = kKeyMax;
-  st.bound = ((unsigned long long)ordered_bits(t) << 32) | 0xffffffffull;
-  st.staged = 0;
-  st.have_best = false;
-  for (int p0 = 0; p0 < n; p0 += kWave) {
-    const int p = p0 + lane;
-    const bool in = p < n;
-    const float d = in ? neg_pd(g[p], xi, xx[p]) : 0.f;
-    knn_offer(st, stage, ((unsigned long long)ordered_bits(d) << 32) | (unsigned)p, in, k);
+  const float4* pts = reinterpret_cast<const float4*>(lds_xyz);
+  if (XYZ) {
+    float4* pw = reinterpret_cast<float4*>(lds_xyz);
+    float* xw = reinterpret_cast<float*>(lds_xyz + (size_t)n * 16);
+    const float4* gsrc = reinterpret_cast<const float4*>(src_all) + (size_t)bi * n;
+    for (int p = threadIdx.x; p < n; p += 256) pw[p] = gsrc[p], xw[p] = xx[p];
+    __syncthreads();
+    xx = xw;
   }
-  if (st.staged > 0 || !st.have_best) knn_flush(st, stage, st.staged, k);
-  if (lane < k) idx_all[((size_t)bi * n + i) * k + lane] = (int)(st.best & 0xffffffffull);
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int i = (blockIdx.x * RPW + rr) * 4 + wave;
+    if (i >= n) return;
+    const float* g = XYZ ? nullptr : src_all + ((size_t)bi * n + i) * n;
+    const float xi = xx[i];
+    float4 pi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (XYZ) pi = pts[i];
+    auto dist = [&](int p) {
+      if (!XYZ) return neg_pd(g[p], xi, xx[p]);
+      const float4 q = pts[p];
+      return neg_pd(fmaf(pi.z, q.z, fmaf(pi.y, q.y, pi.x * q.x)), xi, xx[p]);
+    };
+    float lane_min = __builtin_huge_valf();
+    for (int p = lane; p < n; p += kWave) lane_min = fminf(lane_min, dist(p));
+    const float t = wave_kth_smallest(lane_min, k);
+    KnnSelect st;
+    st.best = kKeyMax;
+    st.bound = ((unsigned long long)ordered_bits(t) << 32) | 0xffffffffull;
+    st.staged = 0;
+    st.have_best = false;
+    for (int p0 = 0; p0 < n; p0 += kWave) {
+      const int p = p0 + lane;
+      const bool in = p < n;
+      const float d = in ? dist(p) : 0.f;
+      if (XYZ && pd_out && in) pd_out[((size_t)bi * n + i) * n + p] = d;     // (tests: the values the selection saw)
+      knn_offer(st, stage, ((unsigned long long)ordered_bits(d) << 32) | (unsigned)p, in, k);
+    }
+    if (st.staged > 0 || !st.have_best) knn_flush(st, stage, st.staged, k);
+    if (lane < k) idx_all[((size_t)bi * n + i) * k + lane] = (int)(st.best & 0xffffffffull);
+  }
 }
 
 // ---- reverse graph: for every point the points that list it as a neighbour, ascending ----------------------------
@@ -567,8 +596,30 @@ extern "C" int pdae_gram_topk(int b, int n, int k, const float* gram, const floa
   if (b > 65535) return unsupported("gram_topk: b > 65535");
   if (b == 0) return PDAE_OK;
   if (!gram || !xx || !idx) return bad_arg("gram_topk: null pointer");
-  hipLaunchKernelGGL(gram_topk_kernel, dim3((n + 3) / 4, b), dim3(256), 0, as_stream(stream), n, k, gram, xx, idx);
+  hipLaunchKernelGGL(gram_topk_kernel<false>, dim3((n + 3) / 4, b), dim3(256), 0, as_stream(stream), n, k, gram, xx, idx,
+                     static_cast<float*>(nullptr));
   return check_launch("gram_topk");
+}
+
+extern "C" int pdae_xyz_topk(int b, int n, int k, const float* x4, const float* xx, int* idx, float* pd_out,
+                             pdae_stream_t stream) {
+  if (b < 0 || n <= 0 || k <= 0) return bad_arg("xyz_topk: b>=0, n>0, k>0 required");
+  if (k > n) return bad_arg("xyz_topk: k > n");
+  if (k > 64) return unsupported("xyz_topk: k > 64 not implemented");
+  if (b > 65535) return unsupported("xyz_topk: b > 65535");
+  if (b == 0) return PDAE_OK;
+  if (!x4 || !xx || !idx) return bad_arg("xyz_topk: null pointer");
+  if (n > 6144) return unsupported("xyz_topk: clouds of more than 6144 points (the cloud is staged in LDS)");
+  const size_t lds = (size_t)n * 20;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gram_topk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            6144 * 20) != hipSuccess)
+      return unsupported("xyz_topk: dynamic LDS limit");
+    attr = true;
+  }
+  hipLaunchKernelGGL(gram_topk_kernel<true>, dim3((n + 15) / 16, b), dim3(256), lds, as_stream(stream), n, k, x4, xx, idx, pd_out);
+  return check_launch("xyz_topk");
 }
 
 extern "C" int pdae_knn_reverse(int b, int n, int k, const int* idx, int* rev_start, int* rev_src, pdae_stream_t stream) {

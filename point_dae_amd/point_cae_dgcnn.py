@@ -38,17 +38,25 @@ def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
-def feature_knn(x_rows, B, N, k=K_GRAPH, out=None):
+def feature_knn(x_rows, B, N, k=K_GRAPH, out=None, xyz=False, pd_out=None):
     """x_rows (B*N, C), C % 4 == 0 -> (B, N, k) int32 neighbour ids within the cloud (dgcnn_util.knn :7-12):
     Gram matrices on the batched row GEMM, the reference's distance expression and its top-k on one wave per row.
-    out: a (B, N, k) int32 tensor to fill (the encoder keeps its four graphs in one allocation)."""
+    out: a (B, N, k) int32 tensor to fill (the encoder keeps its four graphs in one allocation).  xyz: x_rows are the
+    points themselves (3 coordinates, a zero 4th column): no Gram matrix (pdae_xyz_topk); pd_out (tests): (B, N, N) that
+    receives the -pd values that kernel selected from."""
     x = x_rows.detach()
     C = x.shape[1]
-    gram = _empty((B, N, N), x)
-    _lib.call('pdae_rows_gemm_batched', x, B, N, N, C, _lib.ptr(x), N * C, _lib.ptr(x), N * C, _lib.ptr(gram), N * N)
     xx = _empty((B * N,), x)
     _lib.call('pdae_rows_sqnorm', x, B * N, C, _lib.ptr(x), _lib.ptr(xx))
     idx = _empty((B, N, k), x, torch.int32) if out is None else out
+    if xyz:
+        # the first layer's features are the points (3 coordinates + a zero column): distances straight from the rows
+        if C != 4:
+            raise RuntimeError('feature_knn(xyz=True): rows of 3 coordinates padded to 4 columns')
+        _lib.call('pdae_xyz_topk', x, B, N, k, _lib.ptr(x), _lib.ptr(xx), _lib.ptr(idx), _lib.ptr(pd_out))
+        return idx
+    gram = _empty((B, N, N), x)
+    _lib.call('pdae_rows_gemm_batched', x, B, N, N, C, _lib.ptr(x), N * C, _lib.ptr(x), N * C, _lib.ptr(gram), N * N)
     _lib.call('pdae_gram_topk', x, B, N, k, _lib.ptr(gram), _lib.ptr(xx), _lib.ptr(idx))
     return idx
 
@@ -85,7 +93,7 @@ class _Encoder(torch.autograd.Function):
             co, kp = convs[li].shape[0], x.shape[1]
             w = _empty((2 * co, kp), x)                             # [W1; W2 - W1], K padded like x
             _lib.call('pdae_edge_weight_stack', x, co, cin, kp, _lib.ptr(convs[li].contiguous()), _lib.ptr(w))
-            idx = feature_knn(x, B, N, k, out=graphs[li])
+            idx = feature_knn(x, B, N, k, out=graphs[li], xyz=(li == 0 and cin == 3 and N <= 6144))
             pq = nn_ops.rows_gemm(x, w)
             esel, psum = _empty((R, co), x), _empty((R, co), x)
             sel = _empty((R, co), x, torch.int16)

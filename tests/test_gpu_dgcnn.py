@@ -22,6 +22,33 @@ def _rel(a, b):
     return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
 
 
+@pytest.mark.parametrize('B,N,k', [(32, 1024, 20), (2, 300, 20), (3, 2500, 7), (5, 21, 20), (2, 40, 40)])
+def test_xyz_topk_selects_the_reference_s_neighbours(B, N, k):
+    """pdae_xyz_topk (the first EdgeConv's graph, distances straight from the point rows: no Gram matrix): the values it
+    selected from (pd_out) are dgcnn_util.knn's expression of the fp64 Gram matrix to fp32 rounding, idx is torch.topk's
+    of those values -- the SET per row equal, best first (ids differ only inside ties) -- and agrees with the two-kernel
+    form up to near-ties of the two Gram roundings."""
+    _lib()
+    from point_dae_amd.point_cae_dgcnn import feature_knn
+    g = torch.Generator(device='cuda').manual_seed(N + k)
+    x = torch.randn(B * N, 4, device='cuda', generator=g)
+    x[:, 3] = 0
+    pd = torch.full((B, N, N), float('nan'), device='cuda')
+    idx = feature_knn(x, B, N, k, xyz=True, pd_out=pd).long()
+    assert torch.isfinite(pd).all()
+    xb = x.view(B, N, 4).double()
+    xx64 = xb.square().sum(-1)
+    ref = xx64.unsqueeze(2) - 2 * xb @ xb.transpose(1, 2) + xx64.unsqueeze(1)      # = -pd of dgcnn_util.knn (:8-10)
+    assert (pd.double() - ref).abs().max().item() <= 4e-7 * (xx64.max() * 4).item()
+    want_v, want_i = (-pd).topk(k=k, dim=-1)
+    assert torch.equal(-pd.gather(-1, idx), want_v)
+    assert (idx.sort(-1)[0] == want_i.sort(-1)[0]).float().mean().item() > 0.999
+    assert idx.min().item() >= 0 and idx.max().item() < N
+    assert (idx.sort(-1)[0].diff(dim=-1) > 0).all()
+    idx2 = feature_knn(x, B, N, k).long()                                          # batched Gram GEMM + gram_topk
+    assert (idx.sort(-1)[0] == idx2.sort(-1)[0]).float().mean().item() > 0.995
+
+
 @pytest.mark.parametrize('B,N,C,k', [(3, 1024, 64, 20), (2, 300, 4, 20), (1, 64, 128, 20), (2, 2500, 8, 7), (5, 21, 4, 20)])
 def test_gram_topk_selects_the_reference_s_neighbours(B, N, C, k):
     """idx of dgcnn_util.knn given the same Gram matrix and norms: the SET per row equals torch.topk's and the order is
