@@ -363,6 +363,12 @@ int pdae_rows_sqnorm(int R, int C, const float* x, float* xx, pdae_stream_t stre
 int pdae_rows_pad(long long R, int c, int cp, const float* x, float* out, pdae_stream_t stream);
 int pdae_edge_weight_stack(int co, int cin, int kp, const float* w, float* ws, pdae_stream_t stream);
 int pdae_edge_weight_unstack(int co, int cin, int kp, const float* dws, float* dw, pdae_stream_t stream);
+/* ..._multi: the same for n <= 8 layers in ONE launch (HOST arrays of sizes and device pointers): the encoder stacks its
+ * four EdgeConv weights before the first layer and unstacks their gradients after the last one. */
+int pdae_edge_weight_stack_multi(int n, const int* co, const int* cin, const int* kp, const float* const* w,
+                                 float* const* ws, pdae_stream_t stream);
+int pdae_edge_weight_unstack_multi(int n, const int* co, const int* cin, const int* kp, const float* const* dws,
+                                   float* const* dw, pdae_stream_t stream);
 int pdae_gram_topk(int b, int n, int k, const float* gram, const float* xx, int32_t* idx, pdae_stream_t stream);
 int pdae_xyz_topk(int b, int n, int k, const float* x4, const float* xx, int32_t* idx, float* pd_out /*nullable*/,
                   pdae_stream_t stream);

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "pdae_cloud_pool_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_rows_pad": [ctypes.c_longlong, _i, _i, _vp, _vp, _vp],
     "pdae_edge_weight_stack": [_i, _i, _i, _vp, _vp, _vp],
+    "pdae_edge_weight_stack_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_edge_weight_unstack_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_edge_weight_unstack": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_cloud_pool_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
@@ -365,6 +367,13 @@ def rows_wgrad(on, M, dYs, Xs, dWs, dbs, workspace):
     call('pdae_rows_wgrad', on, M, n, parr(*[ptr(t) for t in dYs]), parr(*[ptr(t) for t in Xs]),
          parr(*[ptr(t) for t in dWs]), parr(*[ptr(t) for t in dbs]),
          iarr(*[t.shape[1] for t in dYs]), iarr(*[t.shape[1] for t in Xs]), ptr(workspace))
+
+
+def edge_weights_multi(name, on, cos, cins, kps, srcs, dsts):
+    """pdae_edge_weight_stack_multi / _unstack_multi over lists (HOST arrays of sizes and device pointers)."""
+    n = len(cos)
+    parr, iarr = ctypes.c_void_p * n, ctypes.c_int * n
+    call(name, on, n, iarr(*cos), iarr(*cins), iarr(*kps), parr(*[ptr(t) for t in srcs]), parr(*[ptr(t) for t in dsts]))
 
 
 WGRAD_MULTI_MAX = 48

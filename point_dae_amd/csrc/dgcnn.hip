@@ -560,6 +560,33 @@ __global__ void edge_weight_unstack_kernel(int co, int cin, int kp, const float*
   const int o = t / (2 * cin), c = t - o * 2 * cin;
   dw[t] = c < cin ? dws[o * kp + c] - dws[(co + o) * kp + c] : dws[(co + o) * kp + c - cin];
 }
+// the same for up to 8 layers in one launch (blockIdx.y = layer): the encoder's four EdgeConv weights per step
+struct EdgeWeightJobs {
+  int n;
+  int co[8], cin[8], kp[8];
+  const float* src[8];
+  float* dst[8];
+};
+__global__ void edge_weight_stack_multi_kernel(const EdgeWeightJobs j) {
+  const int q = blockIdx.y, co = j.co[q], cin = j.cin[q], kp = j.kp[q];
+  const float* w = j.src[q];
+  float* ws = j.dst[q];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * co * kp) return;
+  const int o = t / kp, c = t - o * kp;
+  float v = 0.f;
+  if (c < cin) v = o < co ? w[o * 2 * cin + c] : w[(o - co) * 2 * cin + cin + c] - w[(o - co) * 2 * cin + c];
+  ws[t] = v;
+}
+__global__ void edge_weight_unstack_multi_kernel(const EdgeWeightJobs j) {
+  const int q = blockIdx.y, co = j.co[q], cin = j.cin[q], kp = j.kp[q];
+  const float* dws = j.src[q];
+  float* dw = j.dst[q];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= co * 2 * cin) return;
+  const int o = t / (2 * cin), c = t - o * 2 * cin;
+  dw[t] = c < cin ? dws[o * kp + c] - dws[(co + o) * kp + c] : dws[(co + o) * kp + c - cin];
+}
 // out [R][cp] = x [R][c] with zero columns appended
 __global__ void rows_pad_kernel(long long total, int c, int cp, const float* __restrict__ x, float* __restrict__ out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -761,6 +788,32 @@ extern "C" int pdae_edge_weight_unstack(int co, int cin, int kp, const float* dw
   if (!dws || !dw) return bad_arg("edge_weight_unstack: null pointer");
   hipLaunchKernelGGL(edge_weight_unstack_kernel, dim3((2 * co * cin + 255) / 256), dim3(256), 0, as_stream(stream), co, cin, kp, dws, dw);
   return check_launch("edge_weight_unstack");
+}
+
+static int edge_weight_multi(const char* what, bool unstack, int n, const int* co, const int* cin, const int* kp,
+                             const float* const* src, float* const* dst, pdae_stream_t stream) {
+  if (n < 0 || n > 8 || (n > 0 && (!co || !cin || !kp || !src || !dst))) return bad_arg(what);
+  if (n == 0) return PDAE_OK;
+  EdgeWeightJobs j = {};
+  j.n = n;
+  int most = 0;
+  for (int q = 0; q < n; ++q) {
+    if (co[q] <= 0 || cin[q] <= 0 || kp[q] < cin[q] || !src[q] || !dst[q]) return bad_arg(what);
+    j.co[q] = co[q], j.cin[q] = cin[q], j.kp[q] = kp[q], j.src[q] = src[q], j.dst[q] = dst[q];
+    const int e = unstack ? 2 * co[q] * cin[q] : 2 * co[q] * kp[q];
+    most = e > most ? e : most;
+  }
+  if (unstack) hipLaunchKernelGGL(edge_weight_unstack_multi_kernel, dim3((most + 255) / 256, n), dim3(256), 0, as_stream(stream), j);
+  else hipLaunchKernelGGL(edge_weight_stack_multi_kernel, dim3((most + 255) / 256, n), dim3(256), 0, as_stream(stream), j);
+  return check_launch(what);
+}
+extern "C" int pdae_edge_weight_stack_multi(int n, const int* co, const int* cin, const int* kp, const float* const* w,
+                                            float* const* ws, pdae_stream_t stream) {
+  return edge_weight_multi("edge_weight_stack_multi: 0..8 layers, co, cin > 0, kp >= cin, no null pointer", false, n, co, cin, kp, w, ws, stream);
+}
+extern "C" int pdae_edge_weight_unstack_multi(int n, const int* co, const int* cin, const int* kp, const float* const* dws,
+                                              float* const* dw, pdae_stream_t stream) {
+  return edge_weight_multi("edge_weight_unstack_multi: 0..8 layers, co, cin > 0, kp >= cin, no null pointer", true, n, co, cin, kp, dws, dw, stream);
 }
 
 extern "C" int pdae_rows_pad(long long R, int c, int cp, const float* x, float* out, pdae_stream_t stream) {

@@ -1041,6 +1041,20 @@ extern "C" int pdae_rows_wgrad_multi(int nprob, const int* Ms, const float* cons
     for (int q = 0; q < nprob; ++q)
       a.p[q].dY = dY[perm[q]], a.p[q].X = X[perm[q]], a.p[q].dW = dW[perm[q]], a.p[q].db = db ? db[perm[q]] : nullptr;
   };
+  bool one_chunk = arith_of(true) == PDAE_GEMM_BF16X3 && head == 0;
+  for (int q = 0; q < nprob; ++q) one_chunk = one_chunk && Ms[q] <= WCH;
+  if (one_chunk) {
+    // every layer on at most 32 rows (the coarse heads' Linear layers on a batch of 32 clouds): a tile IS one unit, so a
+    // block per tile stores it itself -- no partials, no reduction launch
+    WgradArgs a = {};
+    int rc = wgrad_layout(nprob, Ms, Ns, Ks, &a, tn, 0, -1, true);
+    if (rc) return rc;
+    if (a.tiles == 0) return check_launch("rows_wgrad_multi");
+    bind(a);
+    a.partials = workspace, a.direct = 1;
+    rows3::launch_wgrad3(a, tn, 1, s);
+    return check_launch("rows_wgrad_multi");
+  }
   if (head > 0) {                          // whole rounds of one tile per block first (wgrad_head_tiles)
     WgradArgs a = {};
     int rc = wgrad_layout(nprob, Ms, Ns, Ks, &a, tn, 0, head, true);

@@ -88,11 +88,17 @@ class _Encoder(torch.autograd.Function):
         cat = _empty((R, sum(w.shape[0] for w in convs[:4])), pts)
         saved, off = [], 0
         graphs = _empty((4, B, N, k), pts, torch.int32)            # the four layers' graphs: ONE reverse-graph launch backward
+        # the stacked weights [W1; W2 - W1] of the four layers (K padded like the layer's input rows) in one launch
+        cos = [convs[li].shape[0] for li in range(4)]
+        cins = [cin] + cos[:3]
+        kps = [x.shape[1]] + cos[:3]
+        stacked = [_empty((2 * co, kp), x) for co, kp in zip(cos, kps)]
+        _lib.edge_weights_multi('pdae_edge_weight_stack_multi', x, cos, cins, kps, [c.contiguous() for c in convs[:4]], stacked)
         for li in range(4):
             gamma, bn = gammas[li], bns[li]
             co, kp = convs[li].shape[0], x.shape[1]
-            w = _empty((2 * co, kp), x)                             # [W1; W2 - W1], K padded like x
-            _lib.call('pdae_edge_weight_stack', x, co, cin, kp, _lib.ptr(convs[li].contiguous()), _lib.ptr(w))
+            assert kp == kps[li]
+            w = stacked[li]
             idx = feature_knn(x, B, N, k, out=graphs[li], xyz=(li == 0 and cin == 3 and N <= 6144))
             pq = nn_ops.rows_gemm(x, w)
             esel, psum = _empty((R, co), x), _empty((R, co), x)
@@ -181,10 +187,11 @@ class _Encoder(torch.autograd.Function):
         # the four stacked-weight gradients [dW1; d(W2 - W1)] = dpq^T x share their rows: ONE grouped launch (+ one ordered
         # reduction) instead of four of each
         dws = nn_ops.rows_wgrad([q[1] for q in queue], [q[2] for q in queue], [False] * len(queue))[0]
-        for (li, _, x, co, cin), dw in zip(queue, dws):
-            dconv = _empty(ctx.shapes[li], dfeat)
-            _lib.call('pdae_edge_weight_unstack', dfeat, co, cin, x.shape[1], _lib.ptr(dw), _lib.ptr(dconv))
-            grads[3 * li] = dconv
+        dconvs = [_empty(ctx.shapes[q[0]], dfeat) for q in queue]
+        _lib.edge_weights_multi('pdae_edge_weight_unstack_multi', dfeat, [q[3] for q in queue], [q[4] for q in queue],
+                                [q[2].shape[1] for q in queue], dws, dconvs)
+        for q, dconv in zip(queue, dconvs):
+            grads[3 * q[0]] = dconv
         return (None, None, None, None, None) + tuple(grads)
 
 
