@@ -29,6 +29,8 @@ struct Args {
   int stream_blocks;  // > 0: stream-K over (tile, k-tile) units on this many blocks, `slabs` C slabs
   int slabs;
   long long strideA, strideB, strideC;   // batched launch: element strides between the problems of blockIdx.z
+  int symmetric;      // fp32-input kernel, square tiles, A == B (Gram matrices): `tiles` counts the tiles on and above the
+                      // diagonal; a block also stores its tile transposed below it
 };
 
 constexpr int WG_MAX = 48;               // layers per launch: 12 Transformer blocks x 4 (the by-value struct is 3.1 KB)

@@ -104,7 +104,14 @@ void rows_gemm_kernel(const Args p) {
     kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
     piece = blockIdx.y;
   }
-  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  int ti_ = tile / p.tiles_n, tj_ = tile % p.tiles_n;
+  if (p.symmetric) {                                          // the tile-th tile on or above the diagonal, row by row
+    int left = tile;
+    ti_ = 0;
+    while (left >= p.tiles_n - ti_) left -= p.tiles_n - ti_, ++ti_;
+    tj_ = ti_ + left;
+  }
+  const int m0 = ti_ * BM, n0 = tj_ * BN;
   // 32-bit BYTE offsets from the (uniform) operand bases: one VGPR per staged row and the
   // scalar-base + vector-offset form of global_load (the launcher checks the operands are < 4 GB);
   // rows past the matrix edge are clamped (their products are never stored)
@@ -362,6 +369,32 @@ void rows_gemm_kernel(const Args p) {
   const bool full = m0 + BM <= M && n0 + BN <= N;
   if (full) epilogue(std::true_type{}, std::false_type{});
   else epilogue(std::false_type{}, std::false_type{});
+  if (p.symmetric && n0 > m0) {
+    // the mirror image below the diagonal: C[col][row] = C[row][col] (the same products in the same order as a block
+    // of its own would sum).  A lane's registers 4 g .. 4 g + 3 are four consecutive rows of its column: one 16-byte
+    // store per group into row `col` of the transpose
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = n0 + (wn * TJ + j) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int rbase = m0 + (wm * TI + i) * 32 + 4 * h;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int row = rbase + 8 * g4;
+          float* dst = Cs + (size_t)col * p.ldc + row;
+          if (col >= N) continue;
+          if (row + 3 < M) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (row + q < M) dst[q] = acc[i][j][4 * g4 + q];
+          }
+        }
+      }
+    }
+  }
   if (!p.stream_blocks) break;
   if (tile_ends)
     for (int q = piece + 1; q < p.slabs; ++q) {
@@ -689,6 +722,7 @@ static void launch_cfg(Args& a, int splits, int stream_blocks, hipStream_t s, in
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+  if (a.symmetric) a.tiles = a.tiles_n * (a.tiles_n + 1) / 2;   // (square tiles, M == N: the caller checked)
   a.kchunk = ((a.K + splits - 1) / splits + BK - 1) / BK * BK;
   const Cfg c = {TI, TJ, WM, WN};
   const size_t lds = lds_bytes(c, BKN);
@@ -1152,6 +1186,15 @@ extern "C" int pdae_rows_gemm_batched(int batch, int M, int N, int K, const floa
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
   a.slab = (long long)M * N, a.strideA = strideX, a.strideB = strideW, a.strideC = strideY;
   hipStream_t s = as_stream(stream);
+  static const bool sym_off = getenv("PDAE_GRAM_SYMMETRIC") && atoi(getenv("PDAE_GRAM_SYMMETRIC")) == 0;   // lab: A/B switch
+  if (X == W && strideX == strideW && M == N && N % 4 == 0 && strideY % 4 == 0 && !sym_off &&
+      (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+    // a Gram matrix X X^T: the 64 x 64 tiles on and above the diagonal, each stored a second time transposed (half the
+    // products; G[j][i] is bit for bit the G[i][j] a tile of its own would compute)
+    a.symmetric = 1;
+    launch_cfg<1, 1, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch);
+    return check_launch("rows_gemm_batched");
+  }
   switch (cfg) {
     case 0: launch_cfg<2, 2, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;
     case 1: launch_cfg<1, 2, 2, 2, false, EPI_STORE>(a, 1, 0, s, batch); break;

@@ -242,3 +242,24 @@ def test_entries_refuse_what_they_do_not_implement():
         L.call('pdae_knn_reverse', t, 1, 5000, 2, t.data_ptr(), t.data_ptr(), t.data_ptr())
     with pytest.raises(RuntimeError, match='powers of two'):
         L.call('pdae_edge_gather_stats', t, 1, 8, 2, 48, *([t.data_ptr()] * 8))
+
+
+@pytest.mark.parametrize('B,N,C', [(32, 1024, 64), (3, 1024, 128), (2, 300, 64), (1, 64, 128), (2, 2500, 8), (5, 20, 4), (2, 68, 4)])
+def test_gram_matrices_on_the_upper_triangle_equal_the_full_product(B, N, C):
+    """pdae_rows_gemm_batched with W = X (a Gram matrix) computes the 64 x 64 tiles on and above the diagonal and stores
+    each one a second time transposed: bit for bit the matrix the general path (a separate copy of X as W) computes,
+    symmetric, and X X^T to fp32 rounding."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(N + C)
+    x = torch.randn(B * N, C, device='cuda', generator=g)
+    sym = torch.full((B, N, N), float('nan'), device='cuda')
+    L.call('pdae_rows_gemm_batched', x, B, N, N, C, x.data_ptr(), N * C, x.data_ptr(), N * C, sym.data_ptr(), N * N)
+    w = x.clone()
+    full = torch.full((B, N, N), float('nan'), device='cuda')
+    L.call('pdae_rows_gemm_batched', x, B, N, N, C, x.data_ptr(), N * C, w.data_ptr(), N * C, full.data_ptr(), N * N)
+    assert torch.isfinite(sym).all()
+    assert torch.equal(sym, full)
+    assert torch.equal(sym, sym.transpose(1, 2))
+    xb = x.view(B, N, C).double()
+    ref = xb @ xb.transpose(1, 2)
+    assert (sym.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
