@@ -523,9 +523,17 @@ __global__ __launch_bounds__(256) void cloud_pool_backward_kernel(long long R, i
                                                                   float* __restrict__ dy) {
   const int c4n = C / 4;
   const long long total = R * c4n;
+  // the launch makes the grid's thread count a multiple of C / 4: a thread keeps its four channels over the whole sweep,
+  // so the per-channel terms (two fp64 divisions each) are formed once, not per element
+  const int c4 = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % c4n) * 4;
+  float c1[4], c2[4], mu[4], is[4], sc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    c1[u] = (float)(sums[c4 + u] / (double)R), c2[u] = (float)(sums[C + c4 + u] / (double)R);
+    mu[u] = mean[c4 + u], is[u] = invstd[c4 + u], sc[u] = scale[c4 + u];
+  }
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const long long r = t / c4n;
-    const int c4 = (int)(t - r * c4n) * 4;
     const long long b = r / n;
     const int rl = (int)(r - b * n);
     const float4 v = *reinterpret_cast<const float4*>(y + r * C + c4);
@@ -536,9 +544,8 @@ __global__ __launch_bounds__(256) void cloud_pool_backward_kernel(long long R, i
     float d[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float c1 = (float)(sums[c4 + u] / (double)R), c2 = (float)(sums[C + c4 + u] / (double)R);
-      const float xh = (vv[u] - mean[c4 + u]) * invstd[c4 + u];
-      d[u] = scale[c4 + u] * ((aa[u] == rl ? gg[u] : 0.f) - c1 - xh * c2);
+      const float xh = (vv[u] - mu[u]) * is[u];
+      d[u] = sc[u] * ((aa[u] == rl ? gg[u] : 0.f) - c1[u] - xh * c2[u]);
     }
     *reinterpret_cast<float4*>(dy + r * C + c4) = make_float4(d[0], d[1], d[2], d[3]);
   }
@@ -595,6 +602,8 @@ __global__ void rows_pad_kernel(long long total, int c, int cp, const float* __r
   const int j = (int)(t - r * cp);
   out[t] = j < c ? x[r * c + j] : 0.f;
 }
+
+static long long gcd_ll(long long a, long long b) { return b ? gcd_ll(b, a % b) : a; }
 
 static int part_reduce(hipStream_t s, int P, int width, const double* part, double* out, float* fa, float* fb) {
   hipLaunchKernelGGL(part_reduce_f64_kernel, dim3((width + kWave - 1) / kWave), dim3(1024), 0, s, P, width, part, out, fa, fb);
@@ -769,8 +778,11 @@ extern "C" int pdae_cloud_pool_backward(int b, int n, int C, const float* y, con
   if (b <= 0 || n <= 0 || C <= 0 || C % 4 != 0) return bad_arg("cloud_pool_backward: b, n > 0, C a positive multiple of 4");
   if (!y || !g || !arow || !scale || !mean || !invstd || !sums || !dy) return bad_arg("cloud_pool_backward: null pointer");
   const long long R = (long long)b * n;
-  long long blocks = (R * (C / 4) + 255) / 256;
+  // a grid whose thread count is a multiple of C / 4 (a thread then owns four channels for the whole sweep)
+  const long long per = C / 4, unit = per / gcd_ll(per, 256);       // blocks come in multiples of `unit`
+  long long blocks = (R * per + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  blocks = (blocks + unit - 1) / unit * unit;
   hipLaunchKernelGGL(cloud_pool_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), R, n, C, y, g, arow,
                      scale, mean, invstd, sums, dy);
   return check_launch("cloud_pool_backward");
