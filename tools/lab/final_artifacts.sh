@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's artefacts from ONE box, taken only on a box of typical speed (boxes differ by +-4 %): a short default bench
+# The round's artefacts from ONE box; boxes differ by +-3 %: a short default bench
 # first; above $1 ms per step the call ends there.   gpurun --timeout 2400 -- bash tools/lab/final_artifacts.sh 9.85
 cd "$GRAFT_REPO_ROOT"
 LIMIT=${1:-9.85}
