@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0
 VALU_F32_PEAK_TOPS = 78.6         # fp32 vector peak counted WITHOUT fused multiply-add (157.3 / 2): the geometry
                                   # kernels are sub / mul / add / min chains
 EXP_PEAK_TOPS = 9.8               # v_exp_f32 per second (T/s): the transcendental rate VERDICT r3 prices EMD against
-ROUND = 5                         # profiles/*_rNN.json this bench refers to
+ROUND = 6                         # profiles/*_rNN.json this bench refers to
 
 
 def parse():
@@ -74,6 +74,9 @@ def parse():
                    help='two-phase graphed step with the all-reduce under the embedder backward (auto: when ranks > 1)')
     p.add_argument('--no-also', action='store_true', help='skip the geometry-kernel rooflines and the cfg2 leg')
     p.add_argument('--also-steps', type=int, default=6, help='timed steps of the cfg2 and published-variant legs')
+    p.add_argument('--cpu-worker', type=int, default=-1,
+                   help='(internal) run the cpu_baseline sample in this process pinned to logical CPUs [16 k, 16 k + 16) and print it')
+    p.add_argument('--no-calibration', action='store_true', help='skip the box calibration block and the three extra timed regions')
     p.add_argument('--no-tvis-table', action='store_true',
                    help='skip the per-visible-token-count replay timings and the straggler model built on them')
     return p.parse_args()
@@ -156,6 +159,118 @@ def geometry_rooflines(args, clouds, shape=None):
     emd_row('emd approxmatch, one wave per pair (%d patches of %dx%d)' % (P, k, k), a, b)
     big = clouds[:16].contiguous()
     emd_row('emd approxmatch, one launch per phase (8 clouds of %dx%d)' % (N, N), big[:8].contiguous(), big[8:16].contiguous())
+    return out
+
+
+def box_calibration(device):
+    """Two kernels of known work, ~1 s in all, so that a round's delta can be read against the box it was measured on
+    (MI355X boxes of this pool differ by +-4 % on the step, more on matrix loops: the clock a device holds under load):
+    a register-only bf16 MFMA loop on pseudo-random operands (one wave per SIMD, every CU; csrc/calib.hip) with the shader
+    clock it held, and a 16 B-per-lane streaming copy of 1 GiB (the microarchitecture guide measures 6.29 TB/s)."""
+    import ctypes
+    from point_dae_amd import _lib
+    out = {}
+    try:
+        blocks, iters = 256, 60000
+        sink = torch.zeros(4, device=device)
+        clk = torch.zeros(blocks, 2, dtype=torch.int64, device=device)
+        flops = ctypes.c_double(0.0)
+        run = lambda it: _lib.call('pdae_calib_mfma_bf16', sink, blocks, it, _lib.ptr(sink), _lib.ptr(clk), ctypes.byref(flops))
+        run(2000)
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            run(iters)
+            e.record()
+            torch.cuda.synchronize()
+            ms.append(s.elapsed_time(e))
+        c = clk.double()
+        ghz = (c[:, 0] / c[:, 1].clamp(min=1)).median().item() * 0.1
+        best = min(ms)
+        out['mfma_bf16'] = {'tflops': flops.value / best / 1e9, 'ms': best, 'ms_all': ms, 'shader_clock_ghz': ghz,
+                            'frac_of_dense_peak': flops.value / best / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                            'what': '256 blocks x 4 waves x %d x 32 v_mfma_f32_32x32x16_bf16, register operands with fresh '
+                                    'mantissa bits every iteration; clock = s_memtime / s_memrealtime, median over blocks' % iters}
+        n = 1 << 30
+        src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+        dst = torch.empty_like(src)
+        cp = lambda: _lib.call('pdae_calib_copy', src, n, _lib.ptr(src), _lib.ptr(dst))
+        cp()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            cp()
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) / 5 * 1e3
+        out['copy_f4'] = {'gbs': 2.0 * n / (us * 1e-6) / 1e9, 'avg_us': us, 'bytes_copied': n,
+                          'frac_of_hbm_peak': 2.0 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          'what': 'dst = src, 1 GiB, 16 B per lane, grid-stride; read + write bytes over the launch time'}
+        del src, dst
+    except Exception as err:                                   # a measurement aid: never fails the bench line
+        out['error'] = repr(err)[:200]
+    return out
+
+
+def cfg2_geometry(device, x):
+    """the geometry kernels of Point_CAE_PointNetv2's encoder at its shapes (B=128) -- FPS
+    1024 -> 512 and 512 -> 128, ball query (512 x 32, r 0.2 on 1024 points; 128 x 64, r 0.4 on 512), the grouping
+    (sa_group_rows, both levels) and the coarse Chamfer loss (1024 x 1024) -- as average launch time (HIP events on the
+    launch stream, back to back) against the HBM roofline (algorithmic bytes / 8 TB/s) and the non-FMA fp32 vector
+    roofline (9 operations per point pair / 78.6 T op/s; for the ball query the pair count is the full scan, an upper
+    bound: a lane stops once its ball is full)."""
+    from point_dae_amd import _lib
+    B, N = x.shape[0], x.shape[1]
+    out = []
+
+    def row(name, us, nbytes, pairs, note=None):
+        r = {'kernel': name, 'avg_us': us, 'algorithmic_bytes': nbytes,
+             'hbm_frac': nbytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+             'pair_ops': pairs * 9, 'valu_frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12)}
+        if note:
+            r['note'] = note
+        out.append(r)
+    x = x.contiguous()
+    levels, src = [], x
+    for (np_, ns, radius) in ((512, 32, 0.2), (128, 64, 0.4)):
+        n = src.shape[1]
+        idx = torch.empty(B, np_, dtype=torch.int32, device=device)
+        ctr = torch.empty(B, np_, 3, device=device)
+        us = _event_time_us(lambda: _lib.call('pdae_furthest_point_sampling', src, B, n, np_, _lib.ptr(src), _lib.ptr(idx), _lib.ptr(ctr)))
+        row('fps_kernel (B=%d, %d->%d, + centre gather)' % (B, n, np_), us, B * (12 * n + 4 * np_ + 12 * np_), B * (np_ - 1) * n)
+        bq = torch.empty(B, np_, ns, dtype=torch.int32, device=device)
+        us = _event_time_us(lambda: _lib.call('pdae_ball_query', src, B, n, np_, float(radius), ns, _lib.ptr(ctr), _lib.ptr(src), _lib.ptr(bq)))
+        row('ball_query (B=%d, %d centres x %d samples, r %.1f, %d points)' % (B, np_, ns, radius, n), us,
+            B * (12 * n + 12 * np_ + 4 * np_ * ns), B * np_ * n, 'pair count = full scan (upper bound)')
+        levels.append((src, ctr, bq, n, np_, ns))
+        src = ctr
+    for (pts, ctr, bq, n, np_, ns), C in zip(levels, (0, 128)):
+        feats = torch.randn(B * n, C, device=device) if C else None
+        rows = torch.empty(B * np_ * ns, 4 + C, device=device)
+        us = _event_time_us(lambda: _lib.call('pdae_sa_group_rows', pts, B, n, np_, ns, C, _lib.ptr(pts), _lib.ptr(ctr), _lib.ptr(bq),
+                                              _lib.ptr(feats), _lib.ptr(rows)), iters=10)
+        row('sa_group_rows (B=%d, %d x %d rows of 4+%d from %d points)' % (B, np_, ns, C, n), us,
+            B * (12 * n + 12 * np_ + 4 * np_ * ns + 4 * n * C + 4 * np_ * ns * (4 + C)), 0)
+        if C:
+            dfeat = torch.empty(B * n, C, device=device)
+            us = _event_time_us(lambda: _lib.call('pdae_sa_group_rows_grad', rows, B, n, np_, ns, C, _lib.ptr(bq), _lib.ptr(rows),
+                                                  _lib.ptr(dfeat)), iters=10)
+            row('sa_group_rows_grad (B=%d, %d x %d rows of 4+%d onto %d points)' % (B, np_, ns, C, n), us,
+                B * (4 * np_ * ns + 4 * np_ * ns * (4 + C) + 4 * n * C), 0)
+    a, b = x, torch.roll(x, 1, 0).contiguous()
+    d1, d2 = torch.empty(B, N, device=device), torch.empty(B, N, device=device)
+    i1, i2 = torch.empty(B, N, dtype=torch.int32, device=device), torch.empty(B, N, dtype=torch.int32, device=device)
+    us = _event_time_us(lambda: _lib.call('pdae_chamfer_forward', a, B, N, _lib.ptr(a), N, _lib.ptr(b), _lib.ptr(d1), _lib.ptr(d2),
+                                          _lib.ptr(i1), _lib.ptr(i2)), iters=10)
+    row('chamfer forward (B=%d, %d x %d: the coarse loss)' % (B, N, N), us, B * (12 * 2 * N + 8 * 2 * N), B * 2 * N * N)
+    g1, g2 = torch.ones(B, N, device=device), torch.ones(B, N, device=device)
+    ga, gb = torch.empty_like(a), torch.empty_like(b)
+    us = _event_time_us(lambda: _lib.call('pdae_chamfer_backward', a, B, N, _lib.ptr(a), N, _lib.ptr(b), _lib.ptr(i1), _lib.ptr(i2),
+                                          _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(ga), _lib.ptr(gb)), iters=10)
+    row('chamfer backward (B=%d, %d x %d)' % (B, N, N), us, B * (12 * 2 * N + 4 * 2 * N + 4 * 2 * N + 12 * 2 * N), B * 2 * N)
     return out
 
 
@@ -293,7 +408,10 @@ def dominant_roofline(per_tvis, G, bf16x3):
                                              'fabric-side counters: Infinity-Cache hits included)' % rnd)
                 break
     return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-            'traffic': traffic, 'traffic_source': traffic_src,
+            'traffic': traffic, 'traffic_source': traffic_src, 'traffic_measured_in_this_run': False,
+            # the expectation runs over the captured visible-token counts: the default run captures the whole support of
+            # P(T_vis) (mass 1.0); a run that covers less than 0.95 of it is flagged, its figure is not comparable
+            'covered_probability_mass': z, 'comparable': bool(z >= 0.95),
             'algorithmic_bytes': gbytes * 1e9,
             'algorithmic_bytes_note': 'per step: every operand and every result of every launch of the two families once, 4 B per '
                                       'element (M K + N K + slabs M N per product, M (N + K) + N K per weight gradient: DESIGN.md 4b)',
@@ -373,11 +491,16 @@ def cfg2_leg(args, device, rank):
         gemm_roof = {'error': repr(err)[:200]}
     model.zero_grad()
     del model, optimizer, gstep
+    try:
+        geo = cfg2_geometry(device, x[:B])
+    except Exception as err:                                   # a measurement aid: never fails the bench line
+        geo = {'error': repr(err)[:200]}
     return {'workload': 'cfg2: pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml (Point_CAE_PointNetv2), '
                         'B=128, N=1024, full train step, hipGraph replay',
             'value': B * args.also_steps / dt, 'unit': 'clouds/s', 'ms_per_step': dt / args.also_steps * 1e3,
             'steps': args.also_steps,
             'roofline_gemm': gemm_roof,
+            'roofline_geometry': geo,
             'roofline': {'kernel': 'chamfer_fwd_tiled (128 x 16384 x 1024)', 'bound': 'valu', 'avg_us': us,
                          'achieved': pairs * 9 / (us * 1e-6) / 1e12, 'peak': VALU_F32_PEAK_TOPS, 'unit': 'T op/s',
                          'frac': pairs * 9 / (us * 1e-6) / (VALU_F32_PEAK_TOPS * 1e12),
@@ -521,6 +644,8 @@ def cpu_baseline(config, args):
     # all host cores up to 16: beyond that torch's intra-op pools only contend on
     # these small GEMMs (256 threads on the GPU box ran 20x SLOWER than 16)
     cores = min(os.cpu_count() or 1, 16)
+    if getattr(args, 'cpu_worker', -1) >= 0:     # one of the pinned processes of cpu_baseline_box
+        os.sched_setaffinity(0, set(range(16 * args.cpu_worker, 16 * args.cpu_worker + 16)))
     torch.set_num_threads(cores)
     O.build()
     O.set_threads(cores)
@@ -566,6 +691,34 @@ def cpu_baseline(config, args):
                           args.cpu_steps, args.cpu_batch, args.npoints, args.num_group, dt)}
 
 
+def cpu_baseline_box(args, one):
+    """The same sample on the whole box: floor(logical CPUs / 16) processes, each pinned to 16 logical CPUs and running
+    16 threads (the size at which ONE process is fastest: cpu_baseline), all at the same time; their rates summed.
+    `one` = the single-process figure, kept as cpu_baseline.value."""
+    import subprocess
+    n = (os.cpu_count() or 1) // 16
+    if n < 2:
+        return None
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='', OMP_NUM_THREADS='16')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-batch', str(args.cpu_batch), '--npoints', str(args.npoints),
+           '--num_group', str(args.num_group)]
+    procs = [subprocess.Popen(cmd + ['--cpu-worker', str(k)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for k in range(n)]
+    vals = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=180)
+            vals.append(json.loads(out.strip().splitlines()[-1])['value'])
+        except Exception:                                      # a worker that failed counts as zero
+            pr.kill()
+    if not vals:
+        return None
+    return {'value': sum(vals), 'unit': 'clouds/s', 'processes': len(vals), 'threads_per_process': 16, 'cores': 16 * len(vals),
+            'per_process_min': min(vals), 'per_process_max': max(vals), 'kind': 'port',
+            'sample': 'the cpu_baseline sample in %d processes at once, each pinned to 16 logical CPUs (of %d); rates summed; '
+                      'one process alone on the idle box: %.1f clouds/s' % (len(vals), os.cpu_count(), one['value'])}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a
     CHILD process (`python -m torch.distributed.run`, one rank per GPU over RCCL), relay rank 0's
@@ -604,6 +757,12 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.cpu_worker >= 0:                       # a pinned CPU-oracle worker of cpu_baseline_box: never touches a GPU
+        from point_dae_amd.config import cfg_from_yaml_file
+        config = cfg_from_yaml_file(os.path.join(ROOT, CFG3))
+        config.npoints, config.model.num_group = args.npoints, args.num_group
+        print(json.dumps(cpu_baseline(config, args)), flush=True)
+        return
     if args.gpus > 1 and 'RANK' not in os.environ:
         raise SystemExit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -696,6 +855,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # three more timed regions of 20 steps each (same bracketing; every rank runs them): their median next to the single
+    # figure above, and the box calibration, so that a round-to-round delta can be told from box-to-box variance
+    regions, calib = None, None
+    if not args.no_calibration:
+        regions = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for i in range(20):
+                step(batches[i % pool])
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            regions.append((time.perf_counter() - t1) / 20 * 1e3)
+        if rank == 0:
+            calib = box_calibration(device)
     probe_mode = 'HIP events around every launch of the kernel inside the timed region (eager launches)'
     per_tvis = None
     if not args.eager and rank == 0 and args.workload == 'cfg3':
@@ -762,7 +939,7 @@ def main():
             R_, c3_, c2_ = args.batch * args.num_group * 32, 512, 256
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS,
-                    'traffic': traffic, 'traffic_source': traffic_src,
+                    'traffic': traffic, 'traffic_source': traffic_src, 'traffic_measured_in_this_run': False,
                     'algorithmic_bytes': 4.0 * (R_ * c2_ + c3_ * c2_ + R_ * c3_ + (R_ // 32) * c3_),
                     'kernel': ('pdae::' + kname) + ': ' + kern['name'],
                     'avg_us': kern['avg_ms'] * 1e3, 'launches': kern['launches'],
@@ -796,6 +973,10 @@ def main():
                                        if bf16x3 else 'hand-written fp32 MFMA kernels (csrc/rows_gemm.hip, gemm.hip); no BLAS library in the step'},
             'roofline': dom if dom else best,
             'roofline_best': best if dom else None,
+            'box_calibration': calib,
+            'timed_regions': ({'ms_per_step': regions, 'median_ms_per_step': sorted(regions)[1], 'steps_each': 20,
+                               'note': 'three more timed regions run right after the one `value` is computed from'}
+                              if regions else None),
             # sanity of the timed steps: Chamfer loss of the first and of the last timed optimisation step
             'loss': {'first_timed_step': float(loss_first), 'last_timed_step': float(loss_last)},
         }
@@ -812,6 +993,7 @@ def main():
                     by_fam[k] = by_fam.get(k, 0.0) + pt[t] / z * r['gflop']
             gf = sum(by_fam.values())
             line['whole_step'] = {'gflop_executed': gf, 'unit': 'TFLOP/s', 'gflop_by_family': by_fam,
+                                  'covered_probability_mass': z,
                                   'timed_ms_per_step': elapsed / args.steps * 1e3,
                                   'achieved_on_timed_ms': gf / (elapsed / args.steps * 1e3),
                                   'note': 'fp32 FLOPs of every dense product the step executes, counted at the launch sites per '
@@ -839,6 +1021,7 @@ def main():
                 line['also']['cfg5_shape'] = cfg5_leg(args, device, rank)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(config, args)
+            line['cpu_baseline']['whole_box'] = cpu_baseline_box(args, line['cpu_baseline'])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -851,6 +851,17 @@ int pdae_adamw_step(long long n, float* param, const float* grad,
                     float beta2, float eps, float weight_decay, int step,
                     pdae_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Measurement aids: box calibration for bench.py (csrc/calib.hip).  They replace nothing of the reference; the training
+ * step never calls them.  MI355X boxes differ by +-4 % on the step and by up to 12 % on matrix loops (the clock a device
+ * holds under load), so a bench line carries the rates of two kernels of known work next to its headline.
+ *   calib_mfma_bf16  `blocks` work-groups of 4 waves (one per SIMD) each issue iters x 32 v_mfma_f32_32x32x16_bf16 on
+ *                    pseudo-random register operands: *flops (host, nullable) = the FLOPs of the launch; clk[b][0..1] =
+ *                    shader-clock cycles and 100 MHz ticks wave 0 of block b lived (clock = 100 MHz x cycles / ticks).
+ *   calib_copy       dst[0..bytes) = src[0..bytes), 16 B per lane, grid-stride: 2 x bytes of HBM traffic.            */
+int pdae_calib_mfma_bf16(int blocks, int iters, float* sink, long long* clk, double* flops, pdae_stream_t stream);
+int pdae_calib_copy(long long bytes, const void* src, void* dst, pdae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,8 @@ _SIGNATURES = {
     "pdae_edge_weight_unstack_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_edge_weight_unstack": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_cloud_pool_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_calib_mfma_bf16": [_i, _i, _vp, _vp, _vp, _vp],
+    "pdae_calib_copy": [ctypes.c_longlong, _vp, _vp, _vp],
 }
 # host-side queries (no stream argument)
 _HOST = {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(int T, int H, float 
       const int qrow = acc_row(e, h);
       const float iv = __shfl(inv, qrow, kWave);  // lane qrow (h = 0 half) holds query qrow's 1/l
       const int q = w * 32 + qrow;
-      if (q < T) o[((size_t)b * T + q) * H * AD + hd * AD + dt * 32 + r] = oa[e] * iv;
+      if (q < T) store_wt(&o[((size_t)b * T + q) * H * AD + hd * AD + dt * 32 + r], oa[e] * iv);
     }
   }
 }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(int T, int H, float 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int qq = w * 32 + acc_row(e, h);
-        if (qq < T) dqkv[((size_t)b * T + qq) * rs + hd * AD + dt * 32 + r] = dqa[dt][e];
+        if (qq < T) store_wt(&dqkv[((size_t)b * T + qq) * rs + hd * AD + dt * 32 + r], dqa[dt][e]);
       }
   }
   // ---- part 2: dK, dV for key tile w.  X = P, dS (rows = queries, lane = key w*32+r)
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(int T, int H, float 
         const int kk = w * 32 + acc_row(e, h);
         if (kk < T) {
           float* row = dqkv + ((size_t)b * T + kk) * rs + hd * AD + dt * 32 + r;
-          row[(size_t)H * AD] = dka[dt][e];
-          row[(size_t)2 * H * AD] = dva[dt][e];
+          store_wt(row + (size_t)H * AD, dka[dt][e]);
+          store_wt(row + (size_t)2 * H * AD, dva[dt][e]);
         }
       }
   }

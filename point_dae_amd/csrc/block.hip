@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
         const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)row * C + c4 * 4);
         a.x += p.x, a.y += p.y, a.z += p.z, a.w += p.w;
       }
-      if (pos || br) *reinterpret_cast<float4*>(xsum + (size_t)row * C + c4 * 4) = a;
+      if (pos || br) store_wt4(xsum + (size_t)row * C + c4 * 4, a);
       v[i] = a;
       s += (a.x + a.y) + (a.z + a.w);
     }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(
       o.y = (v[i].y - mu) * rs * g.y + b.y;
       o.z = (v[i].z - mu) * rs * g.z + b.z;
       o.w = (v[i].w - mu) * rs * g.w + b.w;
-      *reinterpret_cast<float4*>(y + (size_t)row * C + c4 * 4) = o;
+      store_wt4(y + (size_t)row * C + c4 * 4, o);
     }
   }
 }
@@ -185,9 +185,9 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
         o.y = rs_ * (gd[i].y - m1 - xh[i].y * m2) + sk[i].y;
         o.z = rs_ * (gd[i].z - m1 - xh[i].z * m2) + sk[i].z;
         o.w = rs_ * (gd[i].w - m1 - xh[i].w * m2) + sk[i].w;
-        *reinterpret_cast<float4*>(dx + (size_t)row * C + c4 * 4) = o;
+        store_wt4(dx + (size_t)row * C + c4 * 4, o);
         if (dacc_mode == 1) {
-          *reinterpret_cast<float4*>(dacc + (size_t)row * C + c4 * 4) = o;
+          store_wt4(dacc + (size_t)row * C + c4 * 4, o);
         } else if (dacc_mode == 2) {
           float4 t = *reinterpret_cast<const float4*>(dacc + (size_t)row * C + c4 * 4);
           t.x += o.x, t.y += o.y, t.z += o.z, t.w += o.w;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(
         }
         if (dbias) {
           if (keep) o.x *= kp_, o.y *= kp_, o.z *= kp_, o.w *= kp_;
-          if (da) *reinterpret_cast<float4*>(da + (size_t)row * C + c4 * 4) = o;
+          if (da) store_wt4(da + (size_t)row * C + c4 * 4, o);
           ac[i].x += o.x, ac[i].y += o.y, ac[i].z += o.z, ac[i].w += o.w;
         }
       }

@@ -75,6 +75,31 @@ __device__ __forceinline__ void col_add(float* out, float* part, int partition, 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// ---- write-through result stores (round 6) ------------------------------------------------------------------------
+// A kernel's results leave through `sc1` stores: the bytes go to memory while the kernel still runs instead of staying
+// dirty in the XCD's L2 until the write-back at the kernel's end, which the NEXT dependent kernel waits for (a boundary
+// costs ~1.5 us + dirty bytes / 6 TB/s: MI355X_MICROARCH.md price list, "boundary"; the step is a chain of 330 dependent
+// kernels).  The consumer is always another kernel, whose L2 does not keep this one's lines anyway.  Measured on the
+// step with the row GEMMs' epilogues alone: -0.11 ms of 10.4 (tools/lab/NOTES.md).  -DPDAE_PLAIN_STORES: plain stores (A/B).
+typedef float f32x4_wt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float* p, float v) {
+#ifdef PDAE_PLAIN_STORES
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store_dword ... sc1
+#endif
+}
+__device__ __forceinline__ void store_wt4(float* p, const float4& v) {
+#ifdef PDAE_PLAIN_STORES
+  *reinterpret_cast<float4*>(p) = v;
+#else
+  const f32x4_wt t = {v.x, v.y, v.z, v.w};
+  // (no builtin carries the sc1 bit for a 16-byte store; the trailing s_nop keeps the data registers until the store
+  // has read them: cdna_hip_programming.md 5.7)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#endif
+}
+
 // exact (erf) GELU of nn.GELU (models/PointCAE_transformer.py:94-110) and its derivative
 __device__ __forceinline__ float gelu_f(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -96,7 +121,9 @@ __device__ __forceinline__ float gelu_grad_f(float v) {
 // |GELU| 3.8e-7, |GELU'| 1.3e-7 -- the erff / expf formulation above: 6.1e-8, 4.5e-7.  ~22 instructions, two of them
 // transcendental (v_rcp_f32, v_exp_f32).
 __device__ __forceinline__ void gelu_pair_f(float v, float& gelu, float& grad) {
-  const float ax = fabsf(v) * 0.424264069f;                                  // p |v| / sqrt 2
+  // (|v| clamped at 1e18: v = +inf must give GELU = inf, GELU' = 1 as the erff / expf form does, not inf * rcp(inf) = NaN;
+  // finite activations are untouched by the clamp)
+  const float ax = fminf(fabsf(v) * 0.424264069f, 1e18f);                    // p |v| / sqrt 2
   const float u = ax * __builtin_amdgcn_rcpf(1.0f + ax);
   float r = 0.0685024065f;
   r = __builtin_fmaf(r, u, -0.0438022078f);
@@ -109,7 +136,7 @@ __device__ __forceinline__ void gelu_pair_f(float v, float& gelu, float& grad) {
   const float q = (0.5f * __builtin_fmaf(r, u, 1.0f)) * e;                       // Phi(-|v|)
   const float cdf = v >= 0.f ? 1.0f - q : q;
   gelu = v * cdf;
-  grad = __builtin_fmaf(v, 0.39894228040143267794f * e, cdf);
+  grad = __builtin_fmaf(fminf(v, 1e18f), 0.39894228040143267794f * e, cdf);
 }
 
 // ---- 64-lane shuffles on 64-bit keys (two ds_bpermute each) ----------------

@@ -45,6 +45,15 @@ constexpr int BK3 = 32;          // reduction depth of one staged tile (two 16-d
 #else
 #define R3_STAMP_AT(i)
 #endif
+// results leave through write-through stores (common.h store_wt)
+#define R3_STORE(ptr, v) store_wt((ptr), (v))
+// (lab, round 6) -DR3_PRIO: one s_setprio 1 for the younger half of an 8-wave block: measured, nothing (10.38 / 10.35 ms
+// against 10.40 / 10.35)
+#ifdef R3_PRIO
+#define R3_SETPRIO() do { if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1); } while (0)
+#else
+#define R3_SETPRIO() do { } while (0)
+#endif
 #ifndef R3_FPS
 #define R3_FPS 3                 // fragment reads per slot behind a tile's barrier (lab: tools/lab/fps_sweep.sh)
 #endif
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       });
     };
 
+    R3_SETPRIO();
     if (KT > 0) {
       gload_a(C0{}, 0);
       gload_b(C0{}, 0);
@@ -383,12 +393,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
             if (EPI == rows::EPI_BIAS_GELU2) {
               float ge, gr;
               gelu_pair_f(v, ge, gr);                             // (common.h: one exponential for GELU and GELU')
-              p.Z[off + (unsigned)lr * ldc] = gr;
+              R3_STORE(&p.Z[off + (unsigned)lr * ldc], gr);
               v = ge;
             }
             if (EPI == rows::EPI_MUL_GELUGRAD) v *= zv[e];
             if (EPI == rows::EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;
-            Cs[off + (unsigned)lr * ldc] = v;
+            R3_STORE(&Cs[off + (unsigned)lr * ldc], v);
           }
         }
       }
@@ -445,6 +455,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
   const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (TM + wn * TJ * 32 + r) * ROWB + 16 * h;
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
+  R3_SETPRIO();
   for (; u < uend; slot += WSLOT) {
     const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
     const long long rel = u - P.unit0;
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
           for (int e = 0; e < 16; ++e) {
             const int row = n0 + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             const int cc = k0 + (wn * TJ + j) * 32 + r;
-            if (row < P.N && cc < P.K) P.dW[(size_t)row * P.K + cc] = hi[i][j][e] + lo[i][j][e];
+            if (row < P.N && cc < P.K) R3_STORE(&P.dW[(size_t)row * P.K + cc], hi[i][j][e] + lo[i][j][e]);
           }
       continue;
     }
@@ -634,7 +645,257 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          slot[row * TN + (wn * TJ + j) * 32 + r] = hi[i][j][e] + lo[i][j][e];
+          R3_STORE(&slot[row * TN + (wn * TJ + j) * 32 + r], hi[i][j][e] + lo[i][j][e]);
+        }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wgrad3b_kernel's contract with the operands staged THE WAY THEY LIE IN MEMORY (round 6): both bands are stored across
+// the reduction ([m][column]), so a thread loads one OCTET OF A ROW -- eight consecutive columns of one of the tile's 32
+// rows, two 16-byte loads per operand instead of eight 4-byte loads down a column -- splits it with the same split_chunk
+// and stores each plane with one ds_write_b128 into a natural [plane][m][128 columns] image (256-byte rows, no padding:
+// 96 KB for the two buffers instead of 122).  The transpose moves to the fragment reads: ds_read_b64_tr_b16 hands a lane
+// four consecutive m of ITS column (cdna_hip_programming.md T10), two of them make the eight k of a 32x32x16 operand.
+// Image: byte (m, c) = 256 m + ((2 c) ^ ((m & 3) << 6)): the four rows a 16-lane group reads land in the four 64-byte
+// quarters of the bank space, so a half-wave's 32 addresses cover all 64 banks once (conflict-free by construction; the
+// stores are eight consecutive 16-byte chunks of one row).  Same MFMA order as wgrad3b_kernel: dW is bit-identical; the
+// column sums (db) are added in a different order (a thread owns eight columns of one row, not one column of eight).
+// Needs N % 8 == 0, K % 8 == 0 and 16-byte aligned operands (the host falls back to wgrad3b_kernel otherwise).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool FORMS>
+__global__ __launch_bounds__(512) void wgrad3t_kernel(const rows::WgradArgs g) {
+  using rows::WgradProb;
+  constexpr int TM = rows::WTM, TN = 128, WCH = rows::WCH, BKT = 32;
+  constexpr int PROW = 256, BAND = BKT * PROW, PLANE = 2 * BAND, BUF = 3 * PLANE;
+  constexpr int TI = 1, TJ = 2, G = TI * TJ, WN = 2;
+  constexpr int WSLOT = rows::wslot(TN);
+  constexpr bool DUAL = true;
+  static_assert(TM == 128, "one 256-byte image row per band");
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int srow = tid >> 4, sch = tid & 15;                  // staged octet: row srow of the tile, columns 8 sch .. 8 sch + 7
+  const int srow_u = __builtin_amdgcn_readfirstlane(srow) & ~3;   // (a wave stages rows 4 w .. 4 w + 3)
+  const int wlds = srow * PROW + ((sch * 16) ^ ((srow & 3) << 6));
+  // transposed fragment reads: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
+  const int lq = (lane >> 2) & 3, lp = lane & 3, lcb = (lane >> 4) & 1;
+  auto tr_off = [&](int T) { return PROW * (8 * h + lq) + 64 * (T ^ lq) + 32 * lcb + 16 * (lp >> 1) + 8 * (lp & 1); };
+  const int fa_off = tr_off(wm), fb_off0 = BAND + tr_off(wn * TJ), fb_off1 = BAND + tr_off(wn * TJ + 1);
+  const int nb8 = g.blocks >> 3;
+  const int sb = g.blocks % 8 == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  long long u = rows::wg_start(g, sb);
+  const long long uend = rows::wg_start(g, sb + 1);
+  float* slot = g.partials + (size_t)sb * g.slots * WSLOT;
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  R3_SETPRIO();
+  for (; u < uend; slot += WSLOT) {
+    const WgradProb& P = g.p[rows::wg_prob_of_unit(g, u)];
+    const long long rel = u - P.unit0;
+    const int lt = P.lt0 + (int)(rel / P.chunks), c0 = (int)(rel % P.chunks);
+    const int c1 = (int)min((long long)P.chunks, c0 + (uend - u));
+    u += c1 - c0;
+    const int bx = lt % P.tk, by = lt / P.tk;
+    const int n0 = by * TM, k0 = bx * TN;
+    const int mbeg = c0 * WCH, mend = min(P.M, c1 * WCH), mlast = mend - 1;
+    const int KT = (mend - mbeg + BKT - 1) / BKT;
+    const bool aok = n0 + 8 * sch < P.N, bok = k0 + 8 * sch < P.K;             // (N, K multiples of 8: an octet is in or out)
+    const unsigned acol = (unsigned)min(n0 + 8 * sch, P.N - 8), bcol = (unsigned)min(k0 + 8 * sch, P.K - 8);
+    const unsigned lda = P.N, ldb = P.K;
+    const float* const Ab = P.dY;
+    const float* const Bb = P.X;
+    const bool edge = n0 + TM > P.N || k0 + TN > P.K;             // (block-uniform)
+    const bool sums = P.db != nullptr && bx == 0;
+    const int* const grp_a = FORMS ? g.a_groups : nullptr;
+    const int* const grp_b = FORMS ? g.b_groups : nullptr;
+    const bool bnrelu = FORMS && g.scale != nullptr;
+    float bsc[8], bsh[8], asum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsc[e] = 1.f, bsh[e] = 0.f, asum[e] = 0.f;
+    if (bnrelu && bok) {
+      const float4 s0 = *reinterpret_cast<const float4*>(g.scale + k0 + 8 * sch), s1 = *reinterpret_cast<const float4*>(g.scale + k0 + 8 * sch + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(g.shift + k0 + 8 * sch), h1 = *reinterpret_cast<const float4*>(g.shift + k0 + 8 * sch + 4);
+      bsc[0] = s0.x, bsc[1] = s0.y, bsc[2] = s0.z, bsc[3] = s0.w, bsc[4] = s1.x, bsc[5] = s1.y, bsc[6] = s1.z, bsc[7] = s1.w;
+      bsh[0] = h0.x, bsh[1] = h0.y, bsh[2] = h0.z, bsh[3] = h0.w, bsh[4] = h1.x, bsh[5] = h1.y, bsh[6] = h1.z, bsh[7] = h1.w;
+    }
+
+    float ra[2][8], rb[2][8];
+    u32x4 pka[3], pkb[3];
+    // byte offsets of this thread's octet from the tile's first row: a whole tile's loads share one scalar base per operand
+    const unsigned voa = ((unsigned)srow * lda + acol) * 4u, vob = ((unsigned)srow * ldb + bcol) * 4u;
+    auto put8 = [](float (&d)[8], const float4& v0, const float4& v1) __attribute__((always_inline)) {
+      d[0] = v0.x, d[1] = v0.y, d[2] = v0.z, d[3] = v0.w, d[4] = v1.x, d[5] = v1.y, d[6] = v1.z, d[7] = v1.w;
+    };
+    auto gload = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const int mt = mbeg + min(kt, KT - 1) * BKT;
+      int offa = 0, offb = 0;                          // stored row - product row of this tile (listed operands)
+      if (FORMS) {
+        const int gq = mt >> 5;
+        if (grp_a) offa = (grp_a[gq] - gq) * 32;
+        if (grp_b) offb = (grp_b[gq] - gq) * 32;
+      }
+      if (mt + BKT <= mend) {                          // (block-uniform) a whole tile: no row clamps
+        const char* pa = reinterpret_cast<const char*>(Ab + (size_t)(mt + offa) * lda);
+        const char* pb = reinterpret_cast<const char*>(Bb + (size_t)(mt + offb) * ldb);
+        put8(ra[set], *reinterpret_cast<const float4*>(pa + voa), *reinterpret_cast<const float4*>(pa + voa + 16));
+        put8(rb[set], *reinterpret_cast<const float4*>(pb + vob), *reinterpret_cast<const float4*>(pb + vob + 16));
+      } else {                                         // rows past the end re-read the last row (zeroed in fixup)
+        const int m = min(mt + srow, mlast);
+        const float* pa = Ab + (size_t)(m + offa) * lda + acol;
+        const float* pb = Bb + (size_t)(m + offb) * ldb + bcol;
+        put8(ra[set], *reinterpret_cast<const float4*>(pa), *reinterpret_cast<const float4*>(pa + 4));
+        put8(rb[set], *reinterpret_cast<const float4*>(pb), *reinterpret_cast<const float4*>(pb + 4));
+      }
+    };
+    // what a register set still needs before it is split: producer, zeros past the edges, the column sums
+    auto fixup = [&](auto set_c, int kt) __attribute__((always_inline)) {
+      constexpr int set = decltype(set_c)::value;
+      const int mt = mbeg + kt * BKT;
+      const bool live = kt < KT;                       // (tiles past the end are split into the buffer nobody reads)
+      if (bnrelu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rb[set][q] = fmaxf(rb[set][q] * bsc[q] + bsh[q], 0.f);
+      }
+      if (edge || mt + BKT > mend) {
+        const bool in = mt + srow < mend;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          ra[set][q] = (in && aok) ? ra[set][q] : 0.f;
+          rb[set][q] = (in && bok) ? rb[set][q] : 0.f;
+        }
+      }
+      if (sums && live) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asum[q] += ra[set][q];
+      }
+    };
+    auto side_chunk = [&](auto c_c, auto set_c, int buf) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value, o = c / 8, ch = c % 8, set = decltype(set_c)::value;
+      auto run = [&](float (&v)[8], u32x4 (&pk)[3], char* d) __attribute__((always_inline)) {
+        split_chunk<ch>(v, pk);
+        if (ch == 3) *reinterpret_cast<u32x4*>(d) = pk[0];
+        if (ch == 7) {
+          *reinterpret_cast<u32x4*>(d + PLANE) = pk[1];
+          *reinterpret_cast<u32x4*>(d + 2 * PLANE) = pk[2];
+        }
+      };
+      if constexpr (o == 0) run(ra[set], pka, lds3 + buf * BUF + wlds);
+      else run(rb[set], pkb, lds3 + buf * BUF + BAND + wlds);
+    };
+    f32x16 hi[TI][TJ], lo[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+    bf16x8 fa[2][TI][3], fb[2][TJ][3];
+    constexpr int NF = 3 * (TI + TJ);
+    // fragment f of a 16-deep step s16 (rows 16 s16 .. 16 s16 + 15 of the tile): two transposed reads, rows 8 h .. 8 h + 3 and
+    // 8 h + 4 .. 8 h + 7 of the step
+    auto frag_one = [&](auto f_c, auto st_c, int buf, int s16) __attribute__((always_inline)) {
+      constexpr int f = decltype(f_c)::value, st = decltype(st_c)::value;
+      constexpr int FPL[6] = {2, 0, 0, 2, 1, 1};
+      constexpr bool isa = f < 6 ? (f % 2 == 0) : (f - 6 < 3 * (TI - 1));
+      constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
+      constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
+      const char* base = lds3 + buf * BUF + s16 * (16 * PROW) + pl * PLANE;
+      if constexpr (isa) {
+        fa[st][tl][pl] = tr_frag(base + fa_off, base + fa_off + 4 * PROW);
+      } else {
+        const int off = tl == 0 ? fb_off0 : fb_off1;
+        fb[st][tl][pl] = tr_frag(base + off, base + off + 4 * PROW);
+      }
+    };
+    constexpr int S = 12 * G, NR = (NF + R3_FPS - 1) / R3_FPS, SB = S - NR, NC = 16, SC = SB - 1;
+    auto ktile = [&](auto par_c, int kt) __attribute__((always_inline)) {
+      constexpr int P2 = decltype(par_c)::value;
+      using SetN = std::integral_constant<int, P2 ^ 1>;
+      fixup(SetN{}, kt + 1);
+      static_for<S>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        constexpr int step = s / (6 * G), gi = (s % (6 * G)) / 6, q = s % 6;
+        mfma_one<DUAL, q>(fa[step][gi / TJ], fb[step][gi % TJ], hi[gi / TJ][gi % TJ], lo[gi / TJ][gi % TJ]);
+        static_for<NF>([&](auto f_c) {
+          constexpr int f = decltype(f_c)::value;
+          if constexpr (f * (6 * G) / NF == s) frag_one(f_c, C1{}, P2, 1);
+        });
+        static_for<NC>([&](auto c_c) {
+          constexpr int c = decltype(c_c)::value;
+          if constexpr (c * SC / NC == s) side_chunk(c_c, SetN{}, P2 ^ 1);
+        });
+        if constexpr (s == (NC - 1) * SC / NC) gload(SetN{}, kt + 3);
+        if constexpr (s == SB - 1) __syncthreads();
+        if constexpr (s >= SB) {
+          static_for<NF>([&](auto f_c) {
+            constexpr int f = decltype(f_c)::value;
+            if constexpr (f / R3_FPS == s - SB) frag_one(f_c, C0{}, P2 ^ 1, 0);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    gload(C0{}, 0);
+    gload(C1{}, 1);
+    fixup(C0{}, 0);
+    static_for<NC>([&](auto c_c) { side_chunk(c_c, C0{}, 0); });
+    gload(C0{}, 2);
+    __syncthreads();
+    static_for<NF>([&](auto f_c) { frag_one(f_c, C0{}, 0, 0); });
+    for (int kt = 0; kt < KT; kt += 2) {
+      ktile(C0{}, kt);
+      if (kt + 1 < KT) ktile(C1{}, kt + 1);
+    }
+    // ---- the partial tile (whole TM x TN, edges included: the reduction stores what is inside)
+    __syncthreads();
+    if (sums) {
+      float* red = reinterpret_cast<float*>(lds3);     // [32 staged rows][TM]; the tile buffers are free now
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[srow * TM + 8 * sch + e] = asum[e];
+      __syncthreads();
+      if (tid < TM) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < BKT; ++q) t += red[q * TM + tid];
+        if (!g.direct) slot[TM * TN + tid] = t;
+        else if (n0 + tid < P.N) P.db[n0 + tid] = t;
+      }
+      __syncthreads();
+    }
+    (void)srow_u;
+    if (g.direct) {                                    // this block summed the tile over ALL rows: the result, not a partial
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = n0 + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int cc = k0 + (wn * TJ + j) * 32 + r;
+            if (row < P.N && cc < P.K) R3_STORE(&P.dW[(size_t)row * P.K + cc], hi[i][j][e] + lo[i][j][e]);
+          }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          R3_STORE(&slot[row * TN + (wn * TJ + j) * 32 + r], hi[i][j][e] + lo[i][j][e]);
         }
   }
 }
@@ -790,6 +1051,7 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  R3_SETPRIO();
   gload(C0{}, 0);
   gload(C1{}, 1);
   static_for<NC>([&](auto c_c) { side_chunk(c_c, C0{}, 0); });
@@ -846,7 +1108,7 @@ __global__ __launch_bounds__(512) void conv3_kernel(const NtArgs p) {
         if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
           if (v > vmax) vmax = v, amax = lr;            // e ascending => lr ascending within this half
         }
-        if (EPI != EPI_GROUPMAX && in) cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+        if (EPI != EPI_GROUPMAX && in) R3_STORE(&cbase[(unsigned)((e & 3) + 8 * (e >> 2)) * ldc], v);
       }
       if (EPI == EPI_GROUPMAX || EPI == EPI_STORE_GROUPMAX) {
         const float ov = __shfl_xor(vmax, 32, kWave);

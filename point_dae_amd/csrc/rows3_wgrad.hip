@@ -1,8 +1,24 @@
 // rows3_wgrad.hip -- the grouped weight gradients on exact-split bf16 (rows3_kernel.h wgrad3b_kernel)
+#include <cstdlib>
+
 #include "rows3_kernel.h"
 
 namespace pdae {
 namespace rows3 {
+
+// The row-staged kernel (wgrad3t_kernel: 16-byte row loads, transposed fragment reads) takes every group whose widths are
+// multiples of 8 and whose operands are 16-byte aligned -- every weight gradient of the shipped models; PDAE_WGRAD3=b
+// keeps the column-patch kernel (A/B runs).
+static bool row_staged_ok(const rows::WgradArgs& g) {
+  static const bool forced_b = [] { const char* e = getenv("PDAE_WGRAD3"); return e && e[0] == 'b'; }();
+  if (forced_b) return false;
+  for (int i = 0; i < g.nprob; ++i) {
+    const rows::WgradProb& p = g.p[i];
+    if (p.N % 8 || p.K % 8 || ((uintptr_t)p.dY & 15) || ((uintptr_t)p.X & 15)) return false;
+  }
+  if (g.scale && (((uintptr_t)g.scale & 15) || ((uintptr_t)g.shift & 15))) return false;
+  return true;
+}
 
 template <bool FORMS>
 static void wgrad3_launch(const rows::WgradArgs& g, int pl, hipStream_t s) {
@@ -10,14 +26,25 @@ static void wgrad3_launch(const rows::WgradArgs& g, int pl, hipStream_t s) {
   constexpr int TN = 128;
   constexpr int PARTS1 = WTM * TN / 4 / (256 * wru(1));
   constexpr int PARTSL = WTM * TN / 4 / 256;
-  const size_t lds = (size_t)2 * 3 * (WTM + TN) * 80;
-  auto k = wgrad3b_kernel<FORMS>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
+  if (row_staged_ok(g)) {
+    const size_t lds = (size_t)2 * 3 * 2 * 32 * 256;
+    auto k = wgrad3t_kernel<FORMS>;
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      once = true;
+    }
+    hipLaunchKernelGGL(k, dim3(g.blocks), dim3(512), lds, s, g);
+  } else {
+    const size_t lds = (size_t)2 * 3 * (WTM + TN) * 80;
+    auto k = wgrad3b_kernel<FORMS>;
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      once = true;
+    }
+    hipLaunchKernelGGL(k, dim3(g.blocks), dim3(512), lds, s, g);
   }
-  hipLaunchKernelGGL(k, dim3(g.blocks), dim3(512), lds, s, g);
   if (g.direct) return;                              // whole tiles stored by their blocks: nothing to reduce
   if (pl == 1) hipLaunchKernelGGL((wgrad_reduce_kernel<1, TN>), dim3(g.tiles * PARTS1), dim3(256), 0, s, g);
   else if (pl == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<4, TN>), dim3(g.tiles * PARTSL * 4), dim3(256), 0, s, g);

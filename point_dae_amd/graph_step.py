@@ -44,6 +44,34 @@ def _warn_if_null_stream():
                       'replays corrupts hipGraph replays on this platform)', RuntimeWarning, stacklevel=3)
 
 
+def _bn_buffers(module):
+    """running_mean / running_var / num_batches_tracked of every BatchNorm under `module`: the state a training-mode
+    forward changes besides the gradients."""
+    out = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.running_mean is not None:
+            out += [m.running_mean, m.running_var, m.num_batches_tracked]
+    return out
+
+
+class _KeepBNState:
+    """The eager warm-up pass in front of a capture runs the forward once more than the reference does for that batch
+    (warm-up, then the replay): the running estimates are put back behind it, so that the batch that triggers a
+    capture updates them ONCE (the replay), as every other batch does."""
+
+    def __init__(self, module):
+        self.bufs = _bn_buffers(module)
+
+    def __enter__(self):
+        self.saved = [b.clone() for b in self.bufs]
+        return self
+
+    def __exit__(self, *exc):
+        for b, s in zip(self.bufs, self.saved):
+            b.copy_(s)
+        return False
+
+
 SINK = os.environ.get('PDAE_GRAD_SINK', '1') != '0'
 WGRAD_SIDE = os.environ.get('PDAE_WGRAD_SIDE', '0') != '0'     # the stacks' weight gradients on a side stream (lab)
 _AVG_OK = {}
@@ -191,7 +219,7 @@ class GraphedTrainStep:
                 mask, enc.mask_ratio = draw_mask(self.B, self.G, enc.mask_ratio, enc.rand_ratio)
             else:
                 mask, _ = draw_mask(self.B, self.G, (self.G - tvis + 0.5) / self.G, 'False')
-            enc.num_mask = int(enc.mask_ratio * self.G)
+            enc.num_mask = int(enc.mask_ratio * self.G) if tvis is None else self.G - tvis
         n = steps.shape[0]
         slot = self.ring[self.slot]
         self.slot = (self.slot + 1) % self.RING
@@ -299,7 +327,7 @@ class GraphedTrainStep:
         self.model.require_sync = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                          # warm-up on a side stream (PyTorch recipe)
+        with torch.cuda.stream(side), _KeepBNState(self.net):  # warm-up on a side stream (PyTorch recipe)
             self._fwd_bwd(tvis)
         torch.cuda.current_stream().wait_stream(side)
         if self.pool is None:
@@ -444,7 +472,7 @@ class GraphedStaticStep:
             if self.graph is None:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side), _KeepBNState(self.model.module):
                     self._fwd_bwd()
                 torch.cuda.current_stream().wait_stream(side)
                 self.graph = torch.cuda.CUDAGraph()

@@ -507,12 +507,14 @@ def _rows_gemm_few_rows(x, w, w_kn, bias, epi, z=None):
     if splits == 1:
         return rows_gemm(x, w, w_kn, bias, epi, z)
     slabs = _empty((splits, M, N), x)
-    probed_family('rows_gemm', 2.0 * M * N * K,
-                  lambda: _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), None, 0, None,
-                                    _lib.ptr(slabs), cfg, splits, sb),
-                  nbytes=4.0 * (M * K + N * K + slabs.numel()))
     y = _empty((M, N), x)
-    _lib.call('pdae_slab_sum_epi', x, splits, M, N, _lib.ptr(slabs), _lib.ptr(bias), epi, _lib.ptr(z), _lib.ptr(y))
+
+    def both():                                     # the product is complete only behind the slab sum: one probed unit
+        _lib.call('pdae_rows_gemm', x, M, N, K, _lib.ptr(x), _lib.ptr(w), int(w_kn), None, 0, None,
+                  _lib.ptr(slabs), cfg, splits, sb)
+        _lib.call('pdae_slab_sum_epi', x, splits, M, N, _lib.ptr(slabs), _lib.ptr(bias), epi, _lib.ptr(z), _lib.ptr(y))
+    # bytes: operands + the slabs written by the GEMM, then the slabs read and the result written by the sum
+    probed_family('rows_gemm', 2.0 * M * N * K, both, nbytes=4.0 * (M * K + N * K + 2 * slabs.numel() + M * N))
     return y
 
 

@@ -1,0 +1,149 @@
+"""The gfx950 co-execution hazard of packed fp32 math (tools/xproc_repro.hip, INTEGRATION.md "Concurrent streams") under test.
+
+`v_pk_fma_f32 / v_pk_mul_f32 ... op_sel:[0,1,0]` return wrong low halves in lanes 16-31 while ANOTHER wave of the CU runs
+bf16 MFMAs interleaved with `ds_read_b128` -- another stream of the same process suffices.  The library is built
+`-fno-slp-vectorize` (tests/test_abi.py), which removes the compiler-made packed instructions; what remains packed BY HAND is
+the Chamfer forward (csrc/chamfer.hip: ext_vector_type(2) arithmetic in `chamfer_fwd_tiled` and `chamfer_fwd_many`, and the
+small-cloud `chamfer_fwd_packed`).  Here those kernels loop on one stream while `rows3::gemm3_kernel` -- the aggressor of the
+repro -- loops on another stream of this process, and every iteration is compared bit for bit with the solo run.
+
+A positive control keeps the detector honest: the repro's victim kernel, compiled WITH the SLP vectoriser (hipcc on the box),
+must come out damaged under the very same pairing; without that control a quiet pass would prove nothing."""
+import ctypes
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _aggressor(side, rounds=1):
+    """Enqueue `rounds` x 60 exact-split row GEMMs (2944 x 1152 x 384 and 8192 x 1536 x 384: 207 / 768 blocks of 8 waves,
+    122 KB of LDS) on `side`: ~2.5 ms of bf16 MFMAs + ds_read_b128 per round on every CU."""
+    from point_dae_amd import _lib, nn_ops
+    assert _lib.gemm_arith() == _lib.GEMM_BF16X3
+    st = _aggressor.__dict__.setdefault('state', {})
+    if not st:
+        g = torch.Generator(device='cuda').manual_seed(1)
+        st['a'] = torch.randn(2944, 384, device='cuda', generator=g)
+        st['w'] = torch.randn(1152, 384, device='cuda', generator=g)
+        st['a2'] = torch.randn(8192, 384, device='cuda', generator=g)
+        st['w2'] = torch.randn(1536, 384, device='cuda', generator=g)
+    with torch.cuda.stream(side):
+        for _ in range(rounds):
+            for _ in range(40):
+                nn_ops.rows_gemm(st['a'], st['w'])
+            for _ in range(20):
+                nn_ops.rows_gemm(st['a2'], st['w2'])
+
+
+CASES = [('tiled, 4 queries per lane (8 x 16384 x 1024)', 8, 16384, 1024, 600),
+         ('many candidates (8 x 1024 x 16384)', 8, 1024, 16384, 600),
+         ('square (16 x 1024 x 1024)', 16, 1024, 1024, 800),
+         ('packed small clouds (5248 x 32 x 32)', 5248, 32, 32, 1000)]
+
+
+@pytest.mark.parametrize('name,B,n,m,iters', CASES)
+def test_packed_chamfer_forward_is_bit_stable_beside_the_exact_split_gemm(name, B, n, m, iters):
+    from point_dae_amd import _lib
+    from point_dae_amd.graph_step import use_created_stream
+    main = use_created_stream()
+    side = torch.cuda.Stream()
+    g = torch.Generator(device='cuda').manual_seed(n + m)
+    a = torch.randn(B, n, 3, device='cuda', generator=g)
+    b = torch.randn(B, m, 3, device='cuda', generator=g)
+    d1, d2 = torch.empty(B, n, device='cuda'), torch.empty(B, m, device='cuda')
+    i1 = torch.empty(B, n, dtype=torch.int32, device='cuda')
+    i2 = torch.empty(B, m, dtype=torch.int32, device='cuda')
+
+    def run():
+        _lib.call('pdae_chamfer_forward', a, B, n, _lib.ptr(a), m, _lib.ptr(b), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2))
+    run()
+    torch.cuda.synchronize()
+    ref = (d1.clone(), d2.clone(), i1.clone(), i2.clone())
+    bad = torch.zeros((), dtype=torch.int64, device='cuda')
+    done = 0
+    per_round = 25
+    while done < iters:
+        _aggressor(side)                       # ~2.5 ms of GEMMs queued on the other stream ...
+        for _ in range(per_round):             # ... and the victims beside them
+            d1.fill_(-1.0), d2.fill_(-1.0)
+            run()
+            same = (d1 == ref[0]).all() & (d2 == ref[1]).all() & (i1 == ref[2]).all() & (i2 == ref[3]).all()
+            bad += (~same).to(torch.int64)
+        done += per_round
+        side.synchronize()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, '%s: %d of %d iterations differ from the solo run' % (name, int(bad), done)
+    assert main is not None
+
+
+_WRAP = r'''
+#define XPROC_NO_MAIN
+#include "%s"
+extern "C" int victim_launch(int R, int C4, const void* d, const void* x, void* part, void* stream) {
+  hipLaunchKernelGGL(victim_kernel, dim3(R / 1024), dim3(256), sizeof(float4) * 3 * 256, (hipStream_t)stream, R, C4,
+                     (const float4*)d, (const float*)x, (float4*)part);
+  return (int)hipGetLastError();
+}
+'''
+
+
+def test_the_pairing_does_damage_a_slp_packed_victim():
+    """Positive control: tools/xproc_repro.hip's victim reduction built WITH the SLP vectoriser (v_pk_fma_f32 with operand
+    selects) loses bits beside the same aggressor on another stream; built -fno-slp-vectorize -- how the library is built -- it
+    does not.  Skipped when the box has no hipcc."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    from point_dae_amd.graph_step import use_created_stream
+    use_created_stream()
+    side = torch.cuda.Stream()
+    tmp = tempfile.mkdtemp(prefix='pdae_hazard_')
+    try:
+        src = os.path.join(tmp, 'victim.hip')
+        with open(src, 'w') as f:
+            f.write(_WRAP % os.path.join(ROOT, 'tools', 'xproc_repro.hip'))
+        libs = {}
+        for tag, extra in (('slp', []), ('noslp', ['-fno-slp-vectorize'])):
+            out = os.path.join(tmp, 'victim_%s.so' % tag)
+            subprocess.check_call([hipcc, '-O3', '--offload-arch=gfx950', '-shared', '-fPIC'] + extra + [src, '-o', out],
+                                  stderr=subprocess.DEVNULL)
+            libs[tag] = ctypes.CDLL(out)
+            libs[tag].victim_launch.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+        R, C4 = 65536, 32
+        g = torch.Generator(device='cuda').manual_seed(3)
+        d = torch.rand(R * C4 * 4, device='cuda', generator=g) - 0.5
+        x = torch.rand(R * 3, device='cuda', generator=g) - 0.5
+        part = torch.empty(R // 1024 * 3 * C4 * 4, device='cuda')
+        counts = {}
+        for tag, lib in libs.items():
+            def run():
+                rc = lib.victim_launch(R, C4, d.data_ptr(), x.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+            run()
+            torch.cuda.synchronize()
+            ref = part.clone()
+            bad = torch.zeros((), dtype=torch.int64, device='cuda')
+            done = 0
+            while done < 600:
+                _aggressor(side)
+                for _ in range(30):
+                    part.fill_(0.0)
+                    run()
+                    bad += (~(part == ref).all()).to(torch.int64)
+                done += 30
+                side.synchronize()
+            torch.cuda.synchronize()
+            counts[tag] = int(bad)
+        assert counts['noslp'] == 0, counts
+        if counts['slp'] == 0:
+            pytest.skip('the SLP-packed victim came out clean on this box (%r): the hazard did not show, the detector is unproven '
+                        'here' % counts)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

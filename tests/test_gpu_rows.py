@@ -77,6 +77,28 @@ def test_rows_gemm_gelu_pair(M, N, K, cfg):
     _close(dz, zz.grad)
 
 
+@pytest.mark.parametrize('cfg', [0, -1])
+def test_gelu_pair_keeps_the_limits_at_plus_infinity(cfg):
+    """An fc1 output that overflowed to +inf leaves GELU = inf and GELU' = 1 (what erff / expf give and what nn.GELU's
+    autograd gives), not NaN in both (common.h gelu_pair_f).  The overflow enters through the bias, which the
+    epilogue adds behind the accumulation in either GEMM arithmetic."""
+    L = _lib()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    M, N, K = 256, 128, 64
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w1 = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    b1 = torch.randn(N, device='cuda', generator=g)
+    b1[3] = float('inf')
+    b1[5] = 3e38
+    gp = torch.full((M, N), float('nan'), device='cuda')
+    h = _gemm(L, x, w1, 0, b1, 2, gp, cfg, 1)[0]
+    assert torch.isposinf(h[:, 3]).all() and torch.equal(gp[:, 3], torch.ones(M, device='cuda'))
+    assert torch.equal(gp[:, 5], torch.ones(M, device='cuda')) and torch.isfinite(h[:, 5]).all()
+    keep = [c for c in range(N) if c not in (3, 5)]
+    zr = F.linear(x.double(), w1.double(), b1.double())[:, keep]
+    _close(h[:, keep], F.gelu(zr))
+
+
 @pytest.mark.parametrize('M,N,K', [(2944, 384, 1536), (1664, 384, 1152), (8192, 384, 1536), (100, 96, 384)])
 @pytest.mark.parametrize('w_kn', [0, 1])
 @pytest.mark.parametrize('splits', [2, 3, 4])

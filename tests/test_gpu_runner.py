@@ -258,6 +258,9 @@ def test_bn_momentum_schedule_recaptures_the_step_graphs():
         step(pts)
         assert any(not torch.equal(a, m.running_mean) for a, m in zip(before, bns))
     assert len(step.graphs) >= 1
+    # every step updates the running estimates ONCE, the steps that captured a graph included (the capture's eager
+    # warm-up pass is undone: graph_step._KeepBNState)
+    assert all(int(m.num_batches_tracked) == 6 for m in bns), [int(m.num_batches_tracked) for m in bns]
     for item in sch:
         if item is not None:
             item.step(1)
@@ -269,3 +272,4 @@ def test_bn_momentum_schedule_recaptures_the_step_graphs():
         for (mean, var), m in zip(before, bns):
             assert torch.equal(mean, m.running_mean) and torch.equal(var, m.running_var)
     assert len(step.graphs) >= 1
+    assert all(int(m.num_batches_tracked) == 12 for m in bns), [int(m.num_batches_tracked) for m in bns]
