@@ -39,7 +39,7 @@ constexpr int BK3 = 32;          // reduction depth of one staged tile (two 16-d
 #ifdef R3_STAMP
 #define R3_STAMP_AT(i)                                                                                              \
   if (threadIdx.x == 0) {                                                                                           \
-    unsigned long long* st_ = reinterpret_cast<unsigned long long*>(p.Z) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; \
+    unsigned long long* st_ = reinterpret_cast<unsigned long long*>(p.Z) + (size_t)(by * gx + bx) * 8; \
     st_[i] = __builtin_amdgcn_s_memrealtime(), st_[4 + (i)] = __builtin_amdgcn_s_memtime();                         \
   }
 #else
@@ -97,6 +97,18 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// A 32x32x16 operand fragment out of an image stored ACROSS the reduction ([k][column] bf16): two ds_read_b64_tr_b16, each
+// handing the lane four consecutive k of its column (cdna_hip_programming.md T10); p0 / p1 address rows 8 h .. 8 h + 3 and
+// 8 h + 4 .. 8 h + 7 of the 16-deep step.  EXEC must be all ones (every main loop here is branch-free).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // C[M,N] = epi(A[M,K] . op(B)), the contract of rows::rows_gemm_kernel (same Args, same epilogues, same split-K slab
 // form; its stream-K form is not built) for K % 32 == 0.  Block tile (32 TI WM) x (32 TJ WN), WM WN waves of TI x TJ MFMA tiles; an LDS
 // tile holds KS 16-deep steps of the reduction (KS = 2: 80-B rows; KS = 1: 48-B rows, half the LDS, so that TWO blocks
@@ -115,16 +127,29 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Fragments live in two register sets (the stage of a 16-deep step alternates), register sets and fragment stages are
 // indexed statically: the tile loop is unrolled by two.  The loop is branch-free: past the end the last tile is loaded
 // / split / stored again (into the buffer nobody reads).
+// The body of gemm3_kernel for block (bx, by, bz) of a grid gx blocks wide: the kernel below is this and nothing else; a
+// persistent caller (tools/lab/chain3_lab.hip) runs it for a (tile, slab) of its own choice.
 template <int TI, int TJ, int WM, int WN, int KS, bool BKN, int EPI, bool DUAL, int ABL = 0, bool PERS = false>
-__global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
+__device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const int by, const int bz, const int gx) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = 32 * TI * WM, BN = 32 * TJ * WN;
   constexpr int ROWB = KS == 2 ? 80 : 48;                     // bytes per LDS row: 16 KS bf16 + 16 B
   constexpr int BKT = 16 * KS;                                // reduction depth of an LDS tile
   constexpr int OPR = 2 * KS;                                 // octets (8 k) per row and tile
-  constexpr int PLANE = (BM + BN) * ROWB, BUF = 3 * PLANE;
+  // BKN (B stored [K, N], across the reduction: the weight of a data gradient), round 6: the B band is staged THE WAY IT LIES
+  // IN MEMORY -- octets of a k-ROW (eight consecutive columns, two 16-byte loads; was: 8 k x 1 column patches of 4-byte
+  // loads) into a natural [k][BN columns] image of RSB-byte rows, and its fragments are read transposed (tr_frag).  Image
+  // byte (k, c) = RSB k + ((2 c) ^ (SWZ(k & 3) << 6)): the four rows a 16-lane group reads land in different 64-byte
+  // quarters of the bank space (RSB = 256: quarter k & 3; RSB = 128 / 384: rows alternate halves already, quarter by k >> 1).
+  // Needs N % 4 == 0 (16-byte aligned rows; rows_gemm.hip gemm3_takes); same MFMA order: results bit-identical.
+  // Used where it pays: the 128-wide tiles (TJ = 2; 128 x 128: -3 % per launch in the step).  The 192-wide tile has no
+  // registers left for the three transposed-read bases (it spilled: +15 %) and the 64-wide one gained nothing: they keep
+  // the column patches (8 k x 1 column, 4-byte loads, a [column][32 k] image read with ds_read_b128).
+  constexpr bool TRB = BKN && TJ == 2 && KS == 2;
+  constexpr int RSB = 2 * BN;
+  constexpr int PLANE = TRB ? BM * ROWB + BKT * RSB : (BM + BN) * ROWB, BUF = 3 * PLANE;
   constexpr int OA = (BM * OPR + NT - 1) / NT;                // octets of A per thread and tile
-  constexpr int OB = (BN * OPR + NT - 1) / NT;                // octets of B (k-contiguous) / patches (8 k x 1 column)
+  constexpr int OB = (BN * OPR + NT - 1) / NT;                // octets of B: of a row (k-contiguous) / of a k-row (BKN)
   constexpr int G = TI * TJ;
   static_assert(BM % 8 == 0 && BN % 8 == 0, "staging map");
   extern __shared__ __attribute__((aligned(16))) char lds3[];
@@ -140,8 +165,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   // (the stream then keeps its buffer / register-set parity across tiles), else one block per tile.  blockIdx.y = the
   // split of the reduction (slabs the consumer adds).  (The fp32-input kernel's stream-K form is not built here.)
   const int chunk = (p.tiles + 7) >> 3;
-  const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
-  int slot = blockIdx.x >> 3;
+  const int xcd = bx & 7, nslots = gx >> 3;
+  int slot = bx >> 3;
   auto tile_of = [&](int sl) {
     const int t = xcd * chunk + sl;
     return (sl < chunk && t < p.tiles) ? t : -1;
@@ -153,14 +178,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   auto octet_row = [](int o) { return KS == 2 ? ((o >> 5) << 3) + (((o >> 2) & 1) << 2) + ((o >> 3) & 3)
                                               : ((o >> 4) << 3) + (((o >> 1) & 3) << 1) + ((o >> 3) & 1); };
   auto octet_col = [](int o) { return KS == 2 ? (o & 3) : (o & 1); };
-  const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk), piece = blockIdx.y;
+  const int kbeg = by * p.kchunk, kend = min(p.K, kbeg + p.kchunk), piece = by;
   const int KT = (kend - kbeg) / BKT;
   // 32-bit byte offsets of this thread's staged pieces from the (uniform) operand bases, [0] for the tile being
   // multiplied, [1] for the next one of this block; rows / columns past the matrix edge are clamped (their products
   // are never stored)
-  unsigned aoff[2][OA], boff[2][OB];
+  unsigned aoff[2][OA], boff[2][OB], boff2[2][TRB ? OB : 1];   // (boff2: the second 16 bytes of a row-staged B octet)
   int alds[OA], blds[OB];
-  auto offsets_of = [&](int t, unsigned (&ao)[OA], unsigned (&bo)[OB]) __attribute__((always_inline)) {
+  auto offsets_of = [&](int t, unsigned (&ao)[OA], unsigned (&bo)[OB], unsigned (&bo2)[TRB ? OB : 1]) __attribute__((always_inline)) {
     const int tm0 = (t / p.tiles_n) * BM, tn0 = (t % p.tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < OA; ++i) {
@@ -170,7 +195,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
 #pragma unroll
     for (int i = 0; i < OB; ++i) {
       const int o = (tid + i * NT) % (BN * OPR);
-      if (BKN) {
+      if (TRB) {
+        const int krow = o / (BN / 8), ch = o % (BN / 8);     // octet: columns 8 ch .. 8 ch + 7 of k-row krow
+        // (past the edge: the last whole octet again; N % 8 == 4: the last QUAD twice -- the columns past N are never stored)
+        const int c = min(tn0 + 8 * ch, (N & 7) ? N - 4 : N - 8);
+        bo[i] = ((unsigned)krow * (unsigned)p.ldb + (unsigned)c) * 4u;
+        bo2[i] = bo[i] + (c + 8 <= N ? 16u : 0u);
+      } else if (BKN) {
         const int kg = o / BN, col = o % BN;                  // patch: k = 8 kg .. 8 kg + 7 of column col
         bo[i] = ((unsigned)(8 * kg) * (unsigned)p.ldb + (unsigned)min(tn0 + col, N - 1)) * 4u;
       } else {
@@ -187,9 +218,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
 #pragma unroll
   for (int i = 0; i < OB; ++i) {
     const int o = (tid + i * NT) % (BN * OPR);
-    blds[i] = BKN ? (BM + o % BN) * ROWB + (o / BN) * 16 : (BM + octet_row(o)) * ROWB + octet_col(o) * 16;
+    const int krow = o / (BN / 8), ch = o % (BN / 8);
+    blds[i] = TRB ? BM * ROWB + krow * RSB + ((ch * 16) ^ ((BN == 128 ? (krow & 3) : ((krow >> 1) & 1)) << 6))
+              : BKN ? (BM + o % BN) * ROWB + (o / BN) * 16 : (BM + octet_row(o)) * ROWB + octet_col(o) * 16;
   }
-  offsets_of(tile, aoff[0], boff[0]);
+  offsets_of(tile, aoff[0], boff[0], boff2[0]);
   // PERS false (a launch of one tile per block: most of the Transformer blocks' GEMMs): no next tile, and none of its
   // registers or address selects in the loop
   int next = PERS ? tile_of(slot + nslots) : -1;
@@ -197,13 +230,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
   for (int i = 0; i < OA; ++i) aoff[1][i] = aoff[0][i];
 #pragma unroll
   for (int i = 0; i < OB; ++i) boff[1][i] = boff[0][i];
-  if (PERS && next >= 0) offsets_of(next, aoff[1], boff[1]);
+#pragma unroll
+  for (int i = 0; i < (TRB ? OB : 1); ++i) boff2[1][i] = boff2[0][i];
+  if (PERS && next >= 0) offsets_of(next, aoff[1], boff[1], boff2[1]);
   {
-    const char* Ab = reinterpret_cast<const char*>(p.A + (size_t)blockIdx.z * p.strideA) + (size_t)kbeg * 4;
-    const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)blockIdx.z * p.strideB) +
+    const char* Ab = reinterpret_cast<const char*>(p.A + (size_t)bz * p.strideA) + (size_t)kbeg * 4;
+    const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)bz * p.strideB) +
                      (BKN ? (size_t)kbeg * p.ldb * 4 : (size_t)kbeg * 4);
     const size_t bstep = BKN ? (size_t)p.ldb * 4 : 4;         // bytes per unit of k in B
     const unsigned ldb4 = (unsigned)p.ldb * 4u;
+    (void)ldb4;
 
     float ra[2][OA][8], rb[2][OB][8];                         // two register sets of staged fp32
     u32x4 pka[OA][3], pkb[OB][3];
@@ -232,12 +268,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       for (int i = 0; i < OB; ++i) {
         {
           const unsigned bo = nx ? boff[1][i] : boff[0][i];
-          if (BKN) {
+          if constexpr (BKN && !TRB) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) rb[set][i][q] = *reinterpret_cast<const float*>(Bk + bo + q * ldb4);
           } else {
+            // (TRB: the second half through its own offset -- an octet that ends at column N, N % 8 == 4, reads the first half
+            // twice; a block-uniform branch here made the compiler hoist the load out of both arms as four dword loads)
             const float4 v0 = *reinterpret_cast<const float4*>(Bk + bo);
-            const float4 v1 = *reinterpret_cast<const float4*>(Bk + bo + 16);
+            const float4 v1 = *reinterpret_cast<const float4*>(Bk + (TRB ? (nx ? boff2[1][TRB ? i : 0] : boff2[0][TRB ? i : 0]) : bo + 16));
             rb[set][i][0] = v0.x, rb[set][i][1] = v0.y, rb[set][i][2] = v0.z, rb[set][i][3] = v0.w;
             rb[set][i][4] = v1.x, rb[set][i][5] = v1.y, rb[set][i][6] = v1.z, rb[set][i][7] = v1.w;
           }
@@ -276,6 +314,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     f32x16 hi[TI][TJ], lo[TI][TJ];
     bf16x8 fa[2][TI][3], fb[2][TJ][3];                        // fragments: [stage][tile][plane]
     const int fa_off = (wm * TI * 32 + r) * ROWB + 16 * h, fb_off = (BM + wn * TJ * 32 + r) * ROWB + 16 * h;
+    // BKN: lane 4 q + p of a 16-lane group addresses k-row 8 h + q, columns 4 p .. 4 p + 3 of its 4 x 16 block of B tile T
+    int fbt_off[TJ];
+    {
+      const int lq = (lane >> 2) & 3, lp = lane & 3, lcb = (lane >> 4) & 1;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int T = wn * TJ + j;
+        fbt_off[j] = BM * ROWB + RSB * (8 * h + lq) + 64 * (T ^ (BN == 128 ? lq : (lq >> 1))) + 32 * lcb + 16 * (lp >> 1) + 8 * (lp & 1);
+      }
+    }
     constexpr int NF = 3 * (TI + TJ);                         // fragment reads of one 16-deep step
     // read f of a step, in the order the MFMAs want them: A0.l B0.h A0.h B0.l A0.m B0.m, then the other tiles
     auto frag_one = [&](auto f_c, auto st_c, int buf, int s16) __attribute__((always_inline)) {
@@ -285,8 +333,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
       constexpr int tl = f < 6 ? 0 : (isa ? 1 + (f - 6) / 3 : 1 + (f - 6 - 3 * (TI - 1)) / 3);
       constexpr int pl = f < 6 ? FPL[f] : (isa ? (f - 6) % 3 : (f - 6 - 3 * (TI - 1)) % 3);
       const char* base = lds3 + buf * BUF + s16 * 32 + pl * PLANE;
-      if constexpr (isa) fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
-      else fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
+      if constexpr (isa) {
+        fa[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fa_off + tl * 32 * ROWB);
+      } else if constexpr (TRB) {
+        const char* bt = lds3 + buf * BUF + pl * PLANE + s16 * (16 * RSB) + fbt_off[tl];
+        fb[st][tl][pl] = tr_frag(bt, bt + 4 * RSB);
+      } else {
+        fb[st][tl][pl] = *reinterpret_cast<const bf16x8*>(base + fb_off + tl * 32 * ROWB);
+      }
     };
     constexpr int S = 6 * G * KS;                             // slots (MFMAs) of a tile
     constexpr int NR = (NF + R3_FPS - 1) / R3_FPS;            // slots behind the barrier: R3_FPS fragment reads each
@@ -358,7 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     R3_STAMP_AT(2);
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    float* Cs = p.C + (size_t)blockIdx.z * p.strideC + (size_t)piece * p.slab;
+    float* Cs = p.C + (size_t)bz * p.strideC + (size_t)piece * p.slab;
     auto epilogue = [&](auto full_c, auto zero_c) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_c)::value;
       constexpr bool ZERO = decltype(zero_c)::value;
@@ -414,10 +468,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
     for (int i = 0; i < OA; ++i) aoff[0][i] = aoff[1][i];
 #pragma unroll
     for (int i = 0; i < OB; ++i) boff[0][i] = boff[1][i];
+#pragma unroll
+    for (int i = 0; i < (TRB ? OB : 1); ++i) boff2[0][i] = boff2[1][i];
     next = tile_of(slot + nslots);
-    if (next >= 0) offsets_of(next, aoff[1], boff[1]);
+    if (next >= 0) offsets_of(next, aoff[1], boff[1], boff2[1]);
     }   // tiles of this block
   }
+}
+
+template <int TI, int TJ, int WM, int WN, int KS, bool BKN, int EPI, bool DUAL, int ABL = 0, bool PERS = false>
+__global__ __launch_bounds__(WM * WN * 64) void gemm3_kernel(const Args p) {
+  gemm3_body<TI, TJ, WM, WN, KS, BKN, EPI, DUAL, ABL, PERS>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -663,14 +724,6 @@ __global__ __launch_bounds__(512) void wgrad3b_kernel(const rows::WgradArgs g) {
 // stores are eight consecutive 16-byte chunks of one row).  Same MFMA order as wgrad3b_kernel: dW is bit-identical; the
 // column sums (db) are added in a different order (a thread owns eight columns of one row, not one column of eight).
 // Needs N % 8 == 0, K % 8 == 0 and 16-byte aligned operands (the host falls back to wgrad3b_kernel otherwise).
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
-  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 template <bool FORMS>
 __global__ __launch_bounds__(512) void wgrad3t_kernel(const rows::WgradArgs g) {

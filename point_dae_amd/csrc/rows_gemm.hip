@@ -788,7 +788,7 @@ int gemm_arith_rows() { return arith_of(false); }
 }  // namespace pdae
 
 // shapes the exact-split kernels take: the reduction in whole 32-deep tiles (every layer of the models but the K = 3
-// / K = 4 ones), 32-bit byte offsets as the fp32 kernels
+// / K = 4 ones), 32-bit byte offsets as the fp32 kernels; a [K, N] weight is staged in octets of its rows (16-byte loads)
 static bool gemm3_takes(int N, int K, bool bkn) { return K % 32 == 0 && K >= 32 && (!bkn || N % 4 == 0); }
 
 // Plan of the exact-split family (cfg = CFG3_BASE + tile shape).  Cost in microseconds, calibrated on tools/lab/

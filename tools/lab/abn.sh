@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 VAR=$1; shift; ROUNDS=${ROUNDS:-2}; STEPS=${STEPS:-40}
 for round in $(seq 1 $ROUNDS); do
   for v in "$@"; do
-    line=$(env $VAR=$v python bench.py --no-cpu-baseline --no-also --no-tvis-table --probe-steps 0 --steps $STEPS --warmup 10 2>/dev/null | grep '"metric"' | tail -1)
+    line=$(env $VAR=$v python bench.py --no-cpu-baseline --no-also --no-tvis-table --no-calibration --probe-steps 0 --steps $STEPS --warmup 10 2>/dev/null | grep '"metric"' | tail -1)
     echo "$VAR=$v $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])' 2>/dev/null)"
   done
 done
