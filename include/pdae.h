@@ -723,6 +723,31 @@ int pdae_bnrelu_backward(int G, int C, float* dA, const float* X,
 /*   with groups / inv_group / dX: dA is compact (n_listed*32 rows, the listed
  *   groups; every other group's dA is zero), inv_group[g] = position of g in the
  *   list or -1, and the result for ALL G groups is written to dX.            */
+/* The data gradient that flows INTO such a BatchNorm + ReLU, with bnrelu_backward's sums out of the same launch
+ * (autograd of nn.Conv1d -> nn.BatchNorm1d -> nn.ReLU chains: models/PointCAE_transformer.py:26-35 Encoder,
+ * extensions/pointnet2/pointnet2_modules.py SharedMLP; the reference runs a cuDNN/cuBLAS product, then ATen's
+ * threshold_backward and batch_norm_backward sweeps over the (M, N) gradient):
+ *   rows_gemm_bnrelu_stats   T[M,N] = (X*scale+shift > 0) ? dY[M,K] . W[K,N] : 0 -- the ReLU mask applied while the
+ *       product tile is in registers -- and S[0][n] = sum_m T, S[1][n] = sum_m T xhat, xhat = (X-mean)*invstd.  X rows
+ *       through `groups` (row m of the product = row groups[m/32]*32 + m%32 of X; M % 32 == 0) when given.  workspace:
+ *       rows_gemm_bnrelu_stats_workspace(M, N) floats (one partial row of sums per 128-row band; added in band order
+ *       in fp64: no atomics, bit-identical run to run).  On the fp32-input arithmetic, or without a workspace, the
+ *       entry runs the plain product and bnrelu_backward's own reduction sweep.
+ *   bnrelu_backward_apply / bnrelu_backward_listed_apply   the second halves of bnrelu_backward / _listed for a caller
+ *       that holds S already: same arguments, S is read. */
+long long pdae_rows_gemm_bnrelu_stats_workspace(int M, int N);
+int pdae_rows_gemm_bnrelu_stats(int M, int N, int K, const float* dY, const float* W, const float* X,
+                                const int32_t* groups /*nullable*/, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, float* T, float* S, float* workspace,
+                                pdae_stream_t stream);
+int pdae_bnrelu_backward_apply(int G, int C, float* dA, const float* X, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* gamma, const float* S,
+                               float* gsum /*nullable*/, int n_listed, const int32_t* groups /*nullable*/,
+                               const int32_t* inv_group /*nullable*/, float* dX /*nullable*/, pdae_stream_t stream);
+int pdae_bnrelu_backward_listed_apply(int G, int C, float* dA, const float* X, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, const float* gamma, const float* S,
+                                      float* gsum, int gsum_by_group, float* uv, int n_listed, const int32_t* groups,
+                                      pdae_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Transformer block, Block.forward (models/PointCAE_transformer.py:155-158 with

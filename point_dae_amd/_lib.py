@@ -113,6 +113,9 @@ _SIGNATURES = {
     "pdae_edge_weight_unstack_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_edge_weight_unstack": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_cloud_pool_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_rows_gemm_bnrelu_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_backward_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "pdae_bnrelu_backward_listed_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "pdae_calib_mfma_bf16": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_calib_copy": [ctypes.c_longlong, _vp, _vp, _vp],
 }
@@ -137,6 +140,7 @@ _HOST = {
     "pdae_ctx_set_current": [_vp],
     "pdae_ctx_current": [],
     "pdae_cloud_pool_splits": [_i, _i],
+    "pdae_rows_gemm_bnrelu_stats_workspace": [_i, _i],
 }
 _STR = ("pdae_version", "pdae_last_error")
 

@@ -67,6 +67,10 @@ int det_reduce_f64(hipStream_t s, int P, int width, const double* part, double* 
 float* deferred_take(int P, int width, float* o0, int n0, float* o1, int n1, float* o2, int n2);
 bool deferred_on();
 int rows_wgrad_flush(hipStream_t s);   // rows_gemm.hip: the parked weight-gradient reductions
+// embed.hip: S[0][c] = sum_r t, S[1][c] = sum_r t xhat with t = relu'(bn(X)) ? dA : 0 over R rows (the reduction sweep of
+// pdae_bnrelu_backward; X rows through `groups` when given); S is overwritten
+int bnrelu_backward_sums(hipStream_t s, int R, int C, const float* dA, const float* X, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float* S, const int* groups);
 
 __device__ __forceinline__ void col_add(float* out, float* part, int partition, int width, int c, float t) {
   if (part) part[(size_t)partition * width + c] = t;

@@ -360,6 +360,67 @@ extern "C" int pdae_group_scatter_add(int G, int C, const float* grad, const uns
   return check_launch("group_scatter_add");
 }
 
+namespace pdae {
+int bnrelu_backward_sums(hipStream_t s, int Rsum, int C, const float* dA, const float* X, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, float* S, const int* groups) {
+  (void)hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)C, s);
+  if (Rsum <= 0) return check_launch("bnrelu_backward_sums");
+  int rows = 512;
+  int by = (Rsum + rows - 1) / rows;
+  if (by > 16384) {
+    rows = (Rsum + 16383) / 16384;
+    by = (Rsum + rows - 1) / rows;
+  }
+  int rc = PDAE_OK;
+  float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)by * 2 * C, &rc));
+  if (rc) return rc;
+  hipLaunchKernelGGL(bnrelu_backward_reduce_kernel, dim3((C / 4 + 31) / 32, by), dim3(256), 0, s, Rsum, C, dA, X, scale,
+                     shift, mean, invstd, S, rows, groups, det);
+  if (det && (rc = det_reduce(s, by, 2 * C, det, S, 2 * C))) return rc;
+  return check_launch("bnrelu_backward_sums");
+}
+}  // namespace pdae
+
+// The apply halves of pdae_bnrelu_backward / pdae_bnrelu_backward_listed for a caller that already holds the sums S (from
+// pdae_rows_gemm_bnrelu_stats: the data-gradient GEMM that produced dA left them): same arguments, S is an INPUT.  dA may
+// already carry the ReLU mask (the apply re-evaluates it: idempotent).
+extern "C" int pdae_bnrelu_backward_apply(int G, int C, float* dA, const float* X, const float* scale,
+                                          const float* shift, const float* mean, const float* invstd,
+                                          const float* gamma, const float* S, float* gsum, int n_listed,
+                                          const int32_t* groups, const int32_t* inv_group, float* dX,
+                                          pdae_stream_t stream) {
+  if (G < 0 || C <= 0 || C % 4 != 0) return bad_arg("bnrelu_backward_apply: C must be a positive multiple of 4");
+  if (G == 0) return PDAE_OK;
+  if (!dA || !X || !scale || !shift || !mean || !invstd || !gamma || !S) return bad_arg("bnrelu_backward_apply: null pointer");
+  if ((groups == nullptr) != (inv_group == nullptr) || (groups && !dX))
+    return bad_arg("bnrelu_backward_apply: groups, inv_group and dX go together");
+  if (!groups) dX = dA;
+  (void)n_listed;
+  hipLaunchKernelGGL(bnrelu_backward_apply_kernel, dim3((C / 4 + 31) / 32, (G + 7) / 8), dim3(256), 0, as_stream(stream),
+                     G, C, dA, X, scale, shift, mean, invstd, gamma, S, 1.0f / (float)(G * 32), gsum, inv_group, dX);
+  return check_launch("bnrelu_backward_apply");
+}
+
+extern "C" int pdae_bnrelu_backward_listed_apply(int G, int C, float* dA, const float* X, const float* scale,
+                                                 const float* shift, const float* mean, const float* invstd,
+                                                 const float* gamma, const float* S, float* gsum, int gsum_by_group,
+                                                 float* uv, int n_listed, const int32_t* groups, pdae_stream_t stream) {
+  if (G < 0 || n_listed < 0 || n_listed > G || C <= 0 || C % 4 != 0)
+    return bad_arg("bnrelu_backward_listed_apply: C must be a positive multiple of 4, n_listed <= G");
+  if (!S || !scale || !shift || !mean || !invstd || !gamma || (n_listed && (!dA || !X || !groups)))
+    return bad_arg("bnrelu_backward_listed_apply: null pointer");
+  hipStream_t s = as_stream(stream);
+  const float inv_rows = G > 0 ? 1.0f / (float)((long long)G * 32) : 0.f;
+  if (n_listed > 0)
+    hipLaunchKernelGGL(bnrelu_backward_apply_listed_kernel, dim3((C / 4 + 31) / 32, (n_listed + 7) / 8), dim3(256), 0,
+                       s, n_listed, C, dA, X, scale, shift, mean, invstd, gamma, const_cast<float*>(S), inv_rows, gsum, groups,
+                       gsum_by_group);
+  if (uv)
+    hipLaunchKernelGGL(bn_correction_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, S, inv_rows, gamma, mean,
+                       invstd, uv);
+  return check_launch("bnrelu_backward_listed_apply");
+}
+
 extern "C" int pdae_bnrelu_backward(int G, int C, float* dA, const float* X, const float* scale,
                                     const float* shift, const float* mean, const float* invstd,
                                     const float* gamma, float* S, float* gsum, int n_listed,

@@ -385,6 +385,10 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
     };
 
     R3_SETPRIO();
+    if constexpr (EPI == rows::EPI_BNRELU_STATS) {             // the block's running column sums (LDS, behind `red`)
+      float* accb = reinterpret_cast<float*>(lds3 + 2 * BUF) + WM * 2 * BN;
+      for (int c = tid; c < 2 * N; c += NT) accb[c] = 0.f;
+    }
     if (KT > 0) {
       gload_a(C0{}, 0);
       gload_b(C0{}, 0);
@@ -457,9 +461,83 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
         }
       }
     };
+    // EPI_BNRELU_STATS: t = relu'(bn(x)) ? acc : 0 stored; per column sum t and sum t xhat over the tile's rows: a lane's 16
+    // rows, its partner lane, then the WM waves of the column through LDS (`red`, behind the tile buffers: they already
+    // hold the next tile of a persistent block), added to the BLOCK's running sums (`accb` [2][N], LDS): one partial row
+    // per block leaves at its end, whatever the number of tiles it walked.  No atomics: the finishing pass adds the
+    // blocks' rows in order, in fp64.  (All of a tile's X values are requested before the first is used.)
+    auto epilogue_bn = [&](auto full_c) __attribute__((always_inline)) {
+      constexpr bool FULL = decltype(full_c)::value;
+      const unsigned ldc = (unsigned)p.ldc;
+      float* red = reinterpret_cast<float*>(lds3 + 2 * BUF);          // [WM][2][BN]
+      float* accb = red + WM * 2 * BN;                                // [2][N]
+      float zv[TJ][TI][16];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wn * TJ + j) * 32 + r;
+        const bool colok = FULL || col < N;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int rtile = m0 + (wm * TI + i) * 32;                  // (wave-uniform; M % 32 == 0 with a list)
+          int zrow0 = rtile;
+          if (p.z_groups) zrow0 = rtile < M ? __builtin_amdgcn_readfirstlane(p.z_groups[rtile >> 5]) * 32 : 0;
+          const size_t zoff = (size_t)(zrow0 + 4 * h) * ldc + col;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2);
+            zv[j][i][e] = (FULL || (colok && rtile + 4 * h + lr < M)) ? p.Z[zoff + (unsigned)lr * ldc] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wn * TJ + j) * 32 + r;
+        const bool colok = FULL || col < N;
+        const float sc = colok ? p.bn_scale[col] : 0.f, sh = colok ? p.bn_shift[col] : 0.f;
+        const float mu = colok ? p.bn_mean[col] : 0.f, is = colok ? p.bn_invstd[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int rbase = m0 + (wm * TI + i) * 32 + 4 * h;
+          const size_t off = (size_t)rbase * ldc + col;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2);
+            const bool in = FULL || (colok && rbase + lr < M);
+            const float v = hi[i][j][e] + lo[i][j][e];
+            const float t = (in && zv[j][i][e] * sc + sh > 0.f) ? v : 0.f;
+            if (in) R3_STORE(&Cs[off + (unsigned)lr * ldc], t);
+            s1 += t;
+            s2 += t * ((zv[j][i][e] - mu) * is);
+          }
+        }
+        s1 += __shfl_xor(s1, 32, kWave);
+        s2 += __shfl_xor(s2, 32, kWave);
+        if (h == 0) {
+          red[(wm * 2 + 0) * BN + (wn * TJ + j) * 32 + r] = s1;
+          red[(wm * 2 + 1) * BN + (wn * TJ + j) * 32 + r] = s2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int half = tid / BN, cc = tid - half * BN;
+        if (n0 + cc < N) {
+          float t = red[half * BN + cc];
+#pragma unroll
+          for (int k = 1; k < WM; ++k) t += red[(k * 2 + half) * BN + cc];
+          accb[half * N + n0 + cc] += t;               // (this thread owns the entry for every tile of these columns)
+        }
+      }
+      __syncthreads();                                  // red is written again by the next tile's epilogue
+    };
     const bool full = m0 + BM <= M && n0 + BN <= N;
-    if (full) epilogue(std::true_type{}, std::false_type{});
-    else epilogue(std::false_type{}, std::false_type{});
+    if constexpr (EPI == rows::EPI_BNRELU_STATS) {
+      if (full) epilogue_bn(std::true_type{});
+      else epilogue_bn(std::false_type{});
+    } else {
+      if (full) epilogue(std::true_type{}, std::false_type{});
+      else epilogue(std::false_type{}, std::false_type{});
+    }
     R3_STAMP_AT(3);
     if (!PERS || next < 0) break;
     slot += nslots;
@@ -473,6 +551,11 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
     next = tile_of(slot + nslots);
     if (next >= 0) offsets_of(next, aoff[1], boff[1], boff2[1]);
     }   // tiles of this block
+    if constexpr (EPI == rows::EPI_BNRELU_STATS) {             // one partial row of column sums per block
+      const float* accb = reinterpret_cast<const float*>(lds3 + 2 * BUF) + WM * 2 * BN;
+      __syncthreads();
+      for (int c = tid; c < 2 * N; c += NT) p.stats_part[(size_t)bx * 2 * N + c] = accb[c];
+    }
   }
 }
 

@@ -10,7 +10,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32, LD = BK + 4;   // LDS rows of 36 floats: ds_read_b128 of 16 lanes hits 64 banks
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_GELU2 = 2, EPI_MUL_GELUGRAD = 3, EPI_MUL_POS = 4 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_GELU2 = 2, EPI_MUL_GELUGRAD = 3, EPI_MUL_POS = 4,
+       // (exact-split family, [K,N] weights, 128 x 128 tiles: pdae_rows_gemm_bnrelu_stats) the data gradient that flows into a
+       // BatchNorm + ReLU: C = relu'(bn(X)) ? acc : 0 stored, and the two column sums BatchNorm's backward needs
+       // (sum t, sum t xhat) as one partial row per 128-row band of the product
+       EPI_BNRELU_STATS = 5 };
 
 struct Args {
   int M, N, K;
@@ -31,6 +35,12 @@ struct Args {
   long long strideA, strideB, strideC;   // batched launch: element strides between the problems of blockIdx.z
   int symmetric;      // fp32-input kernel, square tiles, A == B (Gram matrices): `tiles` counts the tiles on and above the
                       // diagonal; a block also stores its tile transposed below it
+  // EPI_BNRELU_STATS: Z = X, the BatchNorm's INPUT rows (leading dimension ldc; row m of the product = row
+  // z_groups[m / 32] * 32 + m % 32 of X when a list is given), its folded affine (scale, shift) and statistics, and
+  // stats_part [ceil(M / 128)][2][N]
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+  const int* z_groups;
+  float* stats_part;
 };
 
 constexpr int WG_MAX = 48;               // layers per launch: 12 Transformer blocks x 4 (the by-value struct is 3.1 KB)

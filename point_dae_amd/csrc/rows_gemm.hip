@@ -905,6 +905,79 @@ extern "C" int pdae_rows_gemm(int M, int N, int K, const float* X, const float* 
   return check_launch("rows_gemm");
 }
 
+// ---- data gradient into a BatchNorm + ReLU, with the sums of BatchNorm's backward out of the SAME launch (round 6) ----
+// T[M,N] = relu'(bn(X)) ? (dY[M,K] . W[K,N]) : 0,   S[0][n] = sum_m T[m][n],   S[1][n] = sum_m T[m][n] xhat[m][n]
+// The sweep that used to compute S re-read T and X (bnrelu_backward_reduce: 2 x 89 us of the cfg3 step, half of cfg2's 2.7
+// ms of BatchNorm backward): here the product tile is still in the accumulators when it is masked and summed
+// (gemm3_kernel, EPI_BNRELU_STATS: one partial row per 128-row band, no atomics), and a small pass adds the bands in order
+// in fp64.  On the fp32-input arithmetic (or a shape the exact-split family does not take) the entry runs the plain data
+// gradient and the old sweep: same results up to summation order.
+// S[c] = sum over the blocks that had tiles (grid of gx blocks, XCD-chunked tile order: block b owns tiles iff
+// (b & 7) * chunk + (b >> 3) < tiles and (b >> 3) < chunk) of their partial rows, in block order, fp64
+__global__ __launch_bounds__(1024) void bn_stats_finish_kernel(int gx, int tiles, int W2, const float* __restrict__ part,
+                                                                float* __restrict__ S) {
+  __shared__ double red[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int chunk = (tiles + 7) >> 3;
+  double t = 0.0;
+  if (c < W2)
+    for (int b = ph; b < gx; b += 16) {
+      const int sl = b >> 3, tl = (b & 7) * chunk + sl;
+      if (sl < chunk && tl < tiles) t += (double)part[(size_t)b * W2 + c];
+    }
+  red[ph][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (ph == 0 && c < W2) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][threadIdx.x & 63];
+    S[c] = (float)t;
+  }
+}
+
+// one partial row per block of the launch: at most one block per tile, at most one residency of the chip (+ the XCD padding)
+extern "C" long long pdae_rows_gemm_bnrelu_stats_workspace(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 63) / 64);
+  return (tiles + 8 < 1032 ? tiles + 8 : 1032) * 2 * N;
+}
+
+extern "C" int pdae_rows_gemm_bnrelu_stats(int M, int N, int K, const float* dY, const float* W, const float* X,
+                                           const int32_t* groups, const float* scale, const float* shift, const float* mean,
+                                           const float* invstd, float* T, float* S, float* workspace, pdae_stream_t stream) {
+  if (M < 0 || N <= 0 || K <= 0 || N % 4 != 0 || K % 4 != 0) return bad_arg("rows_gemm_bnrelu_stats: N, K positive multiples of 4");
+  if (!S) return bad_arg("rows_gemm_bnrelu_stats: null pointer");
+  hipStream_t s = as_stream(stream);
+  if (M == 0) {
+    (void)hipMemsetAsync(S, 0, sizeof(float) * 2 * (size_t)N, s);
+    return check_launch("rows_gemm_bnrelu_stats");
+  }
+  if (!dY || !W || !X || !scale || !shift || !mean || !invstd || !T) return bad_arg("rows_gemm_bnrelu_stats: null pointer");
+  if (groups && M % 32 != 0) return bad_arg("rows_gemm_bnrelu_stats: a group list needs M % 32 == 0");
+  if ((long long)M * (K > N ? K : N) >= (1LL << 30) || (long long)N * K >= (1LL << 30))
+    return unsupported("rows_gemm_bnrelu_stats: 32-bit byte offsets");
+  // the grid launch_cfg3 will choose: persistent (8 x 32 blocks) when the stream of LDS tiles keeps its parity, else one
+  // block per tile; 128 x 64 tiles for the narrow layers, 128 x 128 else (the two shapes that carry this epilogue)
+  const int c3 = N <= 64 ? 3 : 0, bn = N <= 64 ? 64 : 128;
+  const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn), chunk = (tiles + 7) / 8, kt = K / 32;
+  const bool pers = kt % 2 == 0 && kt >= 4 && chunk > 32;
+  // (one partial row per BLOCK: a one-tile-per-block launch of thousands of tiles would hand the finishing pass as
+  // many rows -- such a product takes the two-launch form)
+  if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, true) && workspace && N <= 2048 && (pers || tiles <= 1024)) {
+    Args a = {};
+    a.M = M, a.N = N, a.K = K, a.A = dY, a.lda = K, a.B = W, a.ldb = N, a.C = T, a.ldc = N;
+    a.Z = const_cast<float*>(X), a.slab = (long long)M * N;
+    a.bn_scale = scale, a.bn_shift = shift, a.bn_mean = mean, a.bn_invstd = invstd, a.z_groups = groups, a.stats_part = workspace;
+    rows3::launch_gemm3(a, c3, true, EPI_BNRELU_STATS, 1, 0, s);
+    const int gx = 8 * (pers ? 32 : chunk), W2 = 2 * N;
+    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((W2 + 63) / 64), dim3(1024), 0, s, gx, tiles, W2, workspace, S);
+    return check_launch("rows_gemm_bnrelu_stats");
+  }
+  // the two-launch form: plain data gradient, then the sums' own sweep (fp64 chains; deterministic mode: ordered partials)
+  int rc = pdae_rows_gemm(M, N, K, dY, W, 1, nullptr, EPI_STORE, nullptr, T, -1, 1, 0, stream);
+  if (rc) return rc;
+  return bnrelu_backward_sums(s, M, N, T, X, scale, shift, mean, invstd, S, groups);
+}
+
 // the widest tile every layer's K is a multiple of: 384 (the Transformer blocks: 384, 1536), 256 (FoldingNet, the
 // PointNet++ levels: 256, 512, 1024), else 128
 static int wgrad_tile_width(int nprob, const int* Ks) {

@@ -61,6 +61,26 @@ def _gemm(x, w, w_kn=False, bias=None):
     return y
 
 
+BN_FUSED = os.environ.get('PDAE_BN_FUSED', '1') != '0'     # (A/B: 0 = the data gradient and BatchNorm's sums as two launches)
+
+
+def _gemm_bnstats(dy, w, X, groups, sc, sh, mean, invstd):
+    """The data gradient dy . w (w (K, N) as stored: a conv / Linear weight (out, in)) that flows into relu(bn(X)), with the
+    ReLU mask applied and BatchNorm-backward's two column sums S (2, N) out of the same launch (csrc/rows_gemm.hip
+    pdae_rows_gemm_bnrelu_stats) -> (t, S).  X rows through `groups` (int32 list of 32-row groups) when given."""
+    M, K = dy.shape
+    N = w.shape[1]
+    t = _empty((M, N), dy)
+    S = _empty((2, N), dy)
+    ws = _empty((max(_lib.lib().pdae_rows_gemm_bnrelu_stats_workspace(M, N), 1),), dy) if BN_FUSED else None
+    probed_family('rows_gemm', 2.0 * M * N * K,
+                  lambda: _lib.call('pdae_rows_gemm_bnrelu_stats', dy, M, N, K, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(X),
+                                    _lib.ptr(groups), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(mean), _lib.ptr(invstd),
+                                    _lib.ptr(t), _lib.ptr(S), _lib.ptr(ws)),
+                  nbytes=4.0 * (M * K + N * K + 2 * M * N))
+    return t, S
+
+
 # the embedder's own weight gradients (group-listed operands, BatchNorm + ReLU recomputed) on the grouped kernel of
 # csrc/rows_gemm.hip (ordered reduction, no atomics, no memset); PDAE_EMBED_WGRAD=tn: round 1's gemm_tn kernels (A/B)
 WGRAD_ROWS = os.environ.get('PDAE_EMBED_WGRAD', 'rows') != 'tn'
@@ -210,7 +230,7 @@ class PatchEmbedFunction(torch.autograd.Function):
         return tok
 
     @staticmethod
-    def _masked_by_algebra(ctx, d3c, f, h3, sc2, sh2, mean2, is2, g2, wl, groups, BG):
+    def _masked_by_algebra(ctx, d3c, S2, f, h3, sc2, sh2, mean2, is2, g2, wl, groups, BG):
         """conv3 + BatchNorm-2 backward with the masked groups handled by algebra.  A group whose token is
         dropped sends no activation gradient into BatchNorm-2, so on its rows the conv-output gradient is the
         correction alone, dh_r = u + v * h_r, with h_r = f_r W^T + gb_g (W = the local half of conv3's weight):
@@ -224,8 +244,9 @@ class PatchEmbedFunction(torch.autograd.Function):
         masked, gb = ctx.masked, ctx.gb
         Gv, Gm = groups.numel(), masked.numel()
         Rv, Rm, R = Gv * 32, Gm * 32, BG * 32
-        S2, uv, dgb = _empty((2, c3), x), _empty((2, c3), x), _empty((BG, c3), x)
-        _lib.call('pdae_bnrelu_backward_listed', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+        uv, dgb = _empty((2, c3), x), _empty((BG, c3), x)
+        # (S2: BatchNorm-2's sums, left by the GEMM that produced d3c)
+        _lib.call('pdae_bnrelu_backward_listed_apply', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
                   _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), 1, _lib.ptr(uv), Gv,
                   _lib.ptr(groups))              # d3c <- dh of the visible rows; dgb[visible groups] <- their row sums
         u, v = uv[0], uv[1]
@@ -269,18 +290,18 @@ class PatchEmbedFunction(torch.autograd.Function):
         _lib.call('pdae_group_max_scatter', x, Gv, c4, _lib.ptr(dtok), _lib.ptr(arg4), _lib.ptr(dy4))
         db4 = _colsum(dtok)
         dw4, _ = _wgrad_listed(Rv, dy4, None, h3, groups, sc2, sh2)
-        d3c = _gemm(dy4, w4m, True)                               # (Rv, 512) grad of relu(bn2(h3)) rows
+        # (Rv, 512) grad of relu(bn2(h3)) rows, ReLU-masked, + BatchNorm-2's sums out of the same launch
+        d3c, S2 = _gemm_bnstats(dy4, w4m, h3, groups, sc2, sh2, mean2, is2)
         del dy4
         if ctx.algebra:
-            dwl, dgb, df, dbe2, dg2 = PatchEmbedFunction._masked_by_algebra(ctx, d3c, f, h3, sc2, sh2, mean2, is2, g2,
+            dwl, dgb, df, dbe2, dg2 = PatchEmbedFunction._masked_by_algebra(ctx, d3c, S2, f, h3, sc2, sh2, mean2, is2, g2,
                                                                              wl, groups, BG)
             del d3c
         else:
             # ---- ReLU + BN2 backward + per-group sums for the global half
-            S2 = _empty((2, c3), x)
             dgb = _empty((BG, c3), x)
             d3 = _empty((R, c3), x) if groups is not None else d3c
-            _lib.call('pdae_bnrelu_backward', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
+            _lib.call('pdae_bnrelu_backward_apply', x, BG, c3, _lib.ptr(d3c), _lib.ptr(h3), _lib.ptr(sc2), _lib.ptr(sh2),
                       _lib.ptr(mean2), _lib.ptr(is2), _lib.ptr(g2), _lib.ptr(S2), _lib.ptr(dgb), Gv,
                       _lib.ptr(groups), _lib.ptr(inv), _lib.ptr(d3) if groups is not None else None)
             del d3c
@@ -299,13 +320,12 @@ class PatchEmbedFunction(torch.autograd.Function):
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
         dw2, db2 = _wgrad_listed(R, df, None, y1, None, sc1, sh1, bias=True)    # db2: column sums of df, same kernel
-        d1 = _gemm(df, w2m, True)                                 # (R, 128)
+        d1, S1 = _gemm_bnstats(df, w2m, y1, None, sc1, sh1, mean1, is1)      # (R, 128), ReLU-masked, + BatchNorm-1's sums
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.update(df=df.clone(), d1_pre=d1.clone(), dw2=dw2.clone(), y1=y1.clone())
         del df
         # ---- ReLU + BN1 backward, conv1 (K = 3)
-        S1 = _empty((2, c1), x)
-        _lib.call('pdae_bnrelu_backward', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
+        _lib.call('pdae_bnrelu_backward_apply', x, BG, c1, _lib.ptr(d1), _lib.ptr(y1), _lib.ptr(sc1), _lib.ptr(sh1),
                   _lib.ptr(mean1), _lib.ptr(is1), _lib.ptr(g1), _lib.ptr(S1), None, BG, None, None, None)
         dbe1, dg1 = S1[0], S1[1]
         part1 = _empty((_lib.lib().pdae_embed_conv1_backward_weight_parts(R), 3, c1), x)

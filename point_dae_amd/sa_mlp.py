@@ -22,7 +22,7 @@ ATen ran ~7 passes per layer forward (stats, transform, clamp) and ~6 backward.
 import torch
 
 from . import _lib
-from .patch_embed import _bn_finalize, _empty, _gemm, _wgrad, _wgrad_listed
+from .patch_embed import _bn_finalize, _empty, _gemm, _gemm_bnstats, _wgrad, _wgrad_listed
 
 
 # Parity-test hook (None in production): called as ARG_HOOK(arg) with the (groups, C) uint8 winners of a level's
@@ -83,11 +83,16 @@ class SharedMLPMaxFunction(torch.autograd.Function):
         fused_pool = 256 % (C // 4) == 0 and C <= 1024
         if not fused_pool:
             _lib.call('pdae_group_max_scatter_n', x, G, ns, C, _lib.ptr(dout), _lib.ptr(arg), _lib.ptr(d))
+        S_pre = None                     # BatchNorm l's sums when the GEMM that produced d left them (rows_gemm_bnrelu_stats)
         for l in range(nl - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
             N = ws[l].shape[0]
-            S = _empty((2, N), x)
-            if l == nl - 1 and fused_pool:
+            S = _empty((2, N), x) if S_pre is None else S_pre
+            if S_pre is not None:
+                _lib.call('pdae_bnrelu_backward_apply', x, R // 32, N, _lib.ptr(d), _lib.ptr(ys[l]), _lib.ptr(sc),
+                          _lib.ptr(sh), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(gammas[l]), _lib.ptr(S), None,
+                          R // 32, None, None, None)
+            elif l == nl - 1 and fused_pool:
                 # straight through the max-pool: the gradient is non-zero only at the arg-max rows
                 wsp = _empty((max(_lib.lib().pdae_pool_bn_backward_workspace(G, C), 1),), x)
                 _lib.call('pdae_pool_bn_backward', x, G, ns, C, _lib.ptr(dout), _lib.ptr(arg), _lib.ptr(out),
@@ -104,7 +109,8 @@ class SharedMLPMaxFunction(torch.autograd.Function):
                 K = ws[l].shape[1]
                 # BatchNorm + ReLU of the previous layer recomputed while its raw output is staged (patch_embed._wgrad_listed)
                 grads[3 * l] = _wgrad_listed(R, d, None, ys[l - 1], None, psc, psh)[0]
-                d = _gemm(d, ws[l], True)                                        # gradient of relu(bn(y_{l-1}))
+                # gradient of relu(bn(y_{l-1})), ReLU-masked, + that BatchNorm's sums out of the same launch
+                d, S_pre = _gemm_bnstats(d, ws[l], ys[l - 1], None, psc, psh, affs[l - 1][2], affs[l - 1][3])
             else:
                 grads[0] = _wgrad(d, x)
                 if ctx.needs_input_grad[0]:

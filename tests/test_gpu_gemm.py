@@ -363,3 +363,62 @@ def test_conv1_backward_weight(R, C):
     part2 = torch.empty_like(part)
     L.call('pdae_embed_conv1_backward_weight', d, R, C, d.data_ptr(), x.data_ptr(), part2.data_ptr())
     assert torch.equal(part, part2)
+
+
+@pytest.mark.parametrize('M,N,K,listed', [(69632, 512, 384, True), (8192, 128, 256, False), (4000, 260, 256, False),
+                                          (4096, 64, 128, True), (352, 512, 384, True)])
+@pytest.mark.parametrize('arith', [1, 0])
+def test_data_gradient_with_batchnorm_backward_sums(M, N, K, listed, arith):
+    """pdae_rows_gemm_bnrelu_stats: T = relu'(bn(X)) ? dY . W : 0 and S = (sum T, sum T xhat) out of ONE launch on the
+    exact-split arithmetic (gemm3_kernel's EPI_BNRELU_STATS epilogue + the ordered fp64 finish), the two-launch form on the
+    fp32-input arithmetic -- against the fp64 composition; X rows through a group list; ragged M and N; run to run
+    bit-identical (no atomics on the fused path)."""
+    from point_dae_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    prev = _lib.gemm_arith()
+    _lib.set_gemm_arith(arith)
+    try:
+        dy = torch.randn(M, K, device='cuda', generator=g)
+        w = torch.randn(K, N, device='cuda', generator=g) / K ** 0.5
+        groups = None
+        if listed:
+            G = M // 32
+            perm = torch.randperm(2 * G, device='cuda', generator=g)[:G].sort().values.to(torch.int32)
+            X = torch.randn(2 * G * 32, N, device='cuda', generator=g)
+            groups = perm
+            xr = X.view(2 * G, 32, N)[perm.long()].reshape(M, N)
+        else:
+            X = torch.randn(M, N, device='cuda', generator=g)
+            xr = X
+        gamma = torch.rand(N, device='cuda', generator=g) + 0.5
+        beta = torch.randn(N, device='cuda', generator=g) * 0.3
+        mean, var = X.mean(0), X.var(0, unbiased=False)
+        invstd = (var + 1e-5).rsqrt()
+        scale = (gamma * invstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+
+        def run():
+            t = torch.full((M, N), float('nan'), device='cuda')
+            S = torch.full((2, N), float('nan'), device='cuda')
+            ws = torch.empty(max(_lib.lib().pdae_rows_gemm_bnrelu_stats_workspace(M, N), 1), device='cuda')
+            _lib.call('pdae_rows_gemm_bnrelu_stats', dy, M, N, K, _lib.ptr(dy), _lib.ptr(w), _lib.ptr(X), _lib.ptr(groups),
+                      _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(t), _lib.ptr(S), _lib.ptr(ws))
+            return t, S
+        t, S = run()
+        prod = dy.double() @ w.double()
+        on = (xr * scale + shift) > 0
+        t_ref = torch.where(on, prod, torch.zeros_like(prod))
+        tm = torch.where(on, t.double(), torch.zeros_like(prod))             # (the two-launch form leaves T unmasked)
+        assert (tm - t_ref).abs().max().item() <= 2e-5 * prod.abs().max().item()
+        if arith == 1:
+            assert torch.equal(t.double(), tm)                               # masked elements are exact zeros already
+        xhat = (xr.double() - mean.double()) * invstd.double()
+        S_ref = torch.stack([tm.sum(0), (tm * xhat).sum(0)])
+        scale_s = S_ref.abs().max().item() + 1e-12
+        assert (S.double() - S_ref).abs().max().item() <= 2e-5 * scale_s, (S.double() - S_ref).abs().max().item() / scale_s
+        t2, S2 = run()
+        assert torch.equal(t, t2)
+        if arith == 1:
+            assert torch.equal(S, S2)
+    finally:
+        _lib.set_gemm_arith(prev)
