@@ -23,6 +23,8 @@
 //             are recomputed from Q, K, V, dO and the saved log-sum-exp -- four
 //             64-deep products -- instead of transposing through LDS.
 // One wave per 32-row tile of queries (keys in the backward's second half).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pdae {
@@ -309,7 +311,31 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(int T, int H, float 
 
 }  // namespace pdae
 
+namespace pdae {
+int gemm_arith_rows();     // rows_gemm.hip: the arithmetic in force for the dense layers
+// attention3.hip: the same contract on the exact-split bf16 pipe, for 32 < T <= 64
+int attention3_forward(int B, int T, int H, float scale, const float* qkv, float* o, float* lse, hipStream_t s);
+int attention3_backward(int B, int T, int H, float scale, const float* qkv, const float* o, const float* lse, const float* d_o,
+                        float* dqkv, hipStream_t s);
+}  // namespace pdae
+
 using namespace pdae;
+
+// The exact-split kernels take the two-tile sequences when the library's GEMM arithmetic is the exact-split one
+// (pdae_set_gemm_arith / PDAE_GEMM).  Measured at the decoder's size (B = 128, T = 64, H = 6; tools/lab/attn_time.py): the
+// forward 16.0 us against the fp32-input kernel's 19.9: it ships.  The backward 49.7 (two tensors of planes per block,
+// parts as separate blocks) / 46.8 (all four, one block) against 46.2: its blocks are one serial chain -- loads, ~1000
+// split instructions, 190 MFMAs with their fragment reads, two exponential sweeps, stores: ~10 us per block of which the
+// matrix pipe is 2.6 -- at 424 registers, one wave per SIMD: nothing overlaps it.  It stays in the library behind
+// PDAE_ATTN=b3 (lab); PDAE_ATTN=f32 keeps the fp32-input kernels everywhere (A/B runs).
+static bool attn3_takes(int T, bool backward) {
+  static const int mode = [] {
+    const char* e = getenv("PDAE_ATTN");
+    return !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 'b' ? 2 : 0));
+  }();
+  if (mode == 1 || (backward && mode != 2)) return false;
+  return T > 32 && T <= 64 && gemm_arith_rows() == PDAE_GEMM_BF16X3;
+}
 
 static int attn_check(int B, int T, int H, int D) {
   if (B < 0 || T <= 0 || H <= 0) return bad_arg("attention: bad size");
@@ -325,6 +351,7 @@ extern "C" int pdae_attention_forward(int B, int T, int H, int D, float scale, c
   if (rc) return rc;
   if (B == 0) return PDAE_OK;
   if (!qkv || !o || !lse) return bad_arg("attention_forward: null pointer");
+  if (attn3_takes(T, false)) return attention3_forward(B, T, H, scale, qkv, o, lse, as_stream(stream));
   const int NW = (T + 31) / 32;
   const size_t lds = (size_t)3 * NW * 32 * ALD * sizeof(float);
   static bool once = false;
@@ -345,6 +372,7 @@ extern "C" int pdae_attention_backward(int B, int T, int H, int D, float scale, 
   if (rc) return rc;
   if (B == 0) return PDAE_OK;
   if (!qkv || !o || !lse || !d_o || !dqkv) return bad_arg("attention_backward: null pointer");
+  if (attn3_takes(T, true)) return attention3_backward(B, T, H, scale, qkv, o, lse, d_o, dqkv, as_stream(stream));
   const int NW = (T + 31) / 32;
   const size_t lds = ((size_t)4 * NW * 32 * ALD + 2 * NW * 32) * sizeof(float);
   static bool once = false;

@@ -13,7 +13,8 @@ def _close(a, b, tol):
     assert err <= tol, err
 
 
-@pytest.mark.parametrize('B,T,H', [(128, 23, 6), (64, 64, 6), (8, 13, 6), (5, 32, 2), (3, 100, 6), (2, 128, 6), (7, 1, 3)])
+@pytest.mark.parametrize('B,T,H', [(128, 23, 6), (64, 64, 6), (8, 13, 6), (5, 32, 2), (3, 100, 6), (2, 128, 6), (7, 1, 3),
+                                   (16, 47, 6), (4, 33, 2), (128, 64, 6), (9, 63, 3)])
 def test_attention_forward_backward(B, T, H):
     from point_dae_amd import nn_ops
     D, scale = 64, 64 ** -0.5
