@@ -408,6 +408,30 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) hi[i][j][e] = 0.f, lo[i][j][e] = 0.f;
+    // EPI_BNRELU_STATS: the tile's BatchNorm inputs X are requested HERE, ahead of the k-loop: they travel behind the two
+    // k-tiles of operand loads already in flight and are in registers long before the epilogue wants them (requested in
+    // the epilogue they were a cold HBM round trip per tile: 186 against 145 us per launch of the plain data gradient)
+    float zv[EPI == rows::EPI_BNRELU_STATS ? TJ : 1][EPI == rows::EPI_BNRELU_STATS ? TI : 1][16];
+    if constexpr (EPI == rows::EPI_BNRELU_STATS) {
+      const unsigned ldz = (unsigned)p.ldc;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wn * TJ + j) * 32 + r;
+        const bool colok = col < N;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int rtile = m0 + (wm * TI + i) * 32;                  // (wave-uniform; M % 32 == 0 with a list)
+          int zrow0 = rtile;
+          if (p.z_groups) zrow0 = rtile < M ? __builtin_amdgcn_readfirstlane(p.z_groups[rtile >> 5]) * 32 : 0;
+          const size_t zoff = (size_t)(zrow0 + 4 * h) * ldz + col;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int lr = (e & 3) + 8 * (e >> 2);
+            zv[j][i][e] = (colok && rtile + 4 * h + lr < M) ? p.Z[zoff + (unsigned)lr * ldz] : 0.f;
+          }
+        }
+      }
+    }
     R3_STAMP_AT(1);
     for (int kt = 0; kt < KT; kt += 2) {
       ktile(C0{}, kt);
@@ -465,30 +489,12 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
     // rows, its partner lane, then the WM waves of the column through LDS (`red`, behind the tile buffers: they already
     // hold the next tile of a persistent block), added to the BLOCK's running sums (`accb` [2][N], LDS): one partial row
     // per block leaves at its end, whatever the number of tiles it walked.  No atomics: the finishing pass adds the
-    // blocks' rows in order, in fp64.  (All of a tile's X values are requested before the first is used.)
+    // blocks' rows in order, in fp64.  (The tile's X values were requested ahead of the k-loop.)
     auto epilogue_bn = [&](auto full_c) __attribute__((always_inline)) {
       constexpr bool FULL = decltype(full_c)::value;
       const unsigned ldc = (unsigned)p.ldc;
       float* red = reinterpret_cast<float*>(lds3 + 2 * BUF);          // [WM][2][BN]
       float* accb = red + WM * 2 * BN;                                // [2][N]
-      float zv[TJ][TI][16];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int col = n0 + (wn * TJ + j) * 32 + r;
-        const bool colok = FULL || col < N;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          const int rtile = m0 + (wm * TI + i) * 32;                  // (wave-uniform; M % 32 == 0 with a list)
-          int zrow0 = rtile;
-          if (p.z_groups) zrow0 = rtile < M ? __builtin_amdgcn_readfirstlane(p.z_groups[rtile >> 5]) * 32 : 0;
-          const size_t zoff = (size_t)(zrow0 + 4 * h) * ldc + col;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int lr = (e & 3) + 8 * (e >> 2);
-            zv[j][i][e] = (FULL || (colok && rtile + 4 * h + lr < M)) ? p.Z[zoff + (unsigned)lr * ldc] : 0.f;
-          }
-        }
-      }
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int col = n0 + (wn * TJ + j) * 32 + r;

@@ -26,7 +26,7 @@ def _aggressor(side, rounds=1):
     """Enqueue `rounds` x 60 exact-split row GEMMs (2944 x 1152 x 384 and 8192 x 1536 x 384: 207 / 768 blocks of 8 waves,
     122 KB of LDS) on `side`: ~2.5 ms of bf16 MFMAs + ds_read_b128 per round on every CU."""
     from point_dae_amd import _lib, nn_ops
-    assert _lib.gemm_arith() == _lib.GEMM_BF16X3
+    assert _lib.gemm_arith() == _lib.GEMM_BF16X3          # (the callers select it: the aggressor IS the exact-split GEMM)
     st = _aggressor.__dict__.setdefault('state', {})
     if not st:
         g = torch.Generator(device='cuda').manual_seed(1)
@@ -54,6 +54,8 @@ def test_packed_chamfer_forward_is_bit_stable_beside_the_exact_split_gemm(name, 
     from point_dae_amd.graph_step import use_created_stream
     main = use_created_stream()
     side = torch.cuda.Stream()
+    prev = _lib.gemm_arith()
+    _lib.set_gemm_arith(_lib.GEMM_BF16X3)                  # (whatever PDAE_GEMM says: the hazard needs the bf16 MFMA loop)
     g = torch.Generator(device='cuda').manual_seed(n + m)
     a = torch.randn(B, n, 3, device='cuda', generator=g)
     b = torch.randn(B, m, 3, device='cuda', generator=g)
@@ -79,6 +81,7 @@ def test_packed_chamfer_forward_is_bit_stable_beside_the_exact_split_gemm(name, 
         done += per_round
         side.synchronize()
     torch.cuda.synchronize()
+    _lib.set_gemm_arith(prev)
     assert int(bad) == 0, '%s: %d of %d iterations differ from the solo run' % (name, int(bad), done)
     assert main is not None
 
@@ -101,9 +104,12 @@ def test_the_pairing_does_damage_a_slp_packed_victim():
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('no hipcc on this box')
+    from point_dae_amd import _lib
     from point_dae_amd.graph_step import use_created_stream
     use_created_stream()
     side = torch.cuda.Stream()
+    prev = _lib.gemm_arith()
+    _lib.set_gemm_arith(_lib.GEMM_BF16X3)
     tmp = tempfile.mkdtemp(prefix='pdae_hazard_')
     try:
         src = os.path.join(tmp, 'victim.hip')
@@ -146,4 +152,5 @@ def test_the_pairing_does_damage_a_slp_packed_victim():
             pytest.skip('the SLP-packed victim came out clean on this box (%r): the hazard did not show, the detector is unproven '
                         'here' % counts)
     finally:
+        _lib.set_gemm_arith(prev)
         shutil.rmtree(tmp, ignore_errors=True)
