@@ -415,7 +415,7 @@ def dominant_roofline(per_tvis, G, bf16x3):
             'algorithmic_bytes': gbytes * 1e9,
             'algorithmic_bytes_note': 'per step: every operand and every result of every launch of the two families once, 4 B per '
                                       'element (M K + N K + slabs M N per product, M (N + K) + N K per weight gradient: DESIGN.md 4b)',
-            'kernel': 'pdae::rows3::gemm3_kernel + pdae::rows3::wgrad3b_kernel (+ wgrad_reduce_kernel): the row-GEMM family' if bf16x3
+            'kernel': 'pdae::rows3::gemm3_kernel + pdae::rows3::wgrad3t_kernel (+ wgrad_reduce_kernel): the row-GEMM family' if bf16x3
                       else 'pdae::rows::rows_gemm_kernel + pdae::rows::wgrad_kernel (+ wgrad_reduce_kernel): the row-GEMM family',
             'ms_per_step': ms, 'gflop_per_step': gflop,
             'frac_of_f32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS, 'families': rows,
@@ -481,7 +481,7 @@ def cfg2_leg(args, device, rank):
         probe.calls = {}
         keys = [k for k in ('rows_gemm', 'rows_wgrad') if k in fam and k in rep]
         gf, ms = sum(fam[k]['flops'] for k in keys) / 1e9, sum(rep[k] for k in keys)
-        gemm_roof = {'kernel': 'rows3::gemm3_kernel + rows3::wgrad3b_kernel (row-GEMM family of the cfg2 step)', 'bound': 'mfma',
+        gemm_roof = {'kernel': 'rows3::gemm3_kernel + rows3::wgrad3t_kernel (row-GEMM family of the cfg2 step)', 'bound': 'mfma',
                      'gflop_per_step': gf, 'ms_per_step': ms, 'achieved': gf / ms, 'peak': BF16X3_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': gf / ms / BF16X3_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': gf / ms / MFMA_F32_PEAK_TFLOPS,
                      'algorithmic_bytes': sum(fam[k]['bytes'] for k in keys),

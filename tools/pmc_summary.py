@@ -3,7 +3,7 @@ runs: they do not fit one pass on gfx950).
 usage: pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [kernel_summary.txt]  -> JSON on stdout.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced reads ->
 doubled.  Units: KiB.  With the kernel summary of the same command (tools/trace_summary.py: calls per step) the bytes of
-the row-GEMM families (gemm3 / wgrad3b / wgrad_reduce, or their fp32-input twins) are also summed per STEP:
+the row-GEMM families (gemm3 / wgrad3t / wgrad3b / wgrad_reduce, or their fp32-input twins) are also summed per STEP:
 `rows_families_hbm_bytes_per_step`, the `traffic` of bench.py's roofline."""
 import csv
 import glob
@@ -45,7 +45,7 @@ if len(sys.argv) > 3:
         m = re.match(r'\s*[\d.]+%\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)$', ln)
         if m:
             calls[short(m.group(4).strip())] = float(m.group(2))
-    fam = [k for k in res if re.search(r'rows3::gemm3_kernel|rows3::wgrad3b_kernel|rows::wgrad_reduce_kernel|rows::rows_gemm_kernel|rows::wgrad_kernel', k)]
+    fam = [k for k in res if re.search(r'rows3::gemm3_kernel|rows3::wgrad3b_kernel|rows3::wgrad3t_kernel|rows::wgrad_reduce_kernel|rows::rows_gemm_kernel|rows::wgrad_kernel', k)]
     total, detail = 0.0, {}
     for k in fam:
         c = calls.get(k)
