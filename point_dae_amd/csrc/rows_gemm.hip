@@ -935,10 +935,33 @@ __global__ __launch_bounds__(1024) void bn_stats_finish_kernel(int gx, int tiles
 }
 
 // one partial row per block of the launch: at most one block per tile, at most one residency of the chip (+ the XCD padding)
+// first level of the finishing pass for launches of thousands of one-tile blocks (a reduction too short for persistent
+// blocks: K = 64): block (x, y) adds rows [256 y, 256 y + 256) of the blocks that had tiles, in order, fp64 -> mid[y][c]
+__global__ __launch_bounds__(1024) void bn_stats_finish1_kernel(int gx, int tiles, int W2, const float* __restrict__ part,
+                                                                 float* __restrict__ mid) {
+  __shared__ double red[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int chunk = (tiles + 7) >> 3, b0 = blockIdx.y * 256, b1 = min(gx, b0 + 256);
+  double t = 0.0;
+  if (c < W2)
+    for (int b = b0 + ph; b < b1; b += 16) {
+      const int sl = b >> 3, tl = (b & 7) * chunk + sl;
+      if (sl < chunk && tl < tiles) t += (double)part[(size_t)b * W2 + c];
+    }
+  red[ph][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (ph == 0 && c < W2) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][threadIdx.x & 63];
+    mid[(size_t)blockIdx.y * W2 + c] = (float)t;
+  }
+}
+
+// one partial row per block of the launch (at most one block per tile) + the first-level sums of the two-level finish
 extern "C" long long pdae_rows_gemm_bnrelu_stats_workspace(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  const long long tiles = (long long)((M + 127) / 128) * ((N + 63) / 64);
-  return (tiles + 8 < 1032 ? tiles + 8 : 1032) * 2 * N;
+  const long long rows = (long long)((M + 127) / 128) * ((N + 63) / 64) + 8;
+  return (rows + (rows + 255) / 256) * 2 * N;
 }
 
 extern "C" int pdae_rows_gemm_bnrelu_stats(int M, int N, int K, const float* dY, const float* W, const float* X,
@@ -960,16 +983,24 @@ extern "C" int pdae_rows_gemm_bnrelu_stats(int M, int N, int K, const float* dY,
   const int c3 = N <= 64 ? 3 : 0, bn = N <= 64 ? 64 : 128;
   const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn), chunk = (tiles + 7) / 8, kt = K / 32;
   const bool pers = kt % 2 == 0 && kt >= 4 && chunk > 32;
-  // (one partial row per BLOCK: a one-tile-per-block launch of thousands of tiles would hand the finishing pass as
-  // many rows -- such a product takes the two-launch form)
-  if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, true) && workspace && N <= 2048 && (pers || tiles <= 1024)) {
+  // (one partial row per BLOCK; a one-tile-per-block launch of thousands of tiles -- a reduction too short for the
+  // persistent form -- hands the finishing pass as many rows: it then runs in two levels)
+  if (arith_of(false) == PDAE_GEMM_BF16X3 && gemm3_takes(N, K, true) && workspace && N <= 2048) {
     Args a = {};
     a.M = M, a.N = N, a.K = K, a.A = dY, a.lda = K, a.B = W, a.ldb = N, a.C = T, a.ldc = N;
     a.Z = const_cast<float*>(X), a.slab = (long long)M * N;
     a.bn_scale = scale, a.bn_shift = shift, a.bn_mean = mean, a.bn_invstd = invstd, a.z_groups = groups, a.stats_part = workspace;
     rows3::launch_gemm3(a, c3, true, EPI_BNRELU_STATS, 1, 0, s);
     const int gx = 8 * (pers ? 32 : chunk), W2 = 2 * N;
-    hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((W2 + 63) / 64), dim3(1024), 0, s, gx, tiles, W2, workspace, S);
+    if (gx > 1024) {
+      const int P = (gx + 255) / 256;
+      float* mid = workspace + (size_t)gx * W2;
+      hipLaunchKernelGGL(bn_stats_finish1_kernel, dim3((W2 + 63) / 64, P), dim3(1024), 0, s, gx, tiles, W2, workspace, mid);
+      // (every row of `mid` counts: tiles = 8 P makes the second level's tile test pass for rows 0 .. P - 1)
+      hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((W2 + 63) / 64), dim3(1024), 0, s, P, 8 * P, W2, mid, S);
+    } else {
+      hipLaunchKernelGGL(bn_stats_finish_kernel, dim3((W2 + 63) / 64), dim3(1024), 0, s, gx, tiles, W2, workspace, S);
+    }
     return check_launch("rows_gemm_bnrelu_stats");
   }
   // the two-launch form: plain data gradient, then the sums' own sweep (fp64 chains; deterministic mode: ordered partials)

@@ -366,7 +366,7 @@ def test_conv1_backward_weight(R, C):
 
 
 @pytest.mark.parametrize('M,N,K,listed', [(69632, 512, 384, True), (8192, 128, 256, False), (4000, 260, 256, False),
-                                          (4096, 64, 128, True), (352, 512, 384, True)])
+                                          (4096, 64, 128, True), (352, 512, 384, True), (140000, 64, 64, False)])
 @pytest.mark.parametrize('arith', [1, 0])
 def test_data_gradient_with_batchnorm_backward_sums(M, N, K, listed, arith):
     """pdae_rows_gemm_bnrelu_stats: T = relu'(bn(X)) ? dY . W : 0 and S = (sum T, sum T xhat) out of ONE launch on the

@@ -8,7 +8,7 @@ import os
 import re
 import sys
 
-WANT = re.compile(r'rows3::wgrad3b_kernel|rows3::gemm3_kernel<1, 2, 4, 2, 2, (true|false), \d, true, 0, true>|rows3::conv3_kernel')
+WANT = re.compile(r'rows3::wgrad3b_kernel|rows3::wgrad3t_kernel|rows3::gemm3_kernel<1, 2, 4, 2, 2, (true|false), \d, true, 0, true>|rows3::conv3_kernel')
 acc, dur = {}, {}
 for d in sys.argv[1:]:
     durs = {}
