@@ -97,6 +97,20 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// 4 x 4 transpose inside a lane quad: afterwards x_k of lane i is what x_i of lane k was (b0 / b1 = lane bits 0 / 1)
+__device__ __forceinline__ float dpp_f32_quad_xor1(float v) { return __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v))); }
+__device__ __forceinline__ float dpp_f32_quad_xor2(float v) { return __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v))); }
+__device__ __forceinline__ void quad_transpose(float& x0, float& x1, float& x2, float& x3, bool b0, bool b1) {
+  float t = dpp_f32_quad_xor1(b0 ? x0 : x1);
+  if (b0) x0 = t; else x1 = t;
+  t = dpp_f32_quad_xor1(b0 ? x2 : x3);
+  if (b0) x2 = t; else x3 = t;
+  t = dpp_f32_quad_xor2(b1 ? x0 : x2);
+  if (b1) x0 = t; else x2 = t;
+  t = dpp_f32_quad_xor2(b1 ? x1 : x3);
+  if (b1) x1 = t; else x3 = t;
+}
+
 // A 32x32x16 operand fragment out of an image stored ACROSS the reduction ([k][column] bf16): two ds_read_b64_tr_b16, each
 // handing the lane four consecutive k of its column (cdna_hip_programming.md T10); p0 / p1 address rows 8 h .. 8 h + 3 and
 // 8 h + 4 .. 8 h + 7 of the 16-deep step.  EXEC must be all ones (every main loop here is branch-free).
@@ -462,6 +476,45 @@ __device__ __forceinline__ void gemm3_body(const Args& p, const int bx, const in
               zv[e] = (FULL || (colok && rbase + lr < M)) ? p.Z[off + (unsigned)lr * ldc] : 0.f;
             }
           }
+#ifdef R3_WIDE_STORES
+          // (lab, round 6: measured SLOWER -- the step 10.26 / 10.27 / 10.28 ms against 10.11 / 10.12 / 10.13 with the 4-byte
+          // stores, interleaved on one box; results bit-identical.  Not compiled in.)
+          // Whole tiles, rows of 16-byte multiples: the 16 results of a lane (one column, 16 rows) are transposed 4 x 4 inside
+          // each lane quad (two DPP rounds), after which lane 4 c + i of a quad holds row i of the four columns 4 c .. 4 c + 3:
+          // FOUR 16-byte write-through stores per 32 x 32 tile and lane instead of sixteen 4-byte ones -- a wave instruction
+          // writes eight whole 128-byte row segments (guide T21; narrow sc1 stores are one fabric write each).
+          if constexpr (FULL && !ZERO) {
+            if ((ldc & 3u) == 0) {
+              float vv[16], gg[16];
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                float v = (DUAL ? hi[i][j][e] + lo[i][j][e] : hi[i][j][e]) + bv;
+                if (EPI == rows::EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                if (EPI == rows::EPI_BIAS_GELU2) {
+                  float ge, gr;
+                  gelu_pair_f(v, ge, gr);
+                  gg[e] = gr;
+                  v = ge;
+                }
+                if (EPI == rows::EPI_MUL_GELUGRAD) v *= zv[e];
+                if (EPI == rows::EPI_MUL_POS) v = zv[e] > 0.f ? v : 0.f;
+                vv[e] = v;
+              }
+              const bool b0 = lane & 1, b1 = lane & 2;
+              const size_t qoff = (size_t)(rbase + (lane & 3)) * ldc + (col - (lane & 3));
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {
+                quad_transpose(vv[4 * g4], vv[4 * g4 + 1], vv[4 * g4 + 2], vv[4 * g4 + 3], b0, b1);
+                store_wt4(&Cs[qoff + (unsigned)(8 * g4) * ldc], make_float4(vv[4 * g4], vv[4 * g4 + 1], vv[4 * g4 + 2], vv[4 * g4 + 3]));
+                if (EPI == rows::EPI_BIAS_GELU2) {
+                  quad_transpose(gg[4 * g4], gg[4 * g4 + 1], gg[4 * g4 + 2], gg[4 * g4 + 3], b0, b1);
+                  store_wt4(&p.Z[qoff + (unsigned)(8 * g4) * ldc], make_float4(gg[4 * g4], gg[4 * g4 + 1], gg[4 * g4 + 2], gg[4 * g4 + 3]));
+                }
+              }
+              continue;
+            }
+          }
+#endif
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int lr = (e & 3) + 8 * (e >> 2);
