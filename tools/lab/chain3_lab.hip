@@ -143,3 +143,115 @@ extern "C" int lab_two_launches(int M, int N1, int K1, int N2, int slabs, const 
   hipLaunchKernelGGL(k, dim3(8 * ((p2.tiles + 7) / 8), slabs, 1), dim3(512), lds, (hipStream_t)stream, p2);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same experiment over the FOUR heavy phases of an encoder block's forward (qkv -> proj -> fc1 -> fc2; LayerNorm and the
+// attention core left out: proj reads the q third of qkv's result directly -- the dependency structure and the GEMM work are
+// the block's, the arithmetic in between is not) as ONE table-driven persistent launch: the host hands an ordered unit
+// list (any topological order: phase-major = "four launches without boundaries", or band-group-major = bands drift apart
+// and a band's narrow phases share the chip with other bands' wide ones), every unit = (phase, tile, slab, counter to wait
+// on + how many arrivals, counter to bump).  Same hand-off as chain3_kernel.
+struct Unit { int phase, tile, slab, wait_idx, need, done_idx; };
+struct Chain4Args {
+  rows::Args p[4];
+  int nunits;
+  int waits;
+  const Unit* units;
+  int* cnt;
+  int* sync;
+  unsigned long long* stamps;    // [blocks][MAXU4][4]
+};
+constexpr int MAXU4 = 6;
+
+__global__ __launch_bounds__(512) void chain4_kernel(const Chain4Args c) {
+  constexpr auto E = rows::EPI_STORE;
+  __shared__ int s_epoch;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_epoch = __hip_atomic_load(&c.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int epoch1 = s_epoch + 1;
+  const int pos = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  int k = 0;
+  for (int u = pos; u < c.nunits; u += gridDim.x, ++k) {
+    const Unit un = c.units[u];
+    unsigned long long* st = c.stamps + ((size_t)blockIdx.x * MAXU4 + (k < MAXU4 ? k : MAXU4 - 1)) * 4;
+    if (tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+    if (un.wait_idx >= 0 && c.waits) {
+      if (tid == 0) {
+        int spins = 0;
+        const int target = un.need * epoch1;
+        while (__hip_atomic_load(&c.cnt[un.wait_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 400000) {
+            __hip_atomic_fetch_add(&c.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    if (tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+    const rows::Args& p = c.p[un.phase];
+    gemm3_body<1, 2, 4, 2, 2, false, E, true, 0, false>(p, bx_of_tile(p, un.tile), un.slab, 0, 8 * ((p.tiles + 7) >> 3));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (un.done_idx >= 0) __hip_atomic_fetch_add(&c.cnt[un.done_idx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st[2] = __builtin_amdgcn_s_memrealtime();
+      st[3] = (unsigned long long)u;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(&c.sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (int)gridDim.x - 1) {
+      __hip_atomic_store(&c.sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&c.sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static void fill4(rows::Args (&p)[4], int M, const float* X, const float* Wqkv, float* QKV, const float* Wproj, float* P,
+                  const float* W1, float* H, const float* W2, float* Y, int slabs) {
+  fill(p[0], M, 1152, 384, X, Wqkv, QKV, 1);
+  fill(p[1], M, 384, 384, QKV, Wproj, P, 1);
+  p[1].lda = 1152;                                  // the q third of the qkv rows
+  fill(p[2], M, 1536, 384, P, W1, H, 1);
+  fill(p[3], M, 384, 1536, H, W2, Y, slabs);
+}
+
+extern "C" int lab_chain4(int M, int slabs, const float* X, const float* Wqkv, float* QKV, const float* Wproj, float* P,
+                          const float* W1, float* H, const float* W2, float* Y, const void* units, int nunits, int* cnt, int* sync,
+                          unsigned long long* stamps, int waits, int blocks, void* stream) {
+  Chain4Args c = {};
+  fill4(c.p, M, X, Wqkv, QKV, Wproj, P, W1, H, W2, Y, slabs);
+  if ((nunits + blocks - 1) / blocks > MAXU4) return -3;
+  c.nunits = nunits, c.waits = waits, c.units = reinterpret_cast<const Unit*>(units), c.cnt = cnt, c.sync = sync, c.stamps = stamps;
+  const size_t lds = 2 * 3 * (size_t)(128 + 128) * 80;
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  hipLaunchKernelGGL(chain4_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, c);
+  return (int)hipGetLastError();
+}
+
+// the same four products as four launches of the same tile body
+extern "C" int lab_four_launches(int M, int slabs, const float* X, const float* Wqkv, float* QKV, const float* Wproj, float* P,
+                                 const float* W1, float* H, const float* W2, float* Y, void* stream) {
+  rows::Args p[4];
+  fill4(p, M, X, Wqkv, QKV, Wproj, P, W1, H, W2, Y, slabs);
+  const size_t lds = 2 * 3 * (size_t)(128 + 128) * 80;
+  auto k = gemm3_kernel<1, 2, 4, 2, 2, false, rows::EPI_STORE, true, 0, false>;
+  static bool once = false;
+  if (!once) {
+    once = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  for (int q = 0; q < 4; ++q)
+    hipLaunchKernelGGL(k, dim3(8 * ((p[q].tiles + 7) / 8), q == 3 ? slabs : 1, 1), dim3(512), lds, (hipStream_t)stream, p[q]);
+  return (int)hipGetLastError();
+}

@@ -130,3 +130,117 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# The four heavy phases of an encoder block's forward (qkv -> proj -> fc1 -> fc2) as ONE table-driven persistent launch
+# (chain4_kernel) against four launches; unit orders: phase-major, band-group wavefronts, band-major.
+def unit_table(T, S, order, G=8):
+    import numpy as np
+    B = T                                        # bands of 128 rows
+    c0 = lambda b: b
+    c1 = lambda b: B + b
+    c2 = lambda b, s: 2 * B + b * S + s
+    per_phase = {0: [], 1: [], 2: [], 3: []}
+    for b in range(B):
+        for j in range(9):
+            per_phase[0].append((b, (0, b * 9 + j, 0, -1, 0, c0(b) if j < 3 else -1)))
+        for j in range(3):
+            per_phase[1].append((b, (1, b * 3 + j, 0, c0(b), 3, c1(b))))
+        for j in range(12):
+            per_phase[2].append((b, (2, b * 12 + j, 0, c1(b), 3, c2(b, j // 4))))
+        for s in range(S):
+            for j in range(3):
+                per_phase[3].append((b, (3, b * 3 + j, s, c2(b, s), 4, -1)))
+    units = []
+    if order == 'phase':
+        for ph in range(4):
+            units += [u for _, u in per_phase[ph]]
+    elif order == 'band':
+        for b in range(B):
+            for ph in range(4):
+                units += [u for bb, u in per_phase[ph] if bb == b]
+    else:                                         # wavefront over groups of G bands: (group g, phase p) in slot g + p
+        ngroups = (B + G - 1) // G
+        for slot in range(ngroups + 3):
+            for ph in (3, 2, 1, 0):               # later phases first: they are on the critical path
+                g = slot - ph
+                if 0 <= g < ngroups:
+                    units += [u for bb, u in per_phase[ph] if bb // G == g]
+    return torch.tensor(np.array(units, dtype=np.int32)), 2 * B + B * S
+
+
+def main4():
+    use_created_stream()
+    torch.manual_seed(1)
+    S, blocks, MAXU4 = 3, 256, 6
+    lab.lab_chain4.argtypes = [i32, i32] + [vp] * 10 + [i32] + [vp] * 3 + [i32, i32, vp]
+    lab.lab_four_launches.argtypes = [i32, i32] + [vp] * 9 + [vp]
+    for T in (23, 13, 32):
+        M = 128 * T
+        X = torch.randn(M, 384, device='cuda')
+        Wq, Wp = torch.randn(1152, 384, device='cuda') * 384 ** -0.5, torch.randn(384, 384, device='cuda') * 384 ** -0.5
+        W1, W2 = torch.randn(1536, 384, device='cuda') * 384 ** -0.5, torch.randn(384, 1536, device='cuda') * 1536 ** -0.5
+        def bufs(fill):
+            mk = lambda *s: torch.full(s, fill, device='cuda')
+            return mk(M, 1152), mk(M, 384), mk(M, 1536), mk(S, M, 384)
+        Q0, P0, H0, Y0 = bufs(0.0)
+        Q1, P1, H1, Y1 = bufs(float('nan'))
+        sync = torch.zeros(4, dtype=torch.int32, device='cuda')
+        stamps = torch.zeros(blocks * MAXU4 * 4, dtype=torch.int64, device='cuda')
+
+        def four():
+            rc = lab.lab_four_launches(M, S, X.data_ptr(), Wq.data_ptr(), Q0.data_ptr(), Wp.data_ptr(), P0.data_ptr(), W1.data_ptr(),
+                                       H0.data_ptr(), W2.data_ptr(), Y0.data_ptr(), stream())
+            assert rc == 0, rc
+
+        def shipped():
+            q = nn_ops.rows_gemm(X, Wq)
+            outs = []
+            for a, w in ((q[:, :384].contiguous() if False else q, Wp),):
+                pass
+            # proj reads the q third: the library's entry takes a contiguous operand, so the shipped comparison uses a
+            # (M, 384) operand of its own (same shape, same work)
+            cfg, sp, sb = _lib.rows_gemm_plan(M, 384, 384, False, 8)
+            p_ = torch.empty(max(sp, 1), M, 384, device='cuda')
+            _lib.call('pdae_rows_gemm', X, M, 384, 384, _lib.ptr(X), _lib.ptr(Wp), 0, None, 0, None, _lib.ptr(p_), cfg, sp, sb)
+            h = nn_ops.rows_gemm(p_[0], W1)
+            cfg, sp, sb = _lib.rows_gemm_plan(M, 384, 1536, False, 8)
+            y = torch.empty(max(sp, 1), M, 384, device='cuda')
+            _lib.call('pdae_rows_gemm', h, M, 384, 1536, _lib.ptr(h), _lib.ptr(W2), 0, None, 0, None, _lib.ptr(y), cfg, sp, sb)
+            return y
+        four()
+        torch.cuda.synchronize()
+        t_four, t_ship = graph_ms(four), graph_ms(shipped)
+        print(f'M = {M} (T_vis {T}): four launches (128x128 tiles) {t_four:6.1f} us | shipped plans (four launches) {t_ship:6.1f} us')
+        for order, G in (('phase', 0), ('wave', 8), ('wave', 4), ('band', 0)):
+            table, ncnt = unit_table(T, S, order, G)
+            table = table.cuda().contiguous()
+            cnt = torch.zeros(ncnt, dtype=torch.int32, device='cuda')
+            sync.zero_()
+
+            def chain(waits=1):
+                rc = lab.lab_chain4(M, S, X.data_ptr(), Wq.data_ptr(), Q1.data_ptr(), Wp.data_ptr(), P1.data_ptr(), W1.data_ptr(),
+                                    H1.data_ptr(), W2.data_ptr(), Y1.data_ptr(), table.data_ptr(), table.shape[0], cnt.data_ptr(),
+                                    sync.data_ptr(), stamps.data_ptr(), waits, blocks, stream())
+                assert rc == 0, rc
+            bad = 0
+            for _ in range(50):
+                Y1.fill_(float('nan'))
+                chain()
+                bad += int(not (torch.equal(Y0, Y1) and torch.equal(H0, H1) and torch.equal(P0, P1) and torch.equal(Q0, Q1)))
+            t_chain = graph_ms(chain)
+            chain()
+            torch.cuda.synchronize()
+            st = stamps.view(blocks, MAXU4, 4).cpu().double()
+            t0 = st[:, 0, 0].min()
+            waits = [(st[b, k, 1] - st[b, k, 0]).item() / 100 for b in range(blocks) for k in range(MAXU4) if st[b, k, 2] > 0]
+            end = max((st[b, k, 2] - t0).item() / 100 for b in range(blocks) for k in range(MAXU4) if st[b, k, 2] > 0)
+            import statistics as stt
+            print(f'   ONE launch, order {order:5s}{("/" + str(G)) if G else "  "}: {t_chain:6.1f} us  ({table.shape[0]} units; 50 repeats differing {bad}, '
+                  f'give-ups {int(sync[2])}; in-kernel: launch ends {end:5.1f} us, waiting per unit mean {stt.mean(waits):.2f} max {max(waits):.1f} us, '
+                  f'sum of waits per block {sum(waits) / blocks:.1f} us)')
+
+
+if __name__ == '__main__' and os.environ.get('CHAIN4', '1') == '1':
+    main4()
