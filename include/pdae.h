@@ -846,6 +846,37 @@ int pdae_pos_embed_fc1(int M, int H, const float* xyz, const int64_t* rows, cons
                        float* gp, float* xp, pdae_stream_t stream);
 int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
                 pdae_stream_t stream);
+/* Single launches in place of groups of framework launches inside the graphed step (csrc/glue.hip; every node of the step's
+ * graph costs ~5 us whatever it moves):
+ *   partials_sum_t    out (C, K) = sum_p part[p] (K, C) in a fixed order, written transposed: the first conv's weight gradient in the
+ *                     parameter's layout (models/PointCAE_transformer.py:22 nn.Conv1d(3, 128, 1): weight (128, 3, 1)) from
+ *                     embed_conv1_backward_weight's ordered partials.
+ *   multi_copy        n independent float copies src[i] -> dst[i] of counts[i] elements in ONE launch per 128 entries (the gather of
+ *                     the gradients autograd produced outside the flat gradient buffer of the data-parallel wrapper -- the
+ *                     reference's DistributedDataParallel owns that copy inside its reducer, runner_pretrain.py:84-90).  src, dst,
+ *                     counts, cols, src_ld are HOST arrays; cols / src_ld (both or neither; NULL = contiguous): entry i reads a 2-D
+ *                     source of cols[i] columns with row stride src_ld[i] (<= 65535), dst is always contiguous.  src[i] NULL: dst[i] is zero-filled
+ *                     (the parameters that received no gradient).
+ *   assemble_tokens   the decoder's input (:700-703): out (B, G, C) = per sample [the Tv visible tokens | G - Tv copies of
+ *                     mask_token]; _grad splits dout (B, G, C) into dvis (B, Tv, C) and dmask (B, G - Tv, C) (the mask token's
+ *                     gradient is the column sum of dmask).  C % 4 == 0.
+ *   embed_split_conv3_weight   second_conv[0]'s weight w (N, 2 K2) (:29 nn.Conv1d(512, 512, 1) on concat([global, local]), :44-46)
+ *                     -> wg = w[:, :K2], wl = w[:, K2:], and wlt = wl^T (K2, N) (nullable).
+ *   embed_masked_prep / embed_dw3_assemble   element-wise steps of the masked-groups algebra of conv3's backward
+ *                     (point_dae_amd/patch_embed.py _masked_by_algebra): xe (Gm, C3) = u + gb[masked] * v and wv (C3, C2) =
+ *                     diag(v) wl, with uv (2, C3) = [u; v];  dw3 (C3, 2 C2) = [dwg | dwl + diag(v) wgram + xterm]
+ *                     (v NULL: [dwg | dwl], wgram / xterm unread). */
+int pdae_partials_sum_t(int P, int K, int C, const float* part, float* out, pdae_stream_t stream);
+int pdae_multi_copy(int n, const float* const* src, float* const* dst, const long long* counts, const int* cols /*nullable*/,
+                    const int* src_ld /*nullable*/, pdae_stream_t stream);
+int pdae_assemble_tokens(int B, int G, int Tv, int C, const float* vis, const float* token, float* out, pdae_stream_t stream);
+int pdae_assemble_tokens_grad(int B, int G, int Tv, int C, const float* dout, float* dvis, float* dmask, pdae_stream_t stream);
+int pdae_embed_split_conv3_weight(int N, int K2, const float* w, float* wg, float* wl, float* wlt /*nullable*/,
+                                  pdae_stream_t stream);
+int pdae_embed_masked_prep(int Gm, int C3, int C2, const float* uv, const float* gb, const int32_t* masked, const float* wl,
+                           float* xe, float* wv, pdae_stream_t stream);
+int pdae_embed_dw3_assemble(int C3, int C2, const float* dwg, const float* dwl, const float* v /*nullable*/,
+                            const float* wgram /*nullable*/, const float* xterm /*nullable*/, float* dw3, pdae_stream_t stream);
 /*   scale_colsum        Y = keep[row/T] * X and out[c] (nullable) = column sums
  *                       of Y: autograd of scale_residual w.r.t. its branch and
  *                       bias in one pass (DropPath backward, timm drop.py).   */

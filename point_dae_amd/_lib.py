@@ -116,6 +116,13 @@ _SIGNATURES = {
     "pdae_rows_gemm_bnrelu_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_backward_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_backward_listed_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
+    "pdae_partials_sum_t": [_i, _i, _i, _vp, _vp, _vp],
+    "pdae_multi_copy": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_assemble_tokens": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_assemble_tokens_grad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_embed_split_conv3_weight": [_i, _i, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_masked_prep": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pdae_embed_dw3_assemble": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_calib_mfma_bf16": [_i, _i, _vp, _vp, _vp, _vp],
     "pdae_calib_copy": [ctypes.c_longlong, _vp, _vp, _vp],
 }
@@ -383,6 +390,35 @@ def edge_weights_multi(name, on, cos, cins, kps, srcs, dsts):
 
 
 WGRAD_MULTI_MAX = 48
+
+
+def multi_copy(pairs, strided=()):
+    """pdae_multi_copy: pairs = [(dst, src)] contiguous fp32 device tensors of equal numel (src None: dst is zero-filled);
+    strided = [(dst, src2d, cols)]: dst (contiguous, rows * cols elements) <- src2d[:, :cols] of a row-major 2-D tensor.
+    One launch per 128 entries."""
+    n = len(pairs) + len(strided)
+    if n == 0:
+        return
+    on = pairs[0][0] if pairs else strided[0][0]
+    for d, s_ in list(pairs) + [(d, s_) for d, s_, _ in strided]:
+        for t in (d, s_):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != on.device):
+                raise ValueError('multi_copy: contiguous fp32 tensors on one device')
+    for d, s_ in pairs:
+        if s_ is not None and d.numel() != s_.numel():
+            raise ValueError('multi_copy: %r <- %r' % (tuple(d.shape), tuple(s_.shape)))
+    for d, s_, c in strided:
+        if s_.dim() != 2 or not 0 < c <= s_.shape[1] or d.numel() != s_.shape[0] * c:
+            raise ValueError('multi_copy: %r <- %r[:, :%d]' % (tuple(d.shape), tuple(s_.shape), c))
+    parr, larr, iarr = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
+    src = parr(*([ptr(s_) for _, s_ in pairs] + [ptr(s_) for _, s_, _ in strided]))
+    dst = parr(*([ptr(d) for d, _ in pairs] + [ptr(d) for d, _, _ in strided]))
+    cnt = larr(*([d.numel() for d, _ in pairs] + [d.numel() for d, _, _ in strided]))
+    cols = sld = None
+    if strided:
+        cols = iarr(*([0] * len(pairs) + [c for _, _, c in strided]))
+        sld = iarr(*([0] * len(pairs) + [s_.shape[1] for _, s_, _ in strided]))
+    call('pdae_multi_copy', on, n, src, dst, cnt, cols, sld)
 
 
 def rows_wgrad_multi(jobs):

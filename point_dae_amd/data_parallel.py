@@ -82,6 +82,7 @@ class FlatDataParallel(nn.Module):
         self.grad_views = [p.grad for p in params]
         # gradient sink (nn_ops._sink_views): armed by a graphed step around its own forward + backward only
         self.sink_armed, self.sink_written = False, set()
+        self.sink_strided = []          # (flat view, 2-D tile, cols): gradients the gather copies out of a wider tile
         self.wgrad_queue = []           # the armed step's queued weight gradients (nn_ops.flush_wgrad_queue)
         self.wgrad_stream, self.wgrad_inflight = None, []     # optional side stream for them (graph_step)
         me = weakref.ref(self)

@@ -104,6 +104,29 @@ def _average_gradients(model):
         model.flat_grad.div_(model.world_size)
 
 
+MULTI_COPY = os.environ.get('PDAE_MULTI_COPY', os.environ.get('PDAE_GLUE', '1')) != '0'      # (A/B: 0 = torch._foreach_copy_, two launches per 123 tensors)
+
+
+def _copy_into_views(have, strided=()):
+    """[(flat gradient view, the gradient autograd produced -- None: no gradient, the view is zeroed)] -> ONE launch per 128
+    tensors (csrc/glue.hip multi_copy); strided: [(view, 2-D tensor, cols)] gradients that are the leading columns of a wider
+    tile (nn_ops._PosEmbed)."""
+    fast, slow = [], []
+    for v, g in have:
+        if g is None:
+            if MULTI_COPY and v.dtype == torch.float32:
+                fast.append((v, None))
+            else:
+                v.zero_()
+            continue
+        ok = MULTI_COPY and g.is_contiguous() and g.dtype == torch.float32 and v.dtype == torch.float32 and g.device == v.device
+        (fast if ok else slow).append((v, g))
+    if fast or strided:
+        _lib.multi_copy(fast, strided)
+    if slow:
+        torch._foreach_copy_([v for v, _ in slow], [g for _, g in slow])
+
+
 class GraphedTrainStep:
     MAX_STEPS = 3          # affine_r3 applies 1-3 maps; shorter draws are padded with identities
     RING = int(os.environ.get("PDAE_RING", "4"))   # staging slots = how many steps the host may run ahead
@@ -177,6 +200,7 @@ class GraphedTrainStep:
             raise NotImplementedError('graphed step: loss_type %s' % self.loss_type)
         # weight of the normal loss as the captured graphs read it: normal_weight (x the epoch's gradual weight)
         self.w_dev = torch.full((), self.normal_weight, device=dev)
+        self.seed = torch.ones((), device=dev)
         if self.loss_type in ('xyznormal_gradual', 'xyznormal_warm'):
             self.w_dev.zero_()                                     # epoch 0 of both ramps
         self.spu = int(config.get('step_per_update', 1) if step_per_update is None else step_per_update)
@@ -256,12 +280,9 @@ class GraphedTrainStep:
             for i in written:
                 if m.params[i].grad is None:
                     m.params[i].grad = m.grad_views[i]
-        have = [(m.grad_views[i], m.params[i].grad) for i in idx if m.params[i].grad is not None]
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        _copy_into_views([(m.grad_views[i], m.params[i].grad) for i in idx], m.sink_strided)
+        m.sink_strided = []
         for i in idx:
-            if m.params[i].grad is None:
-                m.grad_views[i].zero_()
             m.params[i].grad = m.grad_views[i]
 
     def _phase1(self, tvis, cut=None):
@@ -276,7 +297,7 @@ class GraphedTrainStep:
         # the blocks' weight gradients go straight into THIS model's flat buffer (nn_ops._sink_views): every .grad
         # is None here and nothing else touches the flat gradient views until the gather below
         from . import nn_ops
-        m.sink_armed, m.sink_written = SINK, set()
+        m.sink_armed, m.sink_written, m.sink_strided = SINK, set(), []
         if WGRAD_SIDE and m.wgrad_stream is None:
             m.wgrad_stream = torch.cuda.Stream()
         try:
@@ -289,7 +310,8 @@ class GraphedTrainStep:
             if SINK:
                 _lib.deferred_begin()
             try:
-                loss.backward()
+                # (the seed of the backward pass is a constant: autograd's own ones_like is a fill launch per step)
+                loss.backward(self.seed if self.seed.shape == loss.shape and self.seed.dtype == loss.dtype else None)
                 nn_ops.flush_wgrad_queue(m)        # (stacks flush themselves; this catches a queue left by a cut)
                 nn_ops.join_wgrad_stream(m)
             finally:
@@ -452,11 +474,8 @@ class GraphedStaticStep:
             p.grad = None
         l1, l2 = m(self.corrupted, self.clean)
         self.loss_mix(l1, l2).backward()
-        have = [(v, p.grad) for p, v in zip(m.params, m.grad_views) if p.grad is not None]
-        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        _copy_into_views([(v, p.grad) for p, v in zip(m.params, m.grad_views)])
         for p, v in zip(m.params, m.grad_views):
-            if p.grad is None:
-                v.zero_()
             p.grad = v
         return l1.detach(), l2.detach()
 

@@ -198,6 +198,39 @@ def expand_token(token, B, M):
     return _ExpandToken.apply(token, B, M)
 
 
+class _AssembleTokens(torch.autograd.Function):
+    """The decoder's input (PointCAE_transformer.py:700-703): per sample [the Tv visible tokens | M copies of the mask token],
+    one launch (csrc/glue.hip assemble_tokens; was expand + cat); the backward splits the gradient into its two contiguous
+    parts in one launch and column-sums the masked part (was two strided copies, the column sum and a clone)."""
+
+    @staticmethod
+    def forward(ctx, x_vis, token, B, Tv, M):
+        C = x_vis.shape[-1]
+        out = _empty((B, Tv + M, C), x_vis)
+        _lib.call('pdae_assemble_tokens', x_vis, B, Tv + M, Tv, C, _lib.ptr(x_vis), _lib.ptr(token), _lib.ptr(out))
+        ctx.dims = (B, Tv, M, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Tv, M, C = ctx.dims
+        g = g.contiguous()
+        dvis, dmask = _empty((B, Tv, C), g), _empty((B * M, C), g)
+        _lib.call('pdae_assemble_tokens_grad', g, B, Tv + M, Tv, C, _lib.ptr(g), _lib.ptr(dvis), _lib.ptr(dmask))
+        return dvis, _colsum(dmask).reshape(1, 1, -1), None, None, None
+
+
+ASSEMBLE = os.environ.get('PDAE_ASSEMBLE', os.environ.get('PDAE_GLUE', '1')) != '0'     # (A/B: 0 = torch.cat of the visible tokens and the expanded mask token)
+
+
+def assemble_tokens(x_vis, token, B, Tv, M):
+    """(B, Tv, C) visible tokens + the (1, 1, C) mask token -> (B, Tv + M, C)."""
+    x_vis = x_vis.reshape(B, Tv, -1)
+    if not ASSEMBLE or not x_vis.is_cuda or x_vis.shape[-1] % 4 != 0 or x_vis.dtype != torch.float32 or Tv == 0:
+        return torch.cat([x_vis, expand_token(token, B, M)], dim=1)
+    return _AssembleTokens.apply(x_vis.contiguous(), token.contiguous(), B, Tv, M)
+
+
 class Pending:
     """A sub-layer's output that has not been added to the residual stream yet:
     stream = res + keep * (a + bias).  The norm that consumes it does the add."""
@@ -354,6 +387,39 @@ def draw_drop_path(B, drop_probs, training, keep):
     else:
         r = (r + keep).floor_() / keep
     return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(drop_probs)]
+
+
+PREDRAW = os.environ.get('PDAE_PREDRAW', os.environ.get('PDAE_GLUE', '1')) != '0'     # (A/B: 0 = one rand + one keep launch per stack)
+
+
+def predraw_drop_path(B, stacks):
+    """The stochastic-depth draws of several stacks of blocks (encoder + decoder) from ONE torch.rand and ONE keep launch: each
+    stack's next stack_keeps() call takes its own rows.  Stacks: modules with .blocks, .dp_keep and .training."""
+    live = [s for s in stacks if s.training and any(b.drop_prob != 0. for b in s.blocks)]
+    if not PREDRAW or len(live) < 2 or not live[0].dp_keep.is_cuda:
+        return
+    owner, key = live[0].__dict__, tuple(id(s) for s in live)
+    cached = owner.get('_dp_keep_all')
+    if cached is None or cached[0] != key or cached[1].device != live[0].dp_keep.device:
+        cached = owner['_dp_keep_all'] = (key, torch.cat([s.dp_keep for s in live], 0))
+    keep = cached[1]
+    r = torch.rand((keep.shape[0], B), dtype=keep.dtype, device=keep.device)
+    _lib.call('pdae_drop_path_keep', r, r.shape[0], B, _lib.ptr(r), _lib.ptr(keep), _lib.ptr(r))
+    o = 0
+    for s in live:
+        n = s.dp_keep.shape[0]
+        s.__dict__['_keeps_next'] = (B, r[o:o + n])
+        o += n
+
+
+def stack_keeps(stack, B):
+    """[(keep_attn, keep_mlp)] of one stack of blocks: its share of predraw_drop_path()'s launch, else its own draw."""
+    probs = [blk.drop_prob for blk in stack.blocks]
+    pre = stack.__dict__.pop('_keeps_next', None)
+    if pre is not None and pre[0] == B and stack.training:
+        r = pre[1]
+        return [(None, None) if p == 0. else (r[2 * i], r[2 * i + 1]) for i, p in enumerate(probs)]
+    return draw_drop_path(B, probs, stack.training, stack.dp_keep)
 
 
 def rows_gemm(x, w, w_kn=False, bias=None, epi=0, z=None, may_split=False, big_cfg=None):
@@ -694,6 +760,7 @@ class _PosEmbed(torch.autograd.Function):
                   _lib.ptr(h), _lib.ptr(gp), _lib.ptr(xp))
         y = rows_gemm(h, w2, False, b2, 0)
         ctx.save_for_backward(xp, gp, h, w2)
+        ctx.sink_tags, ctx.w1 = _sink_tags([w1]), w1
         return y
 
     @staticmethod
@@ -702,6 +769,14 @@ class _PosEmbed(torch.autograd.Function):
         dy = dy.contiguous()
         dz = rows_gemm(dy, w2, True, None, 3, gp)
         (dw2, dw1p), (db2, db1) = rows_wgrad([dy, dz], [h, xp], [True, True])
+        sink = _sink_views(ctx.sink_tags, [ctx.w1])
+        if sink:
+            # graphed step: the (H, 3) gradient is the leading columns of the (H, 4) tile; returned as a view, autograd would
+            # make it contiguous with a launch of its own -- the step's gather copy takes it as one more entry instead
+            owner, idx, views = sink
+            owner.sink_strided.append((views[0], dw1p, 3))
+            owner.sink_written.update(idx)
+            return None, None, None, db1, dw2, db2
         return None, None, dw1p[:, :3], db1, dw2, db2
 
 

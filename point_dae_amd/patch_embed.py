@@ -61,6 +61,8 @@ def _gemm(x, w, w_kn=False, bias=None):
     return y
 
 
+# (A/B: 0 = the small element-wise steps of the embedder as framework launches: 2 + 4 + 3 + 2 of them instead of 1 + 1 + 1 + 1)
+GLUE = os.environ.get('PDAE_EMBED_GLUE', os.environ.get('PDAE_GLUE', '1')) != '0'
 BN_FUSED = os.environ.get('PDAE_BN_FUSED', '1') != '0'     # (A/B: 0 = the data gradient and BatchNorm's sums as two launches)
 
 
@@ -186,8 +188,14 @@ class PatchEmbedFunction(torch.autograd.Function):
             'pdae_embed_bnrelu_conv_store_groupmax', x, R, c2, c1, _lib.ptr(y1), _lib.ptr(sc1),
             _lib.ptr(sh1), _lib.ptr(w2m), _lib.ptr(b2), _lib.ptr(f), _lib.ptr(g), _lib.ptr(arg2)))
         # conv3 on concat([g, f]): global half once per group, local half as the GEMM
-        wg = w3m[:, :c2].contiguous()
-        wl = w3m[:, c2:].contiguous()
+        wlt = None
+        if GLUE and w3m.shape[1] == 2 * c2 and w3m.is_contiguous():
+            wg, wl = _empty((c3, c2), x), _empty((c3, c2), x)
+            wlt = _empty((c2, c3), x) if training else None         # (the backward's visible-rows data gradient reads wl^T)
+            _lib.call('pdae_embed_split_conv3_weight', x, c3, c2, _lib.ptr(w3m), _lib.ptr(wg), _lib.ptr(wl), _lib.ptr(wlt))
+        else:
+            wg = w3m[:, :c2].contiguous()
+            wl = w3m[:, c2:].contiguous()
         gb = _gemm(g, wg, False, b3)
         h3 = _empty((R, c3), x)
         stats = _empty((8, 2, c3), x)
@@ -222,7 +230,7 @@ class PatchEmbedFunction(torch.autograd.Function):
             _lib.ptr(w4m), _lib.ptr(b4), _lib.ptr(tok), _lib.ptr(arg4), _lib.ptr(groups)))
         ctx.save_for_backward(x, y1, sc1, sh1, mean1, is1, f, g, arg2, h3, sc2, sh2, mean2, is2, arg4,
                               w1m, w2m, wg, wl, w4m, g1, g2, groups, inv)
-        ctx.training = training
+        ctx.training, ctx.wlt = training, wlt
         # masked groups by algebra (backward): needs the complementary list and the per-group bias term
         ctx.algebra = algebra
         if ctx.algebra:
@@ -252,23 +260,33 @@ class PatchEmbedFunction(torch.autograd.Function):
         u, v = uv[0], uv[1]
         fsum_m = _empty((Gm, c2), x)
         _lib.call('pdae_group_sum_listed', x, Gm, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(fsum_m))
-        xe = torch.addcmul(u, gb.index_select(0, masked.long()), v)   # u + v * gb_g  (Gm, 512)
+        if GLUE:                                                      # xe and diag(v) W, one launch
+            xe, wv = _empty((Gm, c3), x), _empty((c3, c2), x)
+            _lib.call('pdae_embed_masked_prep', x, Gm, c3, c2, _lib.ptr(uv), _lib.ptr(gb), _lib.ptr(masked), _lib.ptr(wl),
+                      _lib.ptr(xe), _lib.ptr(wv))
+        else:
+            xe = torch.addcmul(u, gb.index_select(0, masked.long()), v)   # u + v * gb_g  (Gm, 512)
+            wv = wl * v.unsqueeze(1)
         # ---- weight gradient: dW_visible + diag(v) W Gram + xe^T fsum   (u (x) sum f rides in xe)
         dwl, _ = _wgrad_listed(Rv, d3c, None, f, groups)
         gram, _ = _wgrad_listed(Rm, f, masked, f, masked)
-        dwl.addcmul_(v.unsqueeze(1), _gemm(wl, gram)).add_(_wgrad(xe, fsum_m))      # (Gram is symmetric)
+        wgram, xterm = _gemm(wl, gram), _wgrad(xe, fsum_m)            # (Gram is symmetric)
+        if GLUE:
+            dwl = (dwl, v, wgram, xterm)                              # summed where conv3's gradient is assembled (backward)
+        else:
+            dwl.addcmul_(v.unsqueeze(1), wgram).add_(xterm)
         # ---- per-group sums of the masked groups (the global half of the split concat weight)
         hs = _gemm(fsum_m, wl)                                        # the group's summed conv output, bias term apart
         _lib.call('pdae_masked_group_sums', x, Gm, c3, _lib.ptr(hs), _lib.ptr(xe), _lib.ptr(v), _lib.ptr(masked),
                   _lib.ptr(dgb))
         # ---- data gradient
-        q = _wgrad(wl * v.unsqueeze(1), wl)                           # W^T diag(v) W  (symmetric)
+        q = _wgrad(wv, wl)                                            # W^T diag(v) W  (symmetric)
         e = _gemm(xe, wl, True)                                       # (gb_g * v + u) W   (Gm, 256)
         df = _empty((R, c2), x)
         probed_family('embed_gemm', 2.0 * Rm * c2 * c2, lambda: _lib.call(
             'pdae_group_gemm_scatter', x, Rm, c2, c2, _lib.ptr(f), _lib.ptr(masked), _lib.ptr(q), _lib.ptr(e),
             _lib.ptr(df), c2, _lib.ptr(masked)))
-        wlt = wl.t().contiguous()
+        wlt = ctx.wlt if ctx.wlt is not None else wl.t().contiguous()
         probed_family('embed_gemm', 2.0 * Rv * c2 * c3, lambda: _lib.call(
             'pdae_group_gemm_scatter', x, Rv, c2, c3, _lib.ptr(d3c), None, _lib.ptr(wlt), None,
             _lib.ptr(df), c2, _lib.ptr(groups)))
@@ -315,7 +333,14 @@ class PatchEmbedFunction(torch.autograd.Function):
         # backward removes the batch mean of the gradient); the column-sum pass over dgb would only measure
         # its own rounding (the reference's value is ~1e-6 of the other gradients, noise of either sign)
         db3 = arena.take(c3, x)[0]
-        dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
+        if GLUE and c2 % 4 == 0:
+            parts = dwl if isinstance(dwl, tuple) else (dwl, None, None, None)
+            dw3 = _empty((c3, 2 * c2, 1), x)
+            _lib.call('pdae_embed_dw3_assemble', x, c3, c2, _lib.ptr(dwg), *[_lib.ptr(t) for t in parts], _lib.ptr(dw3))
+        else:
+            if isinstance(dwl, tuple):
+                dwl = dwl[0].addcmul_(dwl[1].unsqueeze(1), dwl[2]).add_(dwl[3])
+            dw3 = torch.cat([dwg, dwl], dim=1).unsqueeze(-1)
         dg = _gemm(dgb, wg, True)                                 # (BG, 256) -> arg-max rows of f
         _lib.call('pdae_group_scatter_add', x, BG, c2, _lib.ptr(dg), _lib.ptr(arg2), _lib.ptr(df))
         # ---- conv2
@@ -330,7 +355,11 @@ class PatchEmbedFunction(torch.autograd.Function):
         dbe1, dg1 = S1[0], S1[1]
         part1 = _empty((_lib.lib().pdae_embed_conv1_backward_weight_parts(R), 3, c1), x)
         _lib.call('pdae_embed_conv1_backward_weight', x, R, c1, _lib.ptr(d1), _lib.ptr(x), _lib.ptr(part1))
-        dw1 = part1.sum(0).t().unsqueeze(-1)                          # (c1, 3, 1): one pass over d1, ordered partials
+        if GLUE:                                                      # (c1, 3, 1): one pass over d1, ordered partials
+            dw1 = _empty((c1, 3, 1), x)
+            _lib.call('pdae_partials_sum_t', x, part1.shape[0], 3, c1, _lib.ptr(part1), _lib.ptr(dw1))
+        else:
+            dw1 = part1.sum(0).t().unsqueeze(-1)
         if DEBUG_KEEP is not None:
             DEBUG_KEEP.update(d1_post=d1.clone(), part1=part1.clone(), dw1=dw1.clone(), x=x.clone(), S1=S1.clone())
         db1 = arena.take(c1, x)[0]                                   # exactly zero, as db3 (saves a 134 MB pass)

@@ -2,6 +2,7 @@
 (`--kernel-trace --output-format csv`).  usage: trace_summary.py <kernel_trace.csv> <timed steps>
 The timed region = everything after the (2*steps+1)-th-from-last adamw launch (two per step)."""
 import csv
+import os
 import re
 import sys
 
@@ -41,6 +42,6 @@ print('# library GEMMs %.3f ms/step, hand-written pdae:: kernels %.3f ms/step, o
       % (lib / 1e6 / steps, mine / 1e6 / steps, (tot - lib - mine) / 1e6 / steps))
 print('%7s %12s %11s %11s  %s' % ('%time', 'us/step', 'calls/step', 'avg us', 'kernel'))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    if v[1] / tot < 0.0008:
+    if v[1] / tot < float(os.environ.get('TS_MIN', '0.0008')):
         continue
     print('%6.2f%% %12.1f %11.1f %11.1f  %s' % (100 * v[1] / tot, v[1] / 1e3 / steps, v[0] / steps, v[1] / 1e3 / v[0], k))
