@@ -41,21 +41,34 @@ class Sites(TorchDispatchMode):
 
 
 use_created_stream()
-config = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
-model = FlatDataParallel(builder.model_builder(config.model).cuda())
-opt, _ = builder.build_opti_sche(model, config)
-model.train()
+what = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
 B = 128
-x = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=1)).cuda()
-step = GraphedTrainStep(model, opt, config, B, 1024)
-step.pts.copy_(x)
+x = torch.from_numpy(shapenet_like_clouds(2 * B, 1024, seed=1)).cuda()
+if what == 'cfg2':
+    from point_dae_amd.graph_step import GraphedStaticStep  # noqa: E402
+    config = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs', 'pretrain_PointCAE_affine_r3_dropout_local_4xlonger.yaml'))
+    model = FlatDataParallel(builder.model_builder(config.model).cuda())
+    opt, _ = builder.build_opti_sche(model, config)
+    model.train()
+    step = GraphedStaticStep(model, opt, lambda a, b: a + float(config.normal_weight) * b * 0.5, B, 1024)
+    step.corrupted.copy_(x[:B]), step.clean.copy_(x[B:])
+    body = step._fwd_bwd
+else:
+    config = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    if what != 'cfg3':
+        config.model.NAME = what
+    model = FlatDataParallel(builder.model_builder(config.model).cuda())
+    opt, _ = builder.build_opti_sche(model, config)
+    model.train()
+    step = GraphedTrainStep(model, opt, config, B, 1024)
+    step.pts.copy_(x[:B])
+    body = lambda: step._fwd_bwd(step._draw())  # noqa: E731
 for _ in range(2):
-    step._fwd_bwd(step._draw())
+    body()
 torch.cuda.synchronize()
 with Sites() as s:
-    tvis = step._draw()
-    step._fwd_bwd(tvis)
+    body()
 torch.cuda.synchronize()
 for short, shapes, frames in s.rows:
     print('%-34s %-70s %s' % (short[:34], str(shapes)[:70], ' < '.join(reversed(frames))))
-print('ops', len(s.rows), 'tvis', tvis, 'split', step.split)
+print('ops', len(s.rows), what)
