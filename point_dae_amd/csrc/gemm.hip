@@ -45,6 +45,8 @@
 //     all tiles of a split on one XCD -- fp32 atomics into C; optional producer on
 //     B, group-list row gather, fused column sums of A = the bias gradient).
 #include <type_traits>
+#include <cstdlib>
+
 #include "common.h"
 #include "nt_args.h"
 
@@ -734,6 +736,52 @@ extern "C" int pdae_embed_conv_groupbias_stats(int M, int N, int K, const float*
   return det_reduce(s, a.tile_rows, 2 * N, a.stats_det, stats, 2 * N);
 }
 
+// The first layer of a set-abstraction level on coordinates alone (K = 4: xyz - centre and the zero pad column; sa1 of
+// Point_CAE_PointNetv2: 2.1 M rows x 64 channels): 8 FLOPs per stored float, nothing for a matrix pipe to do -- the pass is
+// its (M, N) store.  Thread = 4 adjacent channels of one row phase, weights in registers, y = fma(x3, w3, fma(x2, w2, fma(x1, w1, x0 w0)))
+// (the k-ascending FMA chain of a CPU sgemm micro-kernel: what the reference's conv computes on the host);
+// statistics as in the GEMM epilogue (float atomics into the 8 slots, or one partial row per block in deterministic mode).
+constexpr int K4_ROWS = 2048;   // rows per block
+__global__ __launch_bounds__(256) void conv_k4_stats_kernel(int M, int N, const float4* __restrict__ x, const float4* __restrict__ W,
+                                                            float* __restrict__ y, float* __restrict__ stats,
+                                                            float* __restrict__ det) {
+  extern __shared__ float k4_red[];          // [phases][2][N]
+  const int q = N >> 2, phases = 256 / q;
+  const int cq = threadIdx.x % q, ph = threadIdx.x / q;
+  const int c = cq * 4;
+  float4 w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = W[c + j];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int mbeg = blockIdx.x * K4_ROWS, mend = min(M, mbeg + K4_ROWS);
+  if (ph < phases) {
+#pragma unroll 4
+    for (int m = mbeg + ph; m < mend; m += phases) {
+      const float4 xv = x[m];
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = __builtin_fmaf(xv.w, w[j].w, __builtin_fmaf(xv.z, w[j].z, __builtin_fmaf(xv.y, w[j].y, xv.x * w[j].x)));
+        s1[j] += v[j];
+        s2[j] += v[j] * v[j];
+      }
+      *reinterpret_cast<float4*>(y + (size_t)m * N + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k4_red[(ph * 2 + 0) * N + c + j] = s1[j];
+      k4_red[(ph * 2 + 1) * N + c + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    float t = 0.f;
+    for (int p = 0; p < phases; ++p) t += k4_red[p * 2 * N + i];
+    if (det) det[(size_t)blockIdx.x * 2 * N + i] = t;
+    else atomicAdd(stats + (size_t)(blockIdx.x & 7) * 2 * N + i, t);
+  }
+}
+
 // ---- one layer of a shared MLP (Conv 1x1, no bias -> BatchNorm -> ReLU; pointnet2_modules'
 // SharedMLP): Y = act(X) . W^T with act = the PREVIOUS layer's BatchNorm + ReLU applied while X
 // is staged (scale == null: X as is), and this layer's BatchNorm statistics from the epilogue.
@@ -747,6 +795,17 @@ extern "C" int pdae_conv_stats(int M, int N, int K, const float* X, const float*
   (void)hipMemsetAsync(stats, 0, sizeof(float) * 16 * (size_t)N, s);
   if (M == 0) return check_launch("conv_stats");
   if (!X || !W || !Y) return bad_arg("conv_stats: null pointer");
+  static const bool k4_off = [] { const char* e = getenv("PDAE_CONV_K4"); return e && e[0] == '0'; }();     // (A/B)
+  if (K == 4 && !scale && !k4_off && N % 4 == 0 && N <= 1024 && 256 % (N / 4) == 0 && !(((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15)) {
+    const int blocks = (M + K4_ROWS - 1) / K4_ROWS, phases = 256 / (N / 4);
+    float* det = static_cast<float*>(det_workspace(sizeof(float) * (size_t)blocks * 2 * N, &rc));
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_k4_stats_kernel, dim3(blocks), dim3(256), sizeof(float) * phases * 2 * N, s, M, N,
+                       reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(W), Y, stats, det);
+    rc = check_launch("conv_stats");
+    if (rc || !det) return rc;
+    return det_reduce(s, blocks, 2 * N, det, stats, 2 * N);
+  }
   NtArgs a = {};
   a.M = M, a.N = N, a.K = K, a.A = X, a.lda = K, a.B = W, a.ldb = K, a.C = Y, a.ldc = N;
   a.pro_scale = scale, a.pro_shift = shift, a.stats = stats;

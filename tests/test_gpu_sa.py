@@ -186,3 +186,32 @@ def test_sa_group_rows_matches_the_index_select_form(B, N, npoint, ns, C):
         (ref * w).sum().backward()
         scale = ref_f.grad.abs().max().item()
         assert (feats.grad - ref_f.grad).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize('M,N', [(65536, 64), (2048 * 3 + 96, 128), (32, 16), (4096, 1024)])
+@pytest.mark.parametrize('det', [False, True])
+def test_first_layer_on_coordinates_alone(M, N, det):
+    """conv_stats with K = 4 (xyz - centre | 0: the first layer of a level without features) runs on its own pass
+    (csrc/gemm.hip conv_k4_stats_kernel): values against fp64, statistics against the sums of the values it stored."""
+    from point_dae_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    x = torch.randn(M, 4, device='cuda', generator=g)
+    x[:, 3] = 0
+    w = torch.randn(N, 4, device='cuda', generator=g)
+    y = torch.full((M, N), float('nan'), device='cuda')
+    st = torch.full((8, 2, N), float('nan'), device='cuda')
+    prev = _lib.deterministic()
+    _lib.set_deterministic(det)
+    try:
+        _lib.call('pdae_conv_stats', x, M, N, 4, x.data_ptr(), None, None, w.data_ptr(), y.data_ptr(), st.data_ptr())
+        if det:
+            y2, st2 = torch.empty_like(y), torch.empty_like(st)
+            _lib.call('pdae_conv_stats', x, M, N, 4, x.data_ptr(), None, None, w.data_ptr(), y2.data_ptr(), st2.data_ptr())
+            assert torch.equal(y, y2) and torch.equal(st, st2)
+    finally:
+        _lib.set_deterministic(prev)
+    want = x.double() @ w.double().t()
+    assert float((y.double() - want).abs().max()) <= 1e-6 * max(float(want.abs().max()), 1.0)
+    s = st.double().sum(0)
+    assert torch.allclose(s[0], y.double().sum(0), rtol=1e-5, atol=1e-5 * float(y.double().abs().sum(0).max()))
+    assert torch.allclose(s[1], (y.double() ** 2).sum(0), rtol=1e-5, atol=0)
