@@ -1,5 +1,7 @@
 #!/bin/bash
-# does the side-stream slice of fold_input overlap the GEMM?  kernel trace of a few cfg2 steps, start/end of the two kernels
+# start / end of the fold_input launches and the kernels around them in a few cfg2 steps (kernel trace).  Written for the
+# side-stream experiment of tools/lab/NOTES.md (fold_input in slices beside the h2 GEMM: that patch is not in the tree; on the
+# shipped step the table shows the one serial launch)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/side_overlap; rm -rf $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python bench.py --workload cfg2 --no-cpu-baseline --no-also --no-tvis-table --no-calibration --probe-steps 0 --steps 3 --warmup 3 > $OUT.log 2>&1
