@@ -132,3 +132,46 @@ def test_entries_refuse_bad_arguments():
                        ('pdae_embed_dw3_assemble', (4, 4, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t)))]:
         with pytest.raises(RuntimeError):
             _lib.call(name, t, *args)
+
+
+def test_a_step_with_the_single_launches_equals_the_step_with_framework_glue(monkeypatch):
+    """One forward + backward of the graphed step's body (depth 2 + 1, B = 8, the same mask and affine draws) with the glue as
+    library launches (csrc/glue.hip) and with the framework launches they replaced: the losses agree bit for bit (the forward
+    glue is data movement) and every gradient within 2e-6 of its tensor's largest entry (the backward's sums are re-associated:
+    partials_sum_t, dw3_assemble, the mask token's column sums)."""
+    import random
+    import numpy as np
+    from point_dae_amd import builder, graph_step, nn_ops, patch_embed
+    from point_dae_amd.config import cfg_from_yaml_file
+    from point_dae_amd.data_parallel import FlatDataParallel
+    from point_dae_amd.graph_step import GraphedTrainStep
+    from point_dae_amd.synthetic import shapenet_like_clouds
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = cfg_from_yaml_file(os.path.join(root, 'cfgs', 'pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
+    config.model.transformer_config.drop_path_rate = 0.0
+    config.model.transformer_config.depth = 2
+    config.model.transformer_config.decoder_depth = 1
+    B = 8
+    x = torch.from_numpy(shapenet_like_clouds(B, 1024, seed=9)).cuda()
+    out = []
+    for glue in (True, False):
+        monkeypatch.setattr(patch_embed, 'GLUE', glue)
+        monkeypatch.setattr(nn_ops, 'ASSEMBLE', glue)
+        monkeypatch.setattr(nn_ops, 'PREDRAW', glue)
+        monkeypatch.setattr(graph_step, 'MULTI_COPY', glue)
+        torch.manual_seed(0)
+        model = FlatDataParallel(builder.model_builder(config.model).cuda().train())
+        opt, _ = builder.build_opti_sche(model, config)
+        step = GraphedTrainStep(model, opt, config, B, 1024, warmup_eager=1)
+        step.pts.copy_(x)
+        random.seed(4), np.random.seed(4), torch.manual_seed(4)
+        lx, ln = step._fwd_bwd(step._draw())
+        torch.cuda.synchronize()
+        out.append((lx.clone(), ln.clone(), model.flat_grad.clone(), [(n, o, c) for n, (o, c) in zip(model.names, model.offsets)]))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    gmax = float(out[1][2].abs().max())          # (a conv bias that feeds a training-mode BatchNorm has an analytically zero
+    for name, off, n in out[0][3]:               #  gradient: rounding noise of either sign on both sides -> an absolute floor)
+        a, b = out[0][2][off:off + n], out[1][2][off:off + n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-7 * gmax, (name, float((a - b).abs().max()), scale, gmax)
