@@ -866,6 +866,9 @@ int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
  *                     (point_dae_amd/patch_embed.py _masked_by_algebra): xe (Gm, C3) = u + gb[masked] * v and wv (C3, C2) =
  *                     diag(v) wl, with uv (2, C3) = [u; v];  dw3 (C3, 2 C2) = [dwg | dwl + diag(v) wgram + xterm]
  *                     (v NULL: [dwg | dwl], wgram / xterm unread). */
+/*   pad2d             out (R2, C2) = in (R, C; row stride ld >= C: a column slice of a wider matrix) in the top-left corner, zeros elsewhere: the zero-padding of a ragged weight or
+ *                     of a 3-column activation to the row GEMMs' multiples of 4 (F.pad: a fill and a copy) in one launch. */
+int pdae_pad2d(int R, int C, int ld, int R2, int C2, const float* in, float* out, pdae_stream_t stream);
 int pdae_partials_sum_t(int P, int K, int C, const float* part, float* out, pdae_stream_t stream);
 int pdae_multi_copy(int n, const float* const* src, float* const* dst, const long long* counts, const int* cols /*nullable*/,
                     const int* src_ld /*nullable*/, pdae_stream_t stream);

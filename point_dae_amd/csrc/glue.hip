@@ -156,9 +156,30 @@ __global__ __launch_bounds__(256) void dw3_assemble_kernel(int C3, int C2, const
   }
 }
 
+// out (R2, C2) = in (R, C; row stride ld) in its top-left corner, zeros elsewhere (F.pad of a small weight / a column slice of one /
+// a narrow activation: was a fill + a copy)
+__global__ __launch_bounds__(256) void pad2d_kernel(long long n, int R, int C, int ld, int C2, const float* __restrict__ in,
+                                                    float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long r = i / C2;
+  const int c = (int)(i - r * C2);
+  out[i] = (r < R && c < C) ? in[r * ld + c] : 0.f;
+}
+
 }  // namespace pdae
 
 using namespace pdae;
+
+extern "C" int pdae_pad2d(int R, int C, int ld, int R2, int C2, const float* in, float* out, pdae_stream_t stream) {
+  if (R < 0 || C < 0 || ld < C || R2 < R || C2 < C || C2 <= 0) return bad_arg("pad2d: 0 <= R <= R2, 0 <= C <= C2, C <= ld, C2 > 0");
+  if (R2 == 0) return PDAE_OK;
+  if (!out || (R > 0 && C > 0 && !in)) return bad_arg("pad2d: null pointer");
+  const long long n = (long long)R2 * C2;
+  if ((n + 255) / 256 > 0x7fffffffLL) return unsupported("pad2d: too many elements");
+  hipLaunchKernelGGL(pad2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), n, R, C, ld, C2, in, out);
+  return check_launch("pad2d");
+}
 
 extern "C" int pdae_partials_sum_t(int P, int K, int C, const float* part, float* out, pdae_stream_t stream) {
   if (P < 0 || K <= 0 || C <= 0) return bad_arg("partials_sum_t: bad size");

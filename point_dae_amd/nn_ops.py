@@ -695,6 +695,38 @@ class _FoldMLP(torch.autograd.Function):
         return (dp.view(clouds, coarse, C).sum(1), dp, part.sum(0), None, dw2, db2, dw3, db3, None, None, None)
 
 
+class _Pad2d(torch.autograd.Function):
+    """x (R, C) [or (C,)] -> (R + pr, C + pc) with zeros, one launch (csrc/glue.hip pad2d; F.pad is a fill + a copy)."""
+
+    @staticmethod
+    def forward(ctx, x, pr, pc):
+        one_d = x.dim() == 1
+        x2 = x.reshape(1, -1) if one_d else x
+        if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+            x2 = x2.contiguous()                        # (a column slice of a row-major matrix is read through its row stride)
+        R, C = x2.shape
+        ld = x2.stride(0) if R > 1 else C
+        out = _empty((R + pr, C + pc), x2)
+        _lib.call('pdae_pad2d', x2, R, C, ld, R + pr, C + pc, _lib.ptr(x2), _lib.ptr(out))
+        ctx.dims = (R, C, one_d)
+        return out.reshape(-1) if one_d else out
+
+    @staticmethod
+    def backward(ctx, g):
+        R, C, one_d = ctx.dims
+        return (g[:C] if one_d else g[:R, :C]), None, None
+
+
+PAD2D = os.environ.get('PDAE_PAD2D', os.environ.get('PDAE_GLUE', '1')) != '0'
+
+
+def pad2d(x, pr, pc):
+    """zero rows below / zero columns right of a 1-D or 2-D fp32 device tensor (1-D: pc elements appended)."""
+    if not PAD2D or not x.is_cuda or x.dtype != torch.float32 or x.dim() not in (1, 2):
+        return F.pad(x, (0, pc, 0, pr)) if x.dim() == 2 else F.pad(x, (0, pc))
+    return _Pad2d.apply(x, pr, pc)
+
+
 def fold_mlp(a, p, gd, conv2, conv3, clouds, coarse, cells, row_term=None):
     """-> (clouds*coarse*cells, 3) offsets; conv2 / conv3 = the stage's second and third Conv1d (kernel 1).
     First-layer terms: a (clouds, C) per cloud, p (clouds*coarse, C) per coarse point / patch, gd (cells, C) per
@@ -703,7 +735,7 @@ def fold_mlp(a, p, gd, conv2, conv3, clouds, coarse, cells, row_term=None):
     n = w3.shape[0]
     pn = (-n) % 4
     if pn:                                              # 3 output coordinates: a zero fourth row
-        w3, b3 = F.pad(w3, (0, 0, 0, pn)), F.pad(b3, (0, pn))
+        w3, b3 = pad2d(w3, pn, 0), pad2d(b3, 0, pn)
     y = _FoldMLP.apply(a, p, gd, row_term, conv2.weight.squeeze(-1), conv2.bias, w3, b3, clouds, coarse, cells)
     return y[:, :n] if pn else y
 
@@ -723,11 +755,11 @@ def linear_any(x, w, b=None, relu=False):
     pk, pn = (-K) % 4, (-N) % 4
     if pk:
         if x.shape[1] == K:
-            x = F.pad(x, (0, pk))
-        w = F.pad(w, (0, pk))
+            x = pad2d(x, 0, pk)
+    if pk or pn:
+        w = pad2d(w, pn, pk)                            # (both paddings of the weight in one launch)
     if pn:
-        w = F.pad(w, (0, 0, 0, pn))
-        b = F.pad(b, (0, pn)) if b is not None else None
+        b = pad2d(b, 0, pn) if b is not None else None
     y = _Linear.apply(x, w, b, relu)
     return y[:, :N] if pn else y
 

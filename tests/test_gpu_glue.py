@@ -175,3 +175,23 @@ def test_a_step_with_the_single_launches_equals_the_step_with_framework_glue(mon
         a, b = out[0][2][off:off + n], out[1][2][off:off + n]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-6 * scale + 1e-7 * gmax, (name, float((a - b).abs().max()), scale, gmax)
+
+
+@pytest.mark.parametrize('R,C,pr,pc', [(384, 3, 0, 1), (3, 384, 1, 0), (5, 6, 3, 2), (131072, 3, 0, 1)])
+def test_pad2d_and_its_gradient(R, C, pr, pc):
+    import torch.nn.functional as F
+    from point_dae_amd import nn_ops
+    x = _rand(R, C).requires_grad_(True)
+    y = nn_ops.pad2d(x, pr, pc)
+    assert torch.equal(y, F.pad(x.detach(), (0, pc, 0, pr)))
+    w = _rand(R + pr, C + pc, seed=1)
+    (y * w).sum().backward()
+    assert torch.equal(x.grad, w[:R, :C])
+    # a column slice of a wider matrix (read through its row stride) and a 1-D tensor
+    wide = _rand(R, C + 5, seed=2)
+    assert torch.equal(nn_ops.pad2d(wide[:, 2:2 + C], pr, pc), F.pad(wide[:, 2:2 + C], (0, pc, 0, pr)))
+    b = _rand(C, seed=3).requires_grad_(True)
+    yb = nn_ops.pad2d(b, 0, pc)
+    assert torch.equal(yb, F.pad(b.detach(), (0, pc)))
+    yb.sum().backward()
+    assert torch.equal(b.grad, torch.ones(C, device='cuda'))
