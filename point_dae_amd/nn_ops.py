@@ -631,6 +631,20 @@ def mlp_chain(x, layers):
     return _MLPChain.apply(x, *params)
 
 
+FOLD_SUMS = os.environ.get('PDAE_FOLD_SUMS', os.environ.get('PDAE_GLUE', '1')) != '0'     # (A/B: 0 = at::sum)
+
+
+def _partials_sum(part):
+    """part (P, ...) -> its sum over P in a fixed order (csrc/glue.hip partials_sum_t with one row: 16 strided lane sums per
+    column, then the lanes; at::sum's reduce kernel took 11-24 us on these shapes)."""
+    if not FOLD_SUMS or not part.is_cuda or part.dtype != torch.float32 or not part.is_contiguous() or part.shape[0] == 0:
+        return part.sum(0)
+    n = part[0].numel()
+    out = _empty(tuple(part.shape[1:]), part)
+    _lib.call('pdae_partials_sum_t', part, part.shape[0], 1, n, _lib.ptr(part), _lib.ptr(out))
+    return out
+
+
 class _FoldMLP(torch.autograd.Function):
     """The FoldingNet stage of Point_CAE_PointNetv2 (models/PointCAE_pointnetv2.py:157-167: folding2 =
     Conv1d(1029,512) ReLU Conv1d(512,512) ReLU Conv1d(512,3)) on rows, given the first conv's three
@@ -673,7 +687,7 @@ class _FoldMLP(torch.autograd.Function):
             d2, part = torch.empty_like(h2), _empty((parts, 4, C), dy)
             _lib.call('pdae_fold_out_backward', dy, dy.shape[0], C, _lib.ptr(dy), _lib.ptr(h2), _lib.ptr(w3.contiguous()),
                       _lib.ptr(d2), _lib.ptr(part))
-            dw3, db3 = part.sum(0), dy.sum(0)
+            dw3, db3 = _partials_sum(part), dy.sum(0)
         else:
             d2 = rows_gemm(dy, w3, True, None, 4, h2)               # gradient of h2's pre-activation
             (dw3,), (db3,) = rows_wgrad([dy], [h2], [True])
@@ -692,7 +706,8 @@ class _FoldMLP(torch.autograd.Function):
         dp = _empty((clouds * coarse, C), dy)
         part = _empty((parts, cells, C), dy)
         _lib.call('pdae_fold_input_grad', dy, clouds, coarse, cells, C, _lib.ptr(d1), _lib.ptr(dp), _lib.ptr(part))
-        return (dp.view(clouds, coarse, C).sum(1), dp, part.sum(0), None, dw2, db2, dw3, db3, None, None, None)
+        da = dp.view(clouds, coarse, C).sum(1) if ctx.needs_input_grad[0] else None     # (a constant zero term has no gradient)
+        return (da, dp, _partials_sum(part), None, dw2, db2, dw3, db3, None, None, None)
 
 
 class _Pad2d(torch.autograd.Function):
