@@ -868,6 +868,11 @@ int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
  *                     (v NULL: [dwg | dwl], wgram / xterm unread). */
 /*   pad2d             out (R2, C2) = in (R, C; row stride ld >= C: a column slice of a wider matrix) in the top-left corner, zeros elsewhere: the zero-padding of a ragged weight or
  *                     of a 3-column activation to the row GEMMs' multiples of 4 (F.pad: a fill and a copy) in one launch. */
+/*   max_plus_mean     out (B, C) = max over t + mean over t of x (B, T, C), arg (B, C) = the first t of the maximum (uint8, T <= 255):
+ *                     the published variant's global feature (models/PointCAE_transformer.py:1024 `x_vis.max(dim=1)[0] +
+ *                     x_vis.mean(1)`); _grad: dx = g (1 / T + [t == arg]). */
+int pdae_max_plus_mean(int B, int T, int C, const float* x, float* out, uint8_t* arg, pdae_stream_t stream);
+int pdae_max_plus_mean_grad(int B, int T, int C, const float* g, const uint8_t* arg, float* dx, pdae_stream_t stream);
 int pdae_pad2d(int R, int C, int ld, int R2, int C2, const float* in, float* out, pdae_stream_t stream);
 int pdae_partials_sum_t(int P, int K, int C, const float* part, float* out, pdae_stream_t stream);
 int pdae_multi_copy(int n, const float* const* src, float* const* dst, const long long* counts, const int* cols /*nullable*/,

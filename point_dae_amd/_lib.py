@@ -116,6 +116,8 @@ _SIGNATURES = {
     "pdae_rows_gemm_bnrelu_stats": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_backward_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "pdae_bnrelu_backward_listed_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
+    "pdae_max_plus_mean": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_max_plus_mean_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_pad2d": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_partials_sum_t": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_multi_copy": [_i, _vp, _vp, _vp, _vp, _vp, _vp],

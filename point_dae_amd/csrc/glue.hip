@@ -167,9 +167,58 @@ __global__ __launch_bounds__(256) void pad2d_kernel(long long n, int R, int C, i
   out[i] = (r < R && c < C) ? in[r * ld + c] : 0.f;
 }
 
+// out[b][c] = max_t x[b][t][c] + mean_t x[b][t][c] (the published variant's global feature, models/PointCAE_transformer.py:1024:
+// x.max(dim=1)[0] + x.mean(1)); arg[b][c] = the first t of the maximum.  Backward: dx[b][t][c] = g[b][c] (1 / T + [t == arg]).
+__global__ __launch_bounds__(256) void max_plus_mean_kernel(int n, int T, int C, const float* __restrict__ x, float* __restrict__ out,
+                                                            unsigned char* __restrict__ arg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;            // i = b * C + c
+  if (i >= n) return;
+  const int b = i / C, c = i - b * C;
+  const float* p = x + (size_t)b * T * C + c;
+  float m = p[0], s = p[0];
+  int a = 0;
+  for (int t = 1; t < T; ++t) {
+    const float v = p[(size_t)t * C];
+    s += v;
+    if (v > m) m = v, a = t;
+  }
+  out[i] = m + s / (float)T;
+  arg[i] = (unsigned char)a;
+}
+
+__global__ __launch_bounds__(256) void max_plus_mean_grad_kernel(long long n, int T, int C, const float* __restrict__ g,
+                                                                 const unsigned char* __restrict__ arg, float* __restrict__ dx) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // i = (b * T + t) * C + c
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long long bt = i / C;
+  const int t = (int)(bt % T);
+  const long long b = bt / T;
+  const float gv = g[b * C + c];
+  dx[i] = gv / (float)T + (arg[b * C + c] == t ? gv : 0.f);
+}
+
 }  // namespace pdae
 
 using namespace pdae;
+
+extern "C" int pdae_max_plus_mean(int B, int T, int C, const float* x, float* out, unsigned char* arg, pdae_stream_t stream) {
+  if (B < 0 || T <= 0 || T > 255 || C <= 0 || (long long)B * C >= (1LL << 31)) return bad_arg("max_plus_mean: 1 <= T <= 255");
+  if (B == 0) return PDAE_OK;
+  if (!x || !out || !arg) return bad_arg("max_plus_mean: null pointer");
+  hipLaunchKernelGGL(max_plus_mean_kernel, dim3((B * C + 255) / 256), dim3(256), 0, as_stream(stream), B * C, T, C, x, out, arg);
+  return check_launch("max_plus_mean");
+}
+
+extern "C" int pdae_max_plus_mean_grad(int B, int T, int C, const float* g, const unsigned char* arg, float* dx, pdae_stream_t stream) {
+  if (B < 0 || T <= 0 || T > 255 || C <= 0) return bad_arg("max_plus_mean_grad: 1 <= T <= 255");
+  if (B == 0) return PDAE_OK;
+  if (!g || !arg || !dx) return bad_arg("max_plus_mean_grad: null pointer");
+  const long long n = (long long)B * T * C;
+  if ((n + 255) / 256 > 0x7fffffffLL) return unsupported("max_plus_mean_grad: too many elements");
+  hipLaunchKernelGGL(max_plus_mean_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), n, T, C, g, arg, dx);
+  return check_launch("max_plus_mean_grad");
+}
 
 extern "C" int pdae_pad2d(int R, int C, int ld, int R2, int C2, const float* in, float* out, pdae_stream_t stream) {
   if (R < 0 || C < 0 || ld < C || R2 < R || C2 < C || C2 <= 0) return bad_arg("pad2d: 0 <= R <= R2, 0 <= C <= C2, C <= ld, C2 > 0");

@@ -710,6 +710,36 @@ class _FoldMLP(torch.autograd.Function):
         return (da, dp, _partials_sum(part), None, dw2, db2, dw3, db3, None, None, None)
 
 
+class _MaxPlusMean(torch.autograd.Function):
+    """x (B, T, C) -> max over T + mean over T (B, C), one launch each way (csrc/glue.hip max_plus_mean)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, T, C = x.shape
+        out, arg = _empty((B, C), x), _empty((B, C), x, torch.uint8)
+        _lib.call('pdae_max_plus_mean', x, B, T, C, _lib.ptr(x), _lib.ptr(out), _lib.ptr(arg))
+        ctx.save_for_backward(arg)
+        ctx.T = T
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, C = g.shape
+        dx = _empty((B, ctx.T, C), g)
+        _lib.call('pdae_max_plus_mean_grad', g, B, ctx.T, C, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(dx))
+        return dx
+
+
+def max_plus_mean(x):
+    """x.max(dim=1)[0] + x.mean(1) for x (B, T, C)."""
+    if not PAD2D or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or not 0 < x.shape[1] <= 255:
+        return x.max(dim=1)[0] + x.mean(1)
+    return _MaxPlusMean.apply(x)
+
+
 class _Pad2d(torch.autograd.Function):
     """x (R, C) [or (C,)] -> (R + pr, C + pc) with zeros, one launch (csrc/glue.hip pad2d; F.pad is a fill + a copy)."""
 

@@ -405,7 +405,7 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
                 rows=None, **kwargs):
         t = self.trunk(pts, mask=mask, steps=steps, rows=rows, encoder_only=return_feat)
         x_vis = t['x_vis']
-        global_feature = x_vis.max(dim=1)[0] + x_vis.mean(1)                       # (B, C), :1024
+        global_feature = nn_ops.max_plus_mean(x_vis)                               # (B, C), :1024: x.max(dim=1)[0] + x.mean(1)
         if return_feat:
             return global_feature
         B, R, C = t['B'], t['R'], t['C']

@@ -195,3 +195,17 @@ def test_pad2d_and_its_gradient(R, C, pr, pc):
     assert torch.equal(yb, F.pad(b.detach(), (0, pc)))
     yb.sum().backward()
     assert torch.equal(b.grad, torch.ones(C, device='cuda'))
+
+
+@pytest.mark.parametrize('B,T,C', [(128, 23, 384), (3, 1, 8), (2, 255, 5)])
+def test_max_plus_mean_and_its_gradient(B, T, C):
+    from point_dae_amd import nn_ops
+    x = _rand(B, T, C).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    out = nn_ops.max_plus_mean(x)
+    want = x2.max(dim=1)[0] + x2.mean(1)
+    assert torch.allclose(out, want, rtol=0, atol=2e-6 * float(want.abs().max()))
+    w = _rand(B, C, seed=1)
+    (out * w).sum().backward()
+    (want * w).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, rtol=0, atol=2e-7 * float(x2.grad.abs().max()))
