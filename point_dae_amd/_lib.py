@@ -118,6 +118,7 @@ _SIGNATURES = {
     "pdae_bnrelu_backward_listed_apply": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "pdae_max_plus_mean": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "pdae_max_plus_mean_grad": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "pdae_hcat": [_i, _i, _vp, _vp, _vp, _vp, _vp],
     "pdae_pad2d": [_i, _i, _i, _i, _i, _vp, _vp, _vp],
     "pdae_partials_sum_t": [_i, _i, _i, _vp, _vp, _vp],
     "pdae_multi_copy": [_i, _vp, _vp, _vp, _vp, _vp, _vp],

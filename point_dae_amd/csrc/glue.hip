@@ -198,9 +198,47 @@ __global__ __launch_bounds__(256) void max_plus_mean_grad_kernel(long long n, in
   dx[i] = gv / (float)T + (arg[b * C + c] == t ? gv : 0.f);
 }
 
+// out (R, C) = [p0 | p1 | ...]: up to four row-major pieces side by side, piece q = cols[q] columns read through row stride ld[q]
+// (the gradient of a weight that was used as column blocks: was a zero fill + a copy per block and the adds of autograd)
+struct HcatArgs {
+  int n, R, C;
+  const float* src[4];
+  int cols[4], ld[4], at[4];
+};
+__global__ __launch_bounds__(256) void hcat_kernel(const HcatArgs a, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.R * a.C) return;
+  const long long r = i / a.C;
+  const int c = (int)(i - r * a.C);
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (q < a.n && c >= a.at[q] && c < a.at[q] + a.cols[q]) v = a.src[q][r * a.ld[q] + (c - a.at[q])];
+  out[i] = v;
+}
+
 }  // namespace pdae
 
 using namespace pdae;
+
+extern "C" int pdae_hcat(int n, int R, const float* const* src, const int* cols, const int* ld, float* out, pdae_stream_t stream) {
+  if (n <= 0 || n > 4 || R < 0 || !src || !cols || !ld) return bad_arg("hcat: 1..4 pieces");
+  HcatArgs a = {};
+  a.n = n, a.R = R;
+  int at = 0;
+  for (int q = 0; q < n; ++q) {
+    if (cols[q] <= 0 || ld[q] < cols[q] || !src[q]) return bad_arg("hcat: bad piece");
+    a.src[q] = src[q], a.cols[q] = cols[q], a.ld[q] = ld[q], a.at[q] = at;
+    at += cols[q];
+  }
+  a.C = at;
+  if (R == 0) return PDAE_OK;
+  if (!out) return bad_arg("hcat: null pointer");
+  const long long n_el = (long long)R * at;
+  if ((n_el + 255) / 256 > 0x7fffffffLL) return unsupported("hcat: too many elements");
+  hipLaunchKernelGGL(hcat_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, as_stream(stream), a, out);
+  return check_launch("hcat");
+}
 
 extern "C" int pdae_max_plus_mean(int B, int T, int C, const float* x, float* out, unsigned char* arg, pdae_stream_t stream) {
   if (B < 0 || T <= 0 || T > 255 || C <= 0 || (long long)B * C >= (1LL << 31)) return bad_arg("max_plus_mean: 1 <= T <= 255");

@@ -230,6 +230,8 @@ class GraphedTrainStep:
             return lx
         if lt == 'normal':
             return self.w_dev * ln.sum()
+        if ln.numel() == 1 and lx.numel() == 1:                   # lx + w * ln as ONE launch (was sum, mul, add)
+            return torch.addcmul(lx.reshape(()), self.w_dev, ln.reshape(()))
         return lx + self.w_dev * ln.sum()
 
     def _draw(self, tvis=None):

@@ -12,6 +12,7 @@ csrc/{attention,block}.hip.  A whole pre-LN block is ONE autograd Function
 block's four weight gradients as one grouped launch.
 Parameters are read from the reference-layout nn.Modules that own them.
 """
+import ctypes
 import os
 
 import torch
@@ -738,6 +739,51 @@ def max_plus_mean(x):
     if not PAD2D or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or not 0 < x.shape[1] <= 255:
         return x.max(dim=1)[0] + x.mean(1)
     return _MaxPlusMean.apply(x)
+
+
+class _SplitWeightCols(torch.autograd.Function):
+    """w (R, C) -> its column blocks [b0, b1), ... as separate contiguous operands, each zero-padded to a multiple of 4 columns
+    (one launch per block: pad2d reads the block through w's row stride); backward: the blocks' gradients side by side as dW
+    in ONE launch (csrc/glue.hip hcat) -- autograd's own path is a zero fill + a copy per block and the adds between them."""
+
+    @staticmethod
+    def forward(ctx, w, *bounds):
+        w = w.contiguous()
+        R, C = w.shape
+        outs = []
+        for b0, b1 in zip(bounds[0::2], bounds[1::2]):
+            n = b1 - b0
+            o = _empty((R, n + (-n) % 4), w)
+            _lib.call('pdae_pad2d', w, R, n, C, R, o.shape[1], w.data_ptr() + 4 * b0, _lib.ptr(o))
+            outs.append(o)
+        ctx.bounds, ctx.shape = bounds, (R, C)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        R, C = ctx.shape
+        widths = [b1 - b0 for b0, b1 in zip(ctx.bounds[0::2], ctx.bounds[1::2])]
+        gs = [g.contiguous() if g is not None else None for g in gs]
+        like = next(g for g in gs if g is not None)
+        srcs = [g if g is not None else torch.zeros((R, n + (-n) % 4), device=like.device) for g, n in zip(gs, widths)]
+        k = len(srcs)
+        dw = _empty((R, C), like)
+        parr, iarr = ctypes.c_void_p * k, ctypes.c_int * k
+        _lib.call('pdae_hcat', like, k, R, parr(*[_lib.ptr(t) for t in srcs]), iarr(*widths), iarr(*[t.shape[1] for t in srcs]),
+                  _lib.ptr(dw))
+        return (dw,) + (None,) * len(ctx.bounds)
+
+
+def split_weight_cols(w, bounds):
+    """w (R, C), bounds = [(b0, b1), ...] covering 0..C in order, at most four -> the column blocks as contiguous (R, width padded
+    to a multiple of 4) operands."""
+    flat = [v for b in bounds for v in b]
+    ok = (PAD2D and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and 1 <= len(bounds) <= 4 and flat[0] == 0
+          and flat[-1] == w.shape[1] and all(flat[2 * i + 1] == flat[2 * i + 2] for i in range(len(bounds) - 1))
+          and all(b1 > b0 for b0, b1 in bounds))
+    if not ok:
+        return tuple(pad2d(w[:, b0:b1], 0, (-(b1 - b0)) % 4) for b0, b1 in bounds)
+    return _SplitWeightCols.apply(w, *flat)
 
 
 class _Pad2d(torch.autograd.Function):

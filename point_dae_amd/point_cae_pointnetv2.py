@@ -205,9 +205,10 @@ class Point_CAE_PointNetv2(nn.Module):
         # folding2[0] on [grid(2) | coarse point(3) | global feature(1024)], split by column block
         w = self.folding2[0].weight.squeeze(-1)                                # (512, 1029)
         g2 = self.grid_size ** 2
-        a = nn_ops.linear_any(feature, w[:, 5:].contiguous(), self.folding2[0].bias)        # (B, 512)  once per cloud
-        p = nn_ops.linear_any(coarse.reshape(-1, 3), w[:, 2:5]).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
-        gd = nn_ops.linear_any(self.grid, w[:, :2])                            # (16, 512)     once per grid cell
+        wg, wc, wf = nn_ops.split_weight_cols(w, [(0, 2), (2, 5), (5, w.shape[1])])          # (narrow blocks padded to 4 columns)
+        a = nn_ops.linear_any(feature, wf, self.folding2[0].bias)                           # (B, 512)  once per cloud
+        p = nn_ops.linear_any(nn_ops.pad2d(coarse.reshape(-1, 3), 0, 1), wc).reshape(B, self.num_coarse, 1, -1)   # once per coarse point
+        gd = nn_ops.linear_any(nn_ops.pad2d(self.grid, 0, 2), wg)               # (16, 512)     once per grid cell
         off = nn_ops.fold_mlp(a, p.reshape(B * self.num_coarse, -1), gd, self.folding2[2], self.folding2[4],
                               B, self.num_coarse, g2)
         fine = off.reshape(B, self.num_coarse, g2, 3) + coarse.unsqueeze(2)

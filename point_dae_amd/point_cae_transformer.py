@@ -394,11 +394,16 @@ class PointCAE_transformer_fc_global_folding_local(PointCAE_transformer):
         patch, extra (P, 36, e) or (36, e) per point.  -> (P*36, 3)."""
         C = tok.shape[1]
         w = stage[0].weight.squeeze(-1)
-        a = nn_ops.linear_any(tok, w[:, :C].contiguous(), stage[0].bias)                  # (P, C) once per patch
-        e = nn_ops.linear_any(extra.reshape(-1, extra.shape[-1]), w[:, C:C + extra_w_cols])
+        # the conv's two column blocks as separate operands (the narrow one zero-padded to 4 columns), their gradients put back
+        # side by side in one launch (nn_ops.split_weight_cols)
+        wa, we = nn_ops.split_weight_cols(w, [(0, C), (C, C + extra_w_cols)])
+        a = nn_ops.linear_any(tok, wa, stage[0].bias)                                     # (P, C) once per patch
+        xe = extra.reshape(-1, extra.shape[-1])
+        e = nn_ops.linear_any(nn_ops.pad2d(xe, 0, we.shape[1] - xe.shape[1]) if we.shape[1] != xe.shape[1] else xe, we)
         P, cells = tok.shape[0], extra.shape[-2]
         if extra.dim() == 2:            # one term per grid cell: the fused first layer (csrc/folding.hip)
-            return nn_ops.fold_mlp(a.new_zeros(1, C), a, e, stage[2], stage[4], 1, P, cells)
+            # (no per-cloud term here: a row of the step's pre-zeroed arena, no fill launch)
+            return nn_ops.fold_mlp(nn_ops.arena.take(C, a)[0].view(1, C), a, e, stage[2], stage[4], 1, P, cells)
         return nn_ops.fold_mlp(None, a, None, stage[2], stage[4], 1, P, cells, row_term=e)   # one term per point
 
     def forward(self, corrupted_pts, pts, vis=False, return_feat=False, mask=None, steps=None, capture=None,

@@ -209,3 +209,25 @@ def test_max_plus_mean_and_its_gradient(B, T, C):
     (out * w).sum().backward()
     (want * w).sum().backward()
     assert torch.allclose(x.grad, x2.grad, rtol=0, atol=2e-7 * float(x2.grad.abs().max()))
+
+
+@pytest.mark.parametrize('R,bounds', [(384, [(0, 384), (384, 386)]), (512, [(0, 2), (2, 5), (5, 1029)]), (8, [(0, 3)]),
+                                      (16, [(0, 4), (4, 5), (5, 9), (9, 12)])])
+def test_split_weight_cols_and_its_gradient(R, bounds):
+    import torch.nn.functional as F
+    from point_dae_amd import nn_ops
+    C = bounds[-1][1]
+    w = _rand(R, C).requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    got = nn_ops.split_weight_cols(w, bounds)
+    want = [F.pad(w2[:, b0:b1], (0, (-(b1 - b0)) % 4)) for b0, b1 in bounds]
+    loss_a = loss_b = 0
+    for i, (g, x) in enumerate(zip(got, want)):
+        assert torch.equal(g, x)
+        m = _rand(*g.shape, seed=i)
+        if i != 1:                                        # (one block without a gradient: its columns of dW are zero)
+            loss_a = loss_a + (g * m).sum()
+            loss_b = loss_b + (x * m).sum()
+    loss_a.backward()
+    loss_b.backward()
+    assert torch.equal(w.grad, w2.grad)
