@@ -1,6 +1,7 @@
 """Soak: N optimisation steps, eager vs hipGraph replay, same seeds; prints the loss every 25 steps.
     python tools/soak.py graph|eager STEPS [B]      env SOAK_POKE=cpu|save_opt|...: a host action at step 50
-    SOAK_NULL=1 SOAK_POKE=cpu python tools/soak.py graph 100   -> the NULL-stream failure (garbage losses)"""
+    SOAK_NULL=1 SOAK_POKE=cpu python tools/soak.py graph 100   -> the NULL-stream failure (garbage losses)
+    SOAK_MODEL=<registered model name>: another Transformer variant on the same YAML"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +18,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = cfg_from_yaml_file(os.path.join(ROOT, 'cfgs/pretrain_PointCAE_transformer_dropout_patch_affine_r3_maskpatch_p0005_whole.yaml'))
 cfg.npoints = 1024
+if os.environ.get('SOAK_MODEL'):                 # e.g. PointCAE_transformer_fc_global_folding_local (the published variant)
+    cfg.model.NAME = os.environ['SOAK_MODEL']
 dev = torch.device('cuda')
 set_random_seed(0)
 model = FlatDataParallel(builder.model_builder(cfg.model).to(dev))
