@@ -874,7 +874,7 @@ int pdae_colsum(int M, int N, const float* X, float* out, int accumulate,
 int pdae_max_plus_mean(int B, int T, int C, const float* x, float* out, uint8_t* arg, pdae_stream_t stream);
 int pdae_max_plus_mean_grad(int B, int T, int C, const float* g, const uint8_t* arg, float* dx, pdae_stream_t stream);
 /*   hcat              out (R, sum cols) = up to four row-major pieces side by side, piece q read through row stride ld[q] >= cols[q]
- *                     (src, cols, ld: HOST arrays): the gradient of a conv weight whose column blocks were used as separate
+ *                     (src, cols, ld: HOST arrays; src[q] NULL: cols[q] zero columns): the gradient of a conv weight whose column blocks were used as separate
  *                     operands (models/PointCAE_transformer.py:1040-1059 folding1/2[0] on [token | grid or point];
  *                     models/PointCAE_pointnetv2.py:157-167 folding2[0] on [grid | coarse point | feature]) in one launch. */
 int pdae_hcat(int n, int R, const float* const* src, const int* cols, const int* ld, float* out, pdae_stream_t stream);

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void hcat_kernel(const HcatArgs a, float* __re
   float v = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    if (q < a.n && c >= a.at[q] && c < a.at[q] + a.cols[q]) v = a.src[q][r * a.ld[q] + (c - a.at[q])];
+    if (q < a.n && a.src[q] && c >= a.at[q] && c < a.at[q] + a.cols[q]) v = a.src[q][r * a.ld[q] + (c - a.at[q])];   // (no source: zeros)
   out[i] = v;
 }
 
@@ -227,7 +227,7 @@ extern "C" int pdae_hcat(int n, int R, const float* const* src, const int* cols,
   a.n = n, a.R = R;
   int at = 0;
   for (int q = 0; q < n; ++q) {
-    if (cols[q] <= 0 || ld[q] < cols[q] || !src[q]) return bad_arg("hcat: bad piece");
+    if (cols[q] <= 0 || (src[q] && ld[q] < cols[q])) return bad_arg("hcat: bad piece");
     a.src[q] = src[q], a.cols[q] = cols[q], a.ld[q] = ld[q], a.at[q] = at;
     at += cols[q];
   }

@@ -774,6 +774,42 @@ class _SplitWeightCols(torch.autograd.Function):
         return (dw,) + (None,) * len(ctx.bounds)
 
 
+def _hcat(pieces, R, like):
+    """pieces: [(2-D tensor or None, cols)] -> (R, sum cols) with the pieces' leading columns side by side (None: zeros)."""
+    k = len(pieces)
+    out = _empty((R, sum(c for _, c in pieces)), like)
+    parr, iarr = ctypes.c_void_p * k, ctypes.c_int * k
+    _lib.call('pdae_hcat', like, k, R, parr(*[_lib.ptr(t) for t, _ in pieces]), iarr(*[c for _, c in pieces]),
+              iarr(*[(t.stride(0) if t is not None else c) for t, c in pieces]), _lib.ptr(out))
+    return out
+
+
+class _InsertZeroCol(torch.autograd.Function):
+    """w (R, C) -> (R, C + 1) with a zero column at `at` (the pad column of a set-abstraction level's first weight: the grouped
+    rows are [xyz - centre | 0 | features]); one launch each way (was new_zeros + cat, and two slice gradients + their add)."""
+
+    @staticmethod
+    def forward(ctx, w, at):
+        w = w.contiguous()
+        R, C = w.shape
+        ctx.at, ctx.shape = at, (R, C)
+        pieces = [(w, at), (None, 1)] + ([(w[:, at:], C - at)] if C > at else [])
+        return _hcat(pieces, R, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        R, C = ctx.shape
+        g = g.contiguous()
+        pieces = [(g, ctx.at)] + ([(g[:, ctx.at + 1:], C - ctx.at)] if C > ctx.at else [])
+        return _hcat(pieces, R, g), None
+
+
+def insert_zero_col(w, at):
+    if not PAD2D or not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not 0 < at <= w.shape[1]:
+        return torch.cat([w[:, :at], w.new_zeros(w.shape[0], 1), w[:, at:]], dim=1)
+    return _InsertZeroCol.apply(w, at)
+
+
 def split_weight_cols(w, bounds):
     """w (R, C), bounds = [(b0, b1), ...] covering 0..C in order, at most four -> the column blocks as contiguous (R, width padded
     to a multiple of 4) operands."""

@@ -125,7 +125,8 @@ def shared_mlp_max(x, layers, ns, pad_at=None):
     for i, layer in enumerate(layers):
         w = layer.conv.weight.reshape(layer.conv.weight.shape[0], -1)
         if i == 0 and pad_at is not None:
-            w = torch.cat([w[:, :pad_at], w.new_zeros(w.shape[0], 1), w[:, pad_at:]], dim=1)
+            from .nn_ops import insert_zero_col
+            w = insert_zero_col(w, pad_at)
         bn = layer.bn.bn
         params += [w, bn.weight, bn.bias]
         bns.append(bn)

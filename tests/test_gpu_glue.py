@@ -231,3 +231,17 @@ def test_split_weight_cols_and_its_gradient(R, bounds):
     loss_a.backward()
     loss_b.backward()
     assert torch.equal(w.grad, w2.grad)
+
+
+@pytest.mark.parametrize('R,C,at', [(64, 3, 3), (128, 131, 3), (256, 259, 3), (5, 7, 2)])
+def test_insert_zero_col_and_its_gradient(R, C, at):
+    from point_dae_amd import nn_ops
+    w = _rand(R, C).requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    got = nn_ops.insert_zero_col(w, at)
+    want = torch.cat([w2[:, :at], w2.new_zeros(R, 1), w2[:, at:]], dim=1)
+    assert torch.equal(got, want)
+    m = _rand(R, C + 1, seed=1)
+    (got * m).sum().backward()
+    (want * m).sum().backward()
+    assert torch.equal(w.grad, w2.grad)
